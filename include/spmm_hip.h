@@ -1,0 +1,144 @@
+/* spmm_hip.h -- C ABI of libspmm_hip.so: the MI355X (gfx950) kernels behind the SPMM pretraining step.
+ *
+ * The reference (jinhojsk515/spmm) is pure Python on stock torch ops and has no FFI layer of its own; this ABI is
+ * the boundary introduced beneath its Python class API.  Each entry point names the
+ * reference code it replaces (file:line under /root/reference).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to call these from SPMM_models.py / xbert.py.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch allocates; the
+ *    library never allocates, frees or retains device memory).
+ *  - "bf16" tensors are raw 16-bit bfloat16, passed as void*.  Token-major activations: row = seq * L + pos.
+ *  - every call is asynchronous on `stream` (a hipStream_t); no call synchronises or reads device data on the host.
+ *  - return value: 0 ok, 1 bad shape/argument, 2 HIP launch failure, 3 unsupported; message via spmm_last_error()
+ *    (thread local).  No C++ exception crosses the boundary.
+ *  - scalars that change from step to step (alpha, temp, lr, dropout seed, queue pointer, loss-gradient scales)
+ *    are read from device memory so that a whole training step can be captured once into a hipGraph and replayed.
+ */
+#ifndef SPMM_HIP_H
+#define SPMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+typedef hipStream_t spmm_stream_t;
+#else
+typedef void* spmm_stream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int spmm_version(void);
+const char* spmm_last_error(void);
+
+/* epilogues of spmm_gemm_nt */
+#define SPMM_EPI_BF16 0        /* C(bf16) = alpha*acc/(*div) + bias + R                                  */
+#define SPMM_EPI_GELU 1        /* C2(bf16) = pre = acc + bias ; C(bf16) = gelu_erf(pre)                  */
+#define SPMM_EPI_F32 2         /* C(f32)  = alpha*acc/(*div) + bias                                      */
+#define SPMM_EPI_F32_ATOMIC 3  /* C(f32) += alpha*acc  with atomicAdd (split-K allowed)                  */
+#define SPMM_EPI_GELU_GRAD 4   /* C(bf16) = acc * gelu_erf'(G)                                           */
+#define SPMM_EPI_F32_ACC 5     /* C(f32) += alpha*acc + bias   (plain read-modify-write, single owner)   */
+
+/* C[M,N] = A[M,K] . W[N,K]^T on MFMA (bf16 in, fp32 accumulate).  Replaces every nn.Linear on the path
+ * (xbert.py:280-300 query/key/value, :370 attention output.dense, :435 intermediate.dense + erf GELU :436,
+ * :448 output.dense, :673 transform.dense, :695 tied decoder; SPMM_models.py:31-42 heads) and, with transposed
+ * operands, their dgrad/wgrad GEMMs; also the similarity GEMMs SPMM_models.py:108-111,121-124 (split-bf16 K=3E). */
+int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
+                 const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
+                 void* C2, long ldc2, int epi, spmm_stream_t stream);
+/* 1 = stage tiles with LDS-DMA (global_load_lds_dwordx4, default), 0 = through registers */
+void spmm_gemm_set_staging(int use_lds_dma);
+
+/* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.
+ * Replaces BertSelfAttention.forward xbert.py:305-354 incl. the additive masks of :889-948 (self: 0/-10000, causal
+ * for sequences >= causal_from) and invert_attention_mask :1038-1043 (cross: 0/finfo.min, is_cross=1). */
+int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask, void* O,
+                  long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross, float dropout_p,
+                  const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
+                  const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ, long lddq, void* dK,
+                  long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross,
+                  float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+
+/* y = LayerNorm(dropout(x) + res): BertSelfOutput xbert.py:369-373, BertOutput :447-451, transform LN :675,
+ * property_mtr_head LN SPMM_models.py:41.  zout (may alias x) keeps the pre-norm sum for backward. */
+int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* zout, float* mean,
+                float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr, uint64_t salt,
+                spmm_stream_t stream);
+/* dz = dLN(dy + dy2); dx = dropout-mask(dz) when drop_on_dy == 0; drop_on_dy == 1 masks dy instead (embeddings);
+ * dgamma/dbeta accumulate with atomics (may be null for frozen parameters). */
+int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd, const float* gamma,
+                void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H, float dropout_p,
+                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, spmm_stream_t stream);
+
+/* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
+ * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings
+ * (inputs_embeds branch).  Sequence s reads PV source row s % src_mod. */
+int spmm_embed_ln_fwd(int mode, const int* ids, const float* word, const float* pos, const float* type0, const float* pv_x,
+                      const float* pv_mask, const float* pv_w, const float* pv_b, const float* pv_cls,
+                      const float* pv_masktok, int src_mod, const float* gamma, const float* beta, void* y, void* zout,
+                      float* mean, float* rstd, long nseq, int L, int H, float eps, float dropout_p,
+                      const uint64_t* seed_ptr, uint64_t salt, spmm_stream_t stream);
+int spmm_embed_bwd(int mode, const void* dz, const int* ids, const float* pv_x, const float* pv_mask, int src_mod,
+                   float* dword, float* dpos, float* dtype0, float* d_w, float* d_b, float* d_cls, float* d_masktok,
+                   long nseq, int L, int H, spmm_stream_t stream);
+
+/* layout helpers for the NT-only GEMM: activations^T for wgrad (+ fused bias-gradient column sums), fp32 master
+ * weight -> bf16 shadow and transposed bf16 shadow for dgrad, casts, row gather / scatter-add
+ * (SPMM_models.py:164-183 negatives; their backward). */
+int spmm_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, int Rpad, float* colsum,
+                        spmm_stream_t stream);
+int spmm_cast_transpose(const float* in, void* out, void* outT, int R, int C, spmm_stream_t stream);
+int spmm_cast_f32_bf16(const float* in, void* out, long n, spmm_stream_t stream);
+int spmm_cast_bf16_f32(const void* in, float* out, long n, spmm_stream_t stream);
+int spmm_acc_rows(float* dst, long ldd, const void* src, long lds, const long* idx, long rows, int H, int atomic,
+                  spmm_stream_t stream);
+int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int H, spmm_stream_t stream);
+
+/* F.normalize(proj(cls), dim=-1) SPMM_models.py:92,95,101,105; also emits split-bf16 GEMM operands. */
+int spmm_l2norm_fwd(const float* x, long ldx, float* y, float* nrm, void* a3, void* w3, void* yT, long ldt, int rows, int E,
+                    spmm_stream_t stream);
+int spmm_l2norm_bwd(const float* dy, const float* y, const float* nrm, const float* gscale, void* dx, int rows, int E,
+                    spmm_stream_t stream);
+/* soft-target contrastive loss rows + gradient (SPMM_models.py:113-131). */
+int spmm_ita_rows(const float* S, const float* SM, long ldj, int nrows, int B, int J, const float* alpha_ptr,
+                  const float* temp_ptr, void* dS, long ldd, int Jpad, float* losses, int loss_slot, float* dtemp,
+                  int* nan_flag, spmm_stream_t stream);
+/* hard negatives SPMM_models.py:154-178: one multinomial draw per row, on device. */
+int spmm_sample_neg(const float* S, long ldj, int B, const long* forced, const uint64_t* seed_ptr, uint64_t salt, long* out,
+                    long out_offset, spmm_stream_t stream);
+/* next-token CE + distillation SPMM_models.py:233-238 and its gradient w.r.t. the student logits. */
+int spmm_lm_loss(const float* logits, const float* logits_m, long ldl, const int* ids, long nseq, int L, int V,
+                 const float* alpha_ptr, int* n_nonpad_ws, const float* gscale, void* dlogits, long ldd, int Vpad,
+                 float* losses, int loss_slot, spmm_stream_t stream);
+/* itm_head + cross entropy SPMM_models.py:201-206 (forward and backward in one pass). */
+int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, int H, const float* W, const float* bias,
+                  int n, int B, const float* gscale, float* losses, int loss_slot, float* logits_out, void* dxa, void* dxb,
+                  float* dW, float* db, int do_bwd, spmm_stream_t stream);
+/* property_mtr_head final Linear(H,1) + masked MSE * 5 SPMM_models.py:251-256. */
+int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
+                  int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
+                  float* dw, float* db, int do_bwd, spmm_stream_t stream);
+/* _dequeue_and_enqueue SPMM_models.py:272-286 (+ the bf16 GEMM shadows of the queue). */
+int spmm_enqueue(const float* feats, int n, int E, float* queue, int Q, void* w3, void* qT, long ldt, int Bloc, long* ptr,
+                 int advance, spmm_stream_t stream);
+int spmm_queue_shadow(const float* queue, int E, int Q, void* w3, void* qT, long ldt, int Bloc, spmm_stream_t stream);
+/* temp.clamp_(0.01, 0.5) SPMM_models.py:80-81 */
+int spmm_clamp_scalar(float* p, float lo, float hi, spmm_stream_t stream);
+
+/* clip_grad_norm_(5.) + AdamW SPMM_models.py:340,361-362 and the EMA of the momentum encoders :266-269. */
+long spmm_adam_scalars_bytes(void);
+int spmm_grad_sqnorm(const float* g, long n, float* out_zeroed, spmm_stream_t stream);
+int spmm_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, const float* lr_ptr,
+                    float beta1, float beta2, float eps, float weight_decay, const float* normsq, float max_norm, int* step,
+                    const int* nan_flag, void* scalars_ws, spmm_stream_t stream);
+int spmm_ema_update(float* pm, const float* p, void* bf16_shadow, long n, float momentum, spmm_stream_t stream);
+int spmm_axpy_scalar(float* dst, const float* src, const float* scale_ptr, float scale, int n, spmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMM_HIP_H */

@@ -1,0 +1,426 @@
+// Attention core for gfx950: softmax(Q K^T / sqrt(64) + mask) -> dropout -> . V, forward and backward.
+//
+// Replaces BertSelfAttention.forward xbert.py:305-354 (scores :305, /sqrt(d) :323, additive mask :327,
+// softmax :335, dropout :344, context :350, head merge :352-354) for both the self- and the cross-attention
+// instantiation (:285-290), with the masks of get_extended_attention_mask :889-948 (0 / -10000, causal AND
+// padding when is_decoder) and invert_attention_mask (0 / finfo.min, call site :1038-1043) folded in from the
+// raw [nseq, Lkv] 0/1 mask -- no [B,1,L,L] tensor is ever materialised.
+//
+// One workgroup per (sequence, head); head_dim is 64; Lq, Lkv <= 128, so the whole K/V panel of a head sits
+// in LDS and the score tile lives in MFMA accumulators: single pass, no online-softmax rescaling.
+// Scores are computed TRANSPOSED (S^T = K Q^T via v_mfma_f32_32x32x16_bf16 with K rows as the A operand), so
+// a lane owns one query row (lane&31) and its kv entries sit in its accumulator registers: the row max / sum
+// need one cross-lane exchange (lane ^ 32) only.  The probabilities feed the second MFMA (O^T = V^T P^T)
+// straight from registers as the B operand: MFMA sums over its k-slots in any order, so the k-slot <-> kv
+// assignment is chosen to be exactly the accumulator layout (kv = 4g+{0..3, 8..11} per 16-wide step) and the
+// V^T fragments are read from LDS in that same order -- no cross-lane shuffle of P at all.
+// Backward recomputes P from the saved log-sum-exp and runs two phases: (A) a wave owns 32 query rows ->
+// dQ; (B) a wave owns 32 kv rows -> dK, dV (scores recomputed un-transposed so that the reduction index q is
+// the register index).  Dropout masks are regenerated from (seed, element index).
+#include "common.h"
+#include "../../include/spmm_hip.h"
+
+namespace {
+
+constexpr int HD = 64;            // head dim
+constexpr int ROWB = 128;         // bytes per row of a row-major [L][64] bf16 LDS tile
+constexpr int TSTR = 264;         // bytes per row of a transposed [64][128] bf16 LDS tile (+8 B pad: conflict-free)
+
+struct AttnP {
+  const bf16* Q; long ldq;
+  const bf16* K; long ldk;
+  const bf16* V; long ldv;
+  const int* kmask;               // [nseq, Lkv] 1 = attend, or null (all ones)
+  bf16* O; long ldo;              // fwd output / bwd input
+  float* LSE;                     // [nseq, nH, Lq]
+  const bf16* dO; long lddo;
+  bf16* dQ; long lddq;
+  bf16* dK; long lddk;
+  bf16* dV; long lddv;
+  int nseq, nH, Lq, Lkv;
+  int causal_from;                // sequences >= causal_from get the causal mask (self-attention only)
+  float mask_neg;                 // -10000 (self) or -FLT_MAX (cross)
+  uint32_t drop_thresh16;         // 0 = no dropout
+  float drop_scale;               // 1/(1-p)
+  const uint64_t* seed_ptr;       // device seed (graph-replay safe), may be null when no dropout
+  uint64_t seed_salt;             // per-call-site salt
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+// reference mask arithmetic: (1 - causal*mask) * -10000 (self) / (1 - mask) * finfo.min (cross)
+__device__ __forceinline__ float score_bias(int mask_kv, bool causal, int q, int kv, float mask_neg) {
+  const bool ok = mask_kv && (!causal || kv <= q);
+  return ok ? 0.f : mask_neg;
+}
+
+// Stage rows [0,L) of a [L][64] head slice into a swizzled row-major LDS tile (zero rows up to 128) and,
+// optionally, into a transposed [64][132] image.
+template <bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_head(const bf16* __restrict__ src, long ld, int L, char* rm, char* tr, int tid,
+                                           int nthreads) {
+  for (int id = tid; id < 128 * 8; id += nthreads) {
+    const int row = id >> 3, sl = id & 7;
+    bf16x8 v;
+    if (row < L) {
+      v = *(const bf16x8*)(src + (long)row * ld + sl * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    }
+    if constexpr (ROWMAJOR) *(bf16x8*)(rm + swz(row, sl)) = v;
+    if constexpr (TRANSPOSED) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(bf16*)(tr + (sl * 8 + e) * TSTR + row * 2) = v[e];
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 ld_rm(const char* tile, int row, int slot) { return *(const bf16x8*)(tile + swz(row, slot)); }
+// transposed tile: 8 values X^T[d][base+{0..3}], X^T[d][base+8+{0..3}]
+__device__ __forceinline__ bf16x8 ld_tr(const char* tile, int d, int base) {
+  const bf16x4 a = *(const bf16x4*)(tile + d * TSTR + base * 2);
+  const bf16x4 b = *(const bf16x4*)(tile + d * TSTR + base * 2 + 16);
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int hf) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (bf16)v[hf * 8 + e];
+  return r;
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NT>   // NT = ceil(Lkv / 32)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                        // 16 KiB  row-major swizzled K
+  char* VT = smem + 16384;                // 64 x 264 B transposed V
+  float* mb = (float*)(smem + 16384 + 64 * TSTR);   // 128 floats: mask value per kv (1/0), -1 = padding
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
+  const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
+  const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
+  const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
+  stage_head<true, false>(Kg, p.ldk, p.Lkv, Ks, nullptr, tid, nthreads);
+  stage_head<false, true>(Vg, p.ldv, p.Lkv, nullptr, VT, tid, nthreads);
+  for (int j = tid; j < 128; j += nthreads)
+    mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
+  // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
+  const int q = wave * 32 + (lane & 31);
+  const int qc = q < p.Lq ? q : p.Lq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Qg + (long)qc * p.ldq + (kk * 2 + g) * 8);
+  __syncthreads();
+
+  const bool causal = seq >= p.causal_from;
+  f32x16 st[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    st[t] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      const float mv = mb[kv];
+      const float s = mv < 0.f ? -INFINITY : st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(st[t][r] - mx);
+      st[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  if (p.LSE && q < p.Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
+  if (p.drop_thresh16) {
+    const uint64_t seed = *p.seed_ptr ^ p.seed_salt;
+    const uint64_t rowbase = (((uint64_t)seq * p.nH + h) * p.Lq + q) * (uint64_t)p.Lkv;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        st[t][r] = drop_keep(seed, rowbase + kv, p.drop_thresh16) ? st[t][r] * p.drop_scale : 0.f;
+      }
+  }
+  // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
+  f32x16 ot[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const bf16x8 pf = pack8(st[t], hf);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ot[dt] = MFMA32(ld_tr(VT, dt * 32 + (lane & 31), t * 32 + hf * 16 + 4 * g), pf, ot[dt]);
+    }
+  if (q < p.Lq) {
+    bf16* Og = p.O + ((long)seq * p.Lq + q) * p.ldo + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = dt * 32 + 8 * gq + 4 * g;
+        *(bf16x4*)(Og + d) = to_bf16x4(ot[dt][gq * 4] * inv, ot[dt][gq * 4 + 1] * inv, ot[dt][gq * 4 + 2] * inv,
+                                       ot[dt][gq * 4 + 3] * inv);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+constexpr int BWD_LDS = 4 * 16384 + 3 * 64 * TSTR + 3 * 128 * 4;
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + 16384;
+  char* Qs = smem + 2 * 16384;
+  char* dOs = smem + 3 * 16384;
+  char* KT = smem + 4 * 16384;
+  char* QT = KT + 64 * TSTR;
+  char* dOT = QT + 64 * TSTR;
+  float* mb = (float*)(dOT + 64 * TSTR);
+  float* lse = mb + 128;
+  float* Dq = lse + 128;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
+  const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
+  const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
+  const bf16* Og = p.O + (long)seq * p.Lq * p.ldo + h * HD;
+  const bf16* dOg = p.dO + (long)seq * p.Lq * p.lddo + h * HD;
+  stage_head<true, true>(Kg, p.ldk, p.Lkv, Ks, KT, tid, 256);
+  stage_head<true, false>(Vg, p.ldv, p.Lkv, Vs, nullptr, tid, 256);
+  stage_head<true, true>(Qg, p.ldq, p.Lq, Qs, QT, tid, 256);
+  stage_head<true, true>(dOg, p.lddo, p.Lq, dOs, dOT, tid, 256);
+  if (tid < 128) {
+    const int j = tid;
+    mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
+    float l = 0.f, dsum = 0.f;
+    if (j < p.Lq) {
+      l = p.LSE[((long)seq * p.nH + h) * p.Lq + j];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 a = *(const bf16x8*)(dOg + (long)j * p.lddo + c * 8);
+        const bf16x8 b = *(const bf16x8*)(Og + (long)j * p.ldo + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
+      }
+    }
+    lse[j] = l;
+    Dq[j] = dsum;
+  }
+  __syncthreads();
+
+  const bool causal = seq >= p.causal_from;
+  const bool drop = p.drop_thresh16 != 0;
+  const uint64_t seed = drop ? (*p.seed_ptr ^ p.seed_salt) : 0;
+  const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
+  const int NTkv = (p.Lkv + 31) >> 5, NTq = (p.Lq + 31) >> 5;
+
+  // ---- phase A: wave owns query tile `wave` -> dQ
+  if (wave < NTq) {
+    const int q = wave * 32 + (lane & 31);
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = ld_rm(Qs, q, kk * 2 + g);
+      dof[kk] = ld_rm(dOs, q, kk * 2 + g);
+    }
+    const float lq = lse[q], dq_row = Dq[q];
+    f32x16 dq[2] = {zero16(), zero16()};
+    for (int t = 0; t < NTkv; ++t) {
+      f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        st = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st);
+        dp = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float mv = mb[kv];
+        float ds = 0.f;
+        if (mv >= 0.f && q < p.Lq) {
+          const float s = st[r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+          const float pr = __expf(s - lq);
+          float dpr = dp[r];
+          if (drop) dpr = drop_keep(seed, (headbase + q) * (uint64_t)p.Lkv + kv, p.drop_thresh16) ? dpr * p.drop_scale : 0.f;
+          ds = pr * (dpr - dq_row);
+        }
+        st[r] = ds;
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 dsf = pack8(st, hf);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = MFMA32(ld_tr(KT, dt * 32 + (lane & 31), t * 32 + hf * 16 + 4 * g), dsf, dq[dt]);
+      }
+    }
+    if (q < p.Lq) {
+      bf16* dQg = p.dQ + ((long)seq * p.Lq + q) * p.lddq + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *(bf16x4*)(dQg + dt * 32 + 8 * gq + 4 * g) =
+              to_bf16x4(dq[dt][gq * 4] * 0.125f, dq[dt][gq * 4 + 1] * 0.125f, dq[dt][gq * 4 + 2] * 0.125f,
+                        dq[dt][gq * 4 + 3] * 0.125f);
+    }
+  }
+
+  // ---- phase B: wave owns kv tile `wave` -> dK, dV   (S[q][kv]: lane = kv column, registers = q rows)
+  if (wave < NTkv) {
+    const int kv = wave * 32 + (lane & 31);
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = ld_rm(Ks, kv, kk * 2 + g);
+      vf[kk] = ld_rm(Vs, kv, kk * 2 + g);
+    }
+    const float mv = mb[kv];
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    for (int qt = 0; qt < NTq; ++qt) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = MFMA32(ld_rm(Qs, qt * 32 + (lane & 31), kk * 2 + g), kf[kk], s);
+        dp = MFMA32(ld_rm(dOs, qt * 32 + (lane & 31), kk * 2 + g), vf[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        float pd = 0.f, ds = 0.f;
+        if (mv >= 0.f && q < p.Lq) {
+          const float sc = s[r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+          const float pr = __expf(sc - lse[q]);
+          float dpr = dp[r];
+          pd = pr;
+          if (drop) {
+            const bool keep = drop_keep(seed, (headbase + q) * (uint64_t)p.Lkv + kv, p.drop_thresh16);
+            pd = keep ? pr * p.drop_scale : 0.f;
+            dpr = keep ? dpr * p.drop_scale : 0.f;
+          }
+          ds = pr * (dpr - Dq[q]);
+        }
+        s[r] = pd;
+        dp[r] = ds;
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = pack8(s, hf), dsf = pack8(dp, hf);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = MFMA32(ld_tr(dOT, dt * 32 + (lane & 31), qt * 32 + hf * 16 + 4 * g), pf, dv[dt]);
+          dk[dt] = MFMA32(ld_tr(QT, dt * 32 + (lane & 31), qt * 32 + hf * 16 + 4 * g), dsf, dk[dt]);
+        }
+      }
+    }
+    if (kv < p.Lkv) {
+      bf16* dKg = p.dK + ((long)seq * p.Lkv + kv) * p.lddk + h * HD;
+      bf16* dVg = p.dV + ((long)seq * p.Lkv + kv) * p.lddv + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = dt * 32 + 8 * gq + 4 * g;
+          *(bf16x4*)(dKg + d) = to_bf16x4(dk[dt][gq * 4] * 0.125f, dk[dt][gq * 4 + 1] * 0.125f,
+                                          dk[dt][gq * 4 + 2] * 0.125f, dk[dt][gq * 4 + 3] * 0.125f);
+          *(bf16x4*)(dVg + d) = to_bf16x4(dv[dt][gq * 4], dv[dt][gq * 4 + 1], dv[dt][gq * 4 + 2], dv[dt][gq * 4 + 3]);
+        }
+    }
+  }
+}
+
+int check_common(const char* name, int nseq, int nH, int Lq, int Lkv, long ldq, long ldk, long ldv) {
+  SPMM_CHECK_SHAPE(nseq > 0 && nH > 0, "%s: empty problem", name);
+  SPMM_CHECK_SHAPE(Lq >= 1 && Lq <= 128 && Lkv >= 1 && Lkv <= 128, "%s: Lq=%d Lkv=%d must be in [1,128]", name, Lq, Lkv);
+  SPMM_CHECK_SHAPE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "%s: row strides must be multiples of 8", name);
+  return SPMM_OK;
+}
+
+}  // namespace
+
+// head_dim is fixed at 64 (config_bert.json: 768 / 12).  Tensors are token-major: row = seq*L + pos, head h at
+// columns [h*64, h*64+64) of the given base pointer.
+extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                             const int* kmask, void* O, long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv,
+                             int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
+                             uint64_t seed_salt, hipStream_t stream) {
+  int rc = check_common("spmm_attn_fwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
+  if (rc) return rc;
+  SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_fwd: dropout needs a device seed");
+  AttnP p = {};
+  p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
+  p.kmask = kmask; p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
+  p.causal_from = is_cross ? nseq : causal_from;
+  p.mask_neg = is_cross ? -3.4028234663852886e38f : -10000.f;
+  p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
+  p.drop_scale = 1.f / (1.f - dropout_p);
+  p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
+  const int nt = (Lkv + 31) / 32, nw = (Lq + 31) / 32;
+  const size_t lds = 16384 + 64 * TSTR + 128 * 4;
+  dim3 grid(nH, nseq), block(64 * nw);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, stream, p); break;
+    case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, stream, p); break;
+    case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, block, lds, stream, p); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, stream, p); break;
+  }
+  SPMM_LAUNCH_CHECK("spmm_attn_fwd");
+  return SPMM_OK;
+}
+
+extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                             const int* kmask, const void* O, long ldo, const float* LSE, const void* dO, long lddo,
+                             void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq,
+                             int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
+                             uint64_t seed_salt, hipStream_t stream) {
+  int rc = check_common("spmm_attn_bwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
+  if (rc) return rc;
+  SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_bwd: dropout needs a device seed");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_attn_bwd: cannot raise dynamic LDS to %d: %s", BWD_LDS, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  AttnP p = {};
+  p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
+  p.kmask = kmask; p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
+  p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
+  p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
+  p.causal_from = is_cross ? nseq : causal_from;
+  p.mask_neg = is_cross ? -3.4028234663852886e38f : -10000.f;
+  p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
+  p.drop_scale = 1.f / (1.f - dropout_p);
+  p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p);
+  SPMM_LAUNCH_CHECK("spmm_attn_bwd");
+  return SPMM_OK;
+}

@@ -1,0 +1,97 @@
+// Shared device helpers for the SPMM gfx950 kernels (wave64, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SPMM_OK 0
+#define SPMM_ERR_SHAPE 1
+#define SPMM_ERR_LAUNCH 2
+#define SPMM_ERR_UNSUPPORTED 3
+
+extern "C" void spmm_set_error(const char* fmt, ...);
+
+#define SPMM_CHECK_SHAPE(cond, ...)                   \
+  do {                                                \
+    if (!(cond)) {                                    \
+      spmm_set_error(__VA_ARGS__);                    \
+      return SPMM_ERR_SHAPE;                          \
+    }                                                 \
+  } while (0)
+
+#define SPMM_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      spmm_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return SPMM_ERR_LAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout RNG.  One 32-bit hash gives two 16-bit uniforms; element e of a tensor
+// uses hash(seed, e>>1) half (e&1).  Forward and backward regenerate the same mask from
+// (seed, element index), so no mask is ever stored.  p=0 short-circuits at the call sites.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32" finaliser
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
+  uint32_t lo = (uint32_t)pair_idx, hi = (uint32_t)(pair_idx >> 32);
+  uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  return mix32(mix32(lo ^ s0) + hi * 0x9E3779B1u + s1);
+}
+// keep-decision for element idx; thresh16 = round(p * 65536)
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
+  uint32_t r = rng_pair(seed, idx >> 1);
+  uint32_t u = (idx & 1) ? (r >> 16) : (r & 0xffffu);
+  return u >= thresh16;
+}
+// four consecutive elements starting at idx (idx % 4 == 0)
+__device__ __forceinline__ void drop_keep4(uint64_t seed, uint64_t idx, uint32_t thresh16, bool k[4]) {
+  uint32_t r0 = rng_pair(seed, idx >> 1), r1 = rng_pair(seed, (idx >> 1) + 1);
+  k[0] = (r0 & 0xffffu) >= thresh16; k[1] = (r0 >> 16) >= thresh16;
+  k[2] = (r1 & 0xffffu) >= thresh16; k[3] = (r1 >> 16) >= thresh16;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {   // [0,1)
+  return (float)(rng_pair(seed, idx) >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) {
+  bf16x4 r; r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d; return r;
+}

@@ -1,0 +1,255 @@
+// bf16 "NT" GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  (both operands K-contiguous, the
+// nn.Linear layout), fp32 accumulate on v_mfma_f32_32x32x16_bf16, fused epilogues.
+//
+// Replaces on the reference path: every nn.Linear of xbert.py (query/key/value :280-300, attention
+// output.dense :370, intermediate.dense :435, output.dense :448, LM transform/decoder :673,:695) and their
+// dgrad / wgrad GEMMs in backward (dgrad uses the [K,N] transposed bf16 weight shadow, wgrad the
+// transposed activations, so all three are NT problems), and the similarity GEMMs SPMM_models.py:108-124.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles,
+// 64 fp32 accumulators per lane).  A/W tiles are staged HBM->LDS with global_load_lds_dwordx4 (no VGPR
+// round trip), double buffered (2 x 32 KiB).  LDS rows are 128 B, so the 16-B slot index is XOR-swizzled
+// with (row>>1)&7 -- applied on the global SOURCE address (LDS-DMA writes lane-linear) and again on the
+// ds_read_b128 address -- which makes every 16-lane ds_read_b128 group hit 16 distinct slots.
+// The MFMA is issued "swapped" (A-operand = W rows, B-operand = A rows) so each lane ends up with 4
+// consecutive output columns per accumulator quad -> 8-byte bf16 / 16-byte fp32 stores.
+// Workgroup ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
+#include "common.h"
+#include "../../include/spmm_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
+
+enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5 };
+
+struct GemmP {
+  const bf16* A; long lda;
+  const bf16* W; long ldw;
+  int M, N, K;               // this launch reduces K elements per split-slice; K % 64 == 0
+  int ksplit;                // elements of K per grid.z slice (multiple of 64)
+  const float* bias;         // [N] or null
+  const float* div_ptr;      // optional device scalar: acc /= *div_ptr
+  float alpha;               // acc *= alpha
+  const bf16* R; long ldr;   // optional bf16 addend (residual-gradient accumulate)
+  const bf16* G; long ldg;   // EPI_GELU_GRAD: pre-activation
+  void* C; long ldc;
+  bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
+};
+
+// LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
+// physical slot = id&7).  The wave's 64 chunks are contiguous in LDS (wave-uniform base + lane*16).
+__device__ __forceinline__ void stage_tile_dma(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0,
+                                               char* lds_tile, int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = c * 256 + tid;
+    const int row = id >> 3, ps = id & 7;
+    const int ls = ps ^ ((row >> 1) & 7);                 // logical k-slot held at this physical slot
+    int grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;               // clamp: out-of-range rows are never stored
+    const bf16* g = src + (long)grow * ld + k0 + ls * 8;
+    const int wave_base = __builtin_amdgcn_readfirstlane((c * 256 + (tid & ~63)) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
+  }
+}
+// Register-staged fallback (same LDS image): load early, write after the MFMA block.
+__device__ __forceinline__ void stage_tile_load(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0,
+                                                int tid, bf16x8 (&r)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = c * 256 + tid;
+    const int row = id >> 3, ps = id & 7;
+    const int ls = ps ^ ((row >> 1) & 7);
+    int grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;
+    r[c] = *(const bf16x8*)(src + (long)grow * ld + k0 + ls * 8);
+  }
+}
+__device__ __forceinline__ void stage_tile_write(char* lds_tile, int tid, const bf16x8 (&r)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *(bf16x8*)(lds_tile + (c * 256 + tid) * 16) = r[c];
+}
+
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile id: workgroup b runs on XCD b%8; give each XCD a contiguous range of tiles.
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tile_m = t / ntn, tile_n = t % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.z * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  const int nk = (kend - kbeg) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 ra[4], rw[4];
+  if (nk > 0) {
+    if constexpr (GLDS) {
+      stage_tile_dma(p.A, p.lda, m0, p.M, kbeg, smem, tid);
+      stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg, smem + TILE_BYTES, tid);
+    } else {
+      stage_tile_load(p.A, p.lda, m0, p.M, kbeg, tid, ra);
+      stage_tile_load(p.W, p.ldw, n0, p.N, kbeg, tid, rw);
+      stage_tile_write(smem, tid, ra);
+      stage_tile_write(smem + TILE_BYTES, tid, rw);
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();   // tile kt landed (vmcnt(0) is part of the barrier's release while LDS-DMA is pending)
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    if (kt + 1 < nk) {
+      if constexpr (GLDS) {
+        stage_tile_dma(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, nxt, tid);
+        stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BK, nxt + TILE_BYTES, tid);
+      } else {
+        stage_tile_load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, tid, ra);
+        stage_tile_load(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BK, tid, rw);
+      }
+    }
+    const char* As = cur;
+    const char* Ws = cur + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if constexpr (!GLDS) {
+      if (kt + 1 < nk) {   // the other buffer was last read in iteration kt-1, before this iteration's barrier
+        stage_tile_write(nxt, tid, ra);
+        stage_tile_write(nxt + TILE_BYTES, tid, rw);
+      }
+    }
+  }
+
+  // ---- epilogue: acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][g * 4 + j] * scale;
+        if (p.bias && (EPI != EPI_F32_ATOMIC || blockIdx.z == 0)) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += b[j];
+        }
+        if (p.R) {
+          const bf16x4 r = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+        if constexpr (EPI == EPI_BF16) {
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (EPI == EPI_GELU) {
+          *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else if constexpr (EPI == EPI_GELU_GRAD) {
+          const bf16x4 x = *(const bf16x4*)(p.G + (long)m * p.ldg + n);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(v[0] * gelu_erf_grad((float)x[0]), v[1] * gelu_erf_grad((float)x[1]),
+                        v[2] * gelu_erf_grad((float)x[2]), v[3] * gelu_erf_grad((float)x[3]));
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o;
+        } else if constexpr (EPI == EPI_F32_ACC) {
+          f32x4* dst = (f32x4*)((float*)p.C + (long)m * p.ldc + n);
+          f32x4 o = *dst;
+          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+          *dst = o;
+        } else {  // EPI_F32_ATOMIC
+          float* dst = (float*)p.C + (long)m * p.ldc + n;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(dst + j, v[j]);
+        }
+      }
+    }
+}
+
+template <bool GLDS>
+int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<EPI_BF16, GLDS>), grid, dim3(256), 0, st, p); break;
+    case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU, GLDS>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32, GLDS>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32_ATOMIC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ATOMIC, GLDS>), grid, dim3(256), 0, st, p); break;
+    case EPI_GELU_GRAD: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU_GRAD, GLDS>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32_ACC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ACC, GLDS>), grid, dim3(256), 0, st, p); break;
+    default: spmm_set_error("spmm_gemm_nt: unknown epilogue %d", epi); return SPMM_ERR_UNSUPPORTED;
+  }
+  return SPMM_OK;
+}
+
+}  // namespace
+
+static int g_gemm_use_glds = 1;
+extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
+
+extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
+                            const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
+                            const void* G, long ldg, void* C, long ldc, void* C2, long ldc2, int epi,
+                            hipStream_t stream) {
+  SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  SPMM_CHECK_SHAPE(K % 64 == 0, "spmm_gemm_nt: K=%d must be a multiple of 64", K);
+  SPMM_CHECK_SHAPE(N % 4 == 0, "spmm_gemm_nt: N=%d must be a multiple of 4", N);
+  SPMM_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "spmm_gemm_nt: lda/ldw must be multiples of 8 elements");
+  SPMM_CHECK_SHAPE(ldc % 4 == 0, "spmm_gemm_nt: ldc must be a multiple of 4");
+  SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
+  if (splits < 1) splits = 1;
+  SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
+  SPMM_CHECK_SHAPE(epi != EPI_GELU || C2 != nullptr, "spmm_gemm_nt: GELU epilogue needs C2");
+  SPMM_CHECK_SHAPE(epi != EPI_GELU_GRAD || G != nullptr, "spmm_gemm_nt: GELU-grad epilogue needs G");
+  int ksplit = ((K / 64 + splits - 1) / splits) * 64;
+  splits = (K + ksplit - 1) / ksplit;
+  GemmP p;
+  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
+  p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
+  p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, 1, splits);
+  int rc = g_gemm_use_glds ? launch<true>(epi, p, grid, stream) : launch<false>(epi, p, grid, stream);
+  if (rc != SPMM_OK) return rc;
+  SPMM_LAUNCH_CHECK("spmm_gemm_nt");
+  return SPMM_OK;
+}

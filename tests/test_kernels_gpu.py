@@ -1,0 +1,585 @@
+"""Per-kernel parity of the HIP kernels (through the C ABI) against plain fp32 PyTorch of the same op.
+Inputs are asymmetric random data rounded to bf16 first, so the only differences are accumulation order and the
+bf16 rounding of outputs; tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from spmm_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def close(got, ref, atol, rtol, name=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} off; max err {err.max().item():.4g} " \
+                          f"(ref max {ref.abs().max().item():.4g}) first bad idx {bad.nonzero()[0].tolist()}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("staging", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (216, 300, 128), (6912, 768, 768), (100, 64, 3072),
+                                   (512, 2304, 768)])
+def test_gemm_bf16_bias(ops, staging, M, N, K):
+    from spmm_amd._lib import lib
+    lib().cdll.spmm_gemm_set_staging(staging)
+    try:
+        A, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+        bias = rnd(N, seed=3, dtype=torch.float32)
+        C = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        ops.gemm_nt(A, W, C, bias=bias)
+        ref = A.float() @ W.float().t() + bias
+        close(C, ref, 2e-2, 1e-2, "gemm bf16")
+    finally:
+        lib().cdll.spmm_gemm_set_staging(1)
+
+
+def test_gemm_strided_operands_and_residual(ops):
+    M, N, K = 300, 128, 256
+    big = rnd(M, 3 * K, seed=5)
+    A = big[:, K:2 * K]                       # row stride 3K, unit column stride
+    W = rnd(N, K, scale=0.05, seed=6)
+    R = rnd(M, N, seed=7)
+    Cbig = torch.zeros(M, 2 * N, dtype=BF, device="cuda")
+    ops.gemm_nt(A, W, Cbig[:, N:], R=R, alpha=0.5)
+    ref = 0.5 * (A.float() @ W.float().t()) + R.float()
+    close(Cbig[:, N:], ref, 2e-2, 1e-2, "gemm strided")
+    assert Cbig[:, :N].abs().max().item() == 0.0
+
+
+def test_gemm_gelu_and_grad_epilogues(ops):
+    M, N, K = 384, 512, 128
+    A, W = rnd(M, K, seed=8), rnd(N, K, scale=0.1, seed=9)
+    bias = rnd(N, seed=10, dtype=torch.float32)
+    C, C2 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm_nt(A, W, C, bias=bias, epi=ops.EPI_GELU, C2=C2)
+    pre = A.float() @ W.float().t() + bias
+    close(C2, pre, 2e-2, 1e-2, "pre-activation")
+    close(C, torch.nn.functional.gelu(pre), 2e-2, 1e-2, "gelu")
+    # GELU-grad epilogue: out = (A W^T) * gelu'(G)
+    G = rnd(M, N, seed=11)
+    D = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm_nt(A, W, D, epi=ops.EPI_GELU_GRAD, G=G)
+    g = G.float().requires_grad_(True)
+    torch.nn.functional.gelu(g).sum().backward()
+    close(D, (A.float() @ W.float().t()) * g.grad, 3e-2, 1.5e-2, "gelu grad")
+
+
+def test_gemm_f32_epilogues_and_splitk(ops):
+    M, N, K = 256, 256, 2048
+    A, W = rnd(M, K, seed=12), rnd(N, K, scale=0.05, seed=13)
+    ref = A.float() @ W.float().t()
+    div = torch.tensor([0.07], device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, W, C, epi=ops.EPI_F32, div=div)
+    close(C, ref / 0.07, 1e-2, 1e-4, "f32 + div")
+    C.fill_(1.0)
+    ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ACC)
+    close(C, ref + 1.0, 2e-3, 1e-4, "f32 acc")
+    for splits in (1, 4, 7, 32):
+        C.fill_(2.0)
+        ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ATOMIC, splits=splits)
+        close(C, ref + 2.0, 2e-3, 1e-4, f"atomic split {splits}")
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    A, W = rnd(64, 96), rnd(64, 96)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_nt(A, W, torch.empty(64, 64, dtype=BF, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, mask, nH, causal_from, is_cross, drop_mask=None, p=0.0):
+    """q [nseq,Lq,nH*64] fp32 etc.; returns O [nseq,Lq,nH*64], lse [nseq,nH,Lq] (reference arithmetic of xbert.py:305-354)."""
+    nseq, Lq, _ = q.shape
+    Lkv = k.shape[1]
+    qh = q.view(nseq, Lq, nH, 64).permute(0, 2, 1, 3)
+    kh = k.view(nseq, Lkv, nH, 64).permute(0, 2, 1, 3)
+    vh = v.view(nseq, Lkv, nH, 64).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / 8.0
+    m = mask.float() if mask is not None else torch.ones(nseq, Lkv, device=q.device)
+    if is_cross:
+        add = (1 - m)[:, None, None, :] * torch.finfo(torch.float32).min
+    else:
+        ext = m[:, None, None, :].expand(nseq, 1, Lq, Lkv).clone()
+        ids = torch.arange(Lq, device=q.device)
+        causal = (torch.arange(Lkv, device=q.device)[None, :] <= ids[:, None]).float()
+        for sidx in range(causal_from, nseq):
+            ext[sidx, 0] = ext[sidx, 0] * causal
+        add = (1 - ext) * -10000.0
+    s = s + add
+    lse = torch.logsumexp(s, dim=-1)
+    pr = torch.softmax(s, dim=-1)
+    if drop_mask is not None:
+        pr = pr * drop_mask / (1 - p)
+    o = (pr @ vh).permute(0, 2, 1, 3).reshape(nseq, Lq, nH * 64)
+    return o, lse
+
+
+ATT_CASES = [  # nseq, nH, Lq, Lkv, causal_from, is_cross
+    (3, 2, 54, 54, 3, False), (4, 2, 54, 54, 2, False), (2, 12, 128, 128, 1, False), (3, 2, 54, 128, 3, True),
+    (3, 2, 128, 54, 3, True), (5, 2, 16, 16, 2, False), (2, 2, 24, 54, 2, True), (2, 3, 100, 77, 2, True),
+    (2, 2, 33, 33, 0, False),
+]
+
+
+def _attn_inputs(nseq, nH, Lq, Lkv, seed):
+    H = nH * 64
+    qkv = rnd(nseq * Lq, 3 * H, seed=seed)            # fused buffer: exercises row strides
+    kv = rnd(nseq * Lkv, 2 * H, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(2, Lkv // 2), Lkv + 1, (nseq,), generator=g)
+    lens[0] = Lkv
+    mask = (torch.arange(Lkv)[None, :] < lens[:, None]).int().cuda()
+    return qkv, kv, mask
+
+
+@pytest.mark.parametrize("nseq,nH,Lq,Lkv,causal_from,is_cross", ATT_CASES)
+def test_attention_forward(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
+    H = nH * 64
+    qkv, kv, mask = _attn_inputs(nseq, nH, Lq, Lkv, seed=20)
+    if is_cross:
+        Q, K, V = qkv[:, :H], kv[:, :H], kv[:, H:]
+    else:
+        Q, K, V = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+    lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    ops.attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, causal_from=causal_from, is_cross=is_cross)
+    ro, rl = ref_attention(Q.float().reshape(nseq, Lq, H), K.float().reshape(nseq, Lkv, H), V.float().reshape(nseq, Lkv, H),
+                           mask, nH, causal_from, is_cross)
+    close(lse, rl, 2e-3, 1e-4, "lse")
+    close(O.view(nseq, Lq, H), ro, 1.5e-2, 1e-2, "attention out")
+
+
+@pytest.mark.parametrize("nseq,nH,Lq,Lkv,causal_from,is_cross", ATT_CASES)
+def test_attention_backward(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
+    H = nH * 64
+    qkv, kv, mask = _attn_inputs(nseq, nH, Lq, Lkv, seed=30)
+    if is_cross:
+        Q, K, V = qkv[:, :H], kv[:, :H], kv[:, H:]
+    else:
+        Q, K, V = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    dO = rnd(nseq * Lq, H, seed=31)
+    O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+    lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    ops.attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, causal_from=causal_from, is_cross=is_cross)
+    dqkv = torch.zeros_like(qkv)
+    dkv = torch.zeros_like(kv)
+    if is_cross:
+        dQ, dK, dV = dqkv[:, :H], dkv[:, :H], dkv[:, H:]
+    else:
+        dQ, dK, dV = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, causal_from=causal_from,
+                 is_cross=is_cross)
+    q = Q.float().reshape(nseq, Lq, H).requires_grad_(True)
+    k = K.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    v = V.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    ro, _ = ref_attention(q, k, v, mask, nH, causal_from, is_cross)
+    ro.backward(dO.float().view(nseq, Lq, H))
+    for got, ref, nm in ((dQ, q.grad, "dQ"), (dK, k.grad, "dK"), (dV, v.grad, "dV")):
+        ref2 = ref.reshape(got.shape)
+        close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
+
+
+def test_attention_dropout_consistency(ops):
+    """Recover the dropout mask from a forward with V = identity, then check fwd/bwd against torch using THAT mask."""
+    nseq, nH, Lq, Lkv, p = 3, 2, 54, 64, 0.1
+    H = nH * 64
+    Q, K = rnd(nseq * Lq, H, seed=40), rnd(nseq * Lkv, H, seed=41)
+    eye = torch.eye(64, dtype=BF, device="cuda").repeat(nseq, nH)          # V[kv][d] = [kv == d] per head
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+    lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    kw = dict(nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, dropout_p=p, seed=seed, salt=99)
+    ops.attn_fwd(Q, K, eye, O, lse, **kw)
+    pd = O.float().view(nseq, Lq, nH, 64).permute(0, 2, 1, 3)              # = dropped probabilities
+    keep = (pd != 0).float()
+    rate = 1 - keep.mean().item()
+    assert abs(rate - p) < 0.02, rate
+    V, dO = rnd(nseq * Lkv, H, seed=42), rnd(nseq * Lq, H, seed=43)
+    ops.attn_fwd(Q, K, V, O, lse, **kw)
+    q = Q.float().reshape(nseq, Lq, H).requires_grad_(True)
+    k = K.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    v = V.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    ro, _ = ref_attention(q, k, v, None, nH, nseq, False, drop_mask=keep, p=p)
+    close(O.view(nseq, Lq, H), ro, 2e-2, 1e-2, "dropout fwd")
+    dQ, dK, dV = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(V)
+    ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, **kw)
+    ro.backward(dO.float().view(nseq, Lq, H))
+    for got, ref, nm in ((dQ, q.grad, "dQ"), (dK, k.grad, "dK"), (dV, v.grad, "dV")):
+        close(got, ref.reshape(got.shape), 4e-2, 2e-2, "dropout " + nm)
+    # a different seed gives a different mask
+    seed.fill_(7654321)
+    O2 = torch.zeros_like(O)
+    ops.attn_fwd(Q, K, eye, O2, lse, **kw)
+    assert ((O2.float() != 0) != (pd.permute(0, 2, 1, 3).reshape(nseq * Lq, H) != 0)).float().mean().item() > 0.05
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,H", [(7, 128), (1000, 768), (333, 256), (64, 1024)])
+def test_layernorm_fwd_bwd(ops, rows, H):
+    x, res = rnd(rows, H, seed=50), rnd(rows, H, seed=51)
+    gamma = (1 + 0.1 * torch.randn(H)).cuda()
+    beta = (0.1 * torch.randn(H)).cuda()
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.ln_fwd(x, res, gamma, beta, y, zout=z, mean=mean, rstd=rstd, eps=1e-12)
+    zr = (x.float() + res.float()).requires_grad_(True)
+    g = gamma.clone().requires_grad_(True)
+    b = beta.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(zr, (H,), g, b, 1e-12)
+    close(y, yr, 2e-2, 1e-2, "ln fwd")
+    close(z, zr, 2e-2, 1e-2, "ln z")
+    dy = rnd(rows, H, seed=52)
+    dy2 = rnd(rows, H, seed=53)
+    # backward from the bf16-rounded z the kernel stored, exactly what the product does
+    zr2 = z.float().requires_grad_(True)
+    yr2 = torch.nn.functional.layer_norm(zr2, (H,), g, b, 1e-12)
+    yr2.backward(dy.float() + dy2.float())
+    dz = torch.empty_like(x)
+    dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dy2=dy2, dgamma=dg, dbeta=db)
+    close(dz, zr2.grad, 3e-2, 2e-2, "ln dz")
+    close(dg, g.grad, 2e-2 * math.sqrt(rows), 1e-2, "ln dgamma")
+    close(db, b.grad, 2e-2 * math.sqrt(rows), 1e-2, "ln dbeta")
+
+
+def test_layernorm_dropout_masks_match(ops):
+    rows, H, p = 256, 768, 0.1
+    x = torch.ones(rows, H, dtype=BF, device="cuda")
+    gamma, beta = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
+    seed = torch.tensor([42], dtype=torch.int64, device="cuda")
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.ln_fwd(x, None, gamma, beta, y, zout=z, mean=mean, rstd=rstd, dropout_p=p, seed=seed, salt=5)
+    keep = z.float() != 0
+    assert abs(1 - keep.float().mean().item() - p) < 0.01
+    assert torch.allclose(z.float()[keep], torch.full_like(z.float()[keep], 1 / (1 - p)), atol=1e-2)
+    dy = rnd(rows, H, seed=54)
+    dz, dx = torch.empty_like(x), torch.empty_like(x)
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dx=dx, dropout_p=p, seed=seed, salt=5)
+    assert ((dx.float() != 0) & ~keep).sum().item() == 0            # dropped inputs get no gradient
+    close(dx.float()[keep], dz.float()[keep] / (1 - p), 1e-2, 1e-2, "dropout dx")
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+def test_text_embedding_fwd_bwd(ops):
+    nseq, L, H, V = 6, 24, 128, 300
+    ids = torch.randint(0, V, (nseq, L))
+    ids[:, -5:] = 0
+    word, pos, typ = torch.randn(V, H).cuda(), torch.randn(512, H).cuda(), torch.randn(2, H).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(H)).cuda(), (0.1 * torch.randn(H)).cuda()
+    idc = ids.int().cuda()
+    y = torch.empty(nseq * L, H, dtype=BF, device="cuda")
+    z = torch.empty_like(y)
+    mean, rstd = torch.empty(nseq * L, device="cuda"), torch.empty(nseq * L, device="cuda")
+    ops.embed_ln_fwd(0, y, nseq=nseq, L=L, H=H, pos=pos, type0=typ[0], gamma=gamma, beta=beta, ids=idc, word=word, zout=z,
+                     mean=mean, rstd=rstd)
+    w, pp, tt = word.clone().requires_grad_(True), pos.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    e = torch.nn.functional.embedding(ids.cuda(), w, padding_idx=0) + tt[0] + pp[:L]
+    yr = torch.nn.functional.layer_norm(e, (H,), gamma, beta, 1e-12)
+    close(y.view(nseq, L, H), yr, 2e-2, 1e-2, "embed fwd")
+    dz = rnd(nseq * L, H, seed=60)
+    e.backward(dz.float().view(nseq, L, H))
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros(H, device="cuda")
+    ops.embed_bwd(0, dz, nseq=nseq, L=L, H=H, dpos=dpos, dtype0=dtyp, ids=idc, dword=dword)
+    close(dword, w.grad, 1e-3, 1e-4, "dword")
+    close(dpos, pp.grad, 1e-3, 1e-4, "dpos")
+    close(dtyp, tt.grad[0], 1e-2, 1e-4, "dtype")
+    assert dword[0].abs().max().item() == 0.0      # padding_idx
+
+
+def test_pv_embedding_fwd_bwd(ops):
+    B, H, Lp = 5, 128, 54
+    x = torch.randn(B, 53).cuda()
+    m = torch.bernoulli(torch.full((B, 53), 0.5)).cuda()
+    w, b, cls, mt = [torch.randn(H).cuda().requires_grad_(True) for _ in range(4)]
+    pos, typ = torch.randn(512, H).cuda().requires_grad_(True), torch.randn(2, H).cuda().requires_grad_(True)
+    gamma, beta = (1 + 0.1 * torch.randn(H)).cuda(), (0.1 * torch.randn(H)).cuda()
+    nseq = 2 * B                                    # P1 | P11 share the source batch (src_mod = B)
+    y = torch.empty(nseq * Lp, H, dtype=BF, device="cuda")
+    z = torch.empty_like(y)
+    mean, rstd = torch.empty(nseq * Lp, device="cuda"), torch.empty(nseq * Lp, device="cuda")
+    ops.embed_ln_fwd(1, y, nseq=nseq, L=Lp, H=H, pos=pos.detach(), type0=typ.detach()[0], gamma=gamma, beta=beta,
+                     pv_x=x, pv_mask=m, pv_w=w.detach(), pv_b=b.detach(), pv_cls=cls.detach(), pv_masktok=mt.detach(),
+                     src_mod=B, zout=z, mean=mean, rstd=rstd)
+    feat = x[:, :, None] * w + b
+    masked = feat * (1 - m[:, :, None]) + mt * m[:, :, None]
+    props = torch.cat([cls.expand(B, 1, H), masked], dim=1).repeat(2, 1, 1)
+    e = props + typ[0] + pos[:Lp]
+    yr = torch.nn.functional.layer_norm(e, (H,), gamma, beta, 1e-12)
+    close(y.view(nseq, Lp, H), yr, 2e-2, 1e-2, "pv embed fwd")
+    dz = rnd(nseq * Lp, H, seed=61)
+    e.backward(dz.float().view(nseq, Lp, H))
+    d = {k: torch.zeros(H, device="cuda") for k in ("w", "b", "cls", "mt", "typ")}
+    dpos = torch.zeros(512, H, device="cuda")
+    ops.embed_bwd(1, dz, nseq=nseq, L=Lp, H=H, dpos=dpos, dtype0=d["typ"], pv_x=x, pv_mask=m, src_mod=B, d_w=d["w"],
+                  d_b=d["b"], d_cls=d["cls"], d_masktok=d["mt"])
+    for got, ref, nm in ((d["w"], w.grad, "dw"), (d["b"], b.grad, "db"), (d["cls"], cls.grad, "dcls"),
+                         (d["mt"], mt.grad, "dmask"), (d["typ"], typ.grad[0], "dtype"), (dpos, pos.grad, "dpos")):
+        close(got, ref, 2e-3 * max(1, ref.abs().max().item()), 1e-4, nm)
+
+
+# ------------------------------------------------------------------------------------- layout helpers
+def test_transpose_cast_gather_acc(ops):
+    R, C = 216, 300
+    big = rnd(R, C + 20, seed=70)
+    x = big[:, 10:10 + C]
+    Rpad = 256
+    out = torch.full((C, Rpad), 9.0, dtype=BF, device="cuda")
+    cs = torch.zeros(C, device="cuda")
+    ops.transpose_bf16(x, out, colsum=cs)
+    assert torch.equal(out[:, :R], x.t())
+    assert out[:, R:].abs().max().item() == 0
+    close(cs, x.float().sum(0), 1e-3, 1e-5, "colsum")
+    w = torch.randn(130, 70).cuda()
+    o, oT = torch.empty(130, 70, dtype=BF, device="cuda"), torch.empty(70, 130, dtype=BF, device="cuda")
+    ops.cast_transpose(w, o, oT)
+    assert torch.equal(o, w.to(BF)) and torch.equal(oT, w.to(BF).t())
+    f = torch.randn(1000).cuda()
+    ob = torch.empty(1000, dtype=BF, device="cuda")
+    ops.cast_f32_bf16(f, ob)
+    assert torch.equal(ob, f.to(BF))
+    back = torch.empty(1000, device="cuda")
+    ops.cast_bf16_f32(ob, back)
+    assert torch.equal(back, ob.float())
+    src = rnd(10, 128, seed=71)
+    idx = torch.tensor([3, 3, 9, 0, 1], device="cuda")
+    dst = torch.empty(5, 128, dtype=BF, device="cuda")
+    ops.gather_rows(dst, src, idx)
+    assert torch.equal(dst, src[idx])
+    acc = torch.ones(10, 128, device="cuda")
+    ops.acc_rows(acc, dst, idx=idx, atomic=True)
+    ref = torch.ones(10, 128, device="cuda").index_add_(0, idx, dst.float())
+    close(acc, ref, 1e-5, 1e-6, "scatter add")
+    ops.acc_rows(acc, src)
+    close(acc, ref + src.float(), 1e-5, 1e-6, "acc")
+
+
+# ------------------------------------------------------------------------------------------ loss side
+def test_l2norm_and_split(ops):
+    rows, E, H = 16, 256, 768
+    big = torch.randn(rows, E + 8).cuda()
+    x = big[:, :E]
+    y, nrm = torch.empty(rows, E, device="cuda"), torch.empty(rows, device="cuda")
+    a3, w3 = torch.empty(rows, 3 * E, dtype=BF, device="cuda"), torch.empty(rows, 3 * E, dtype=BF, device="cuda")
+    yT = torch.zeros(E, 64, dtype=BF, device="cuda")
+    ops.l2norm_fwd(x, y, nrm, a3=a3, w3=w3, yT=yT)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.normalize(xr, dim=-1)
+    close(y, yr, 1e-6, 1e-5, "normalize")
+    # split-bf16 product reproduces the fp32 dot products to ~1e-5
+    sim = torch.empty(rows, rows, device="cuda")
+    ops.gemm_nt(a3, w3, sim, epi=ops.EPI_F32)
+    close(sim, yr.detach() @ yr.detach().t(), 3e-5, 0, "split-bf16 sim")
+    assert torch.equal(yT[:, :rows], y.to(BF).t())
+    dy = torch.randn(rows, E).cuda()
+    yr.backward(dy)
+    dx = torch.empty(rows, E, dtype=BF, device="cuda")
+    gs = torch.tensor([0.5], device="cuda")
+    ops.l2norm_bwd(dy, y, nrm, dx, gscale=gs)
+    close(dx, 0.5 * xr.grad, 1e-3, 1e-2, "normalize bwd")
+
+
+def test_ita_rows(ops):
+    B, Q = 8, 120
+    J = B + Q
+    Jpad = 128
+    temp = torch.tensor([0.07], device="cuda")
+    alpha = torch.tensor([0.4], device="cuda")
+    raw = (torch.randn(2 * B, J) * 0.3).cuda()
+    rawm = (torch.randn(2 * B, J) * 0.3).cuda()
+    S, SM = raw / temp, rawm / temp
+    dS = torch.empty(2 * B, Jpad, dtype=BF, device="cuda")
+    losses, dtemp = torch.zeros(8, device="cuda"), torch.zeros(1, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.ita_rows(S, SM, dS, B=B, J=J, alpha=alpha, temp=temp, losses=losses, slot=2, dtemp=dtemp, nan_flag=flag)
+    t = temp.clone().requires_grad_(True)
+    r = raw.clone().requires_grad_(True)
+    s = r / t
+    tgt = torch.zeros(2 * B, J, device="cuda")
+    tgt[torch.arange(2 * B), torch.arange(2 * B) % B] = 1
+    tg = 0.4 * torch.softmax(SM, dim=1) + 0.6 * tgt
+    loss = (-(torch.log_softmax(s, dim=1) * tg).sum(1)).view(2, B).mean(1).sum() / 2
+    loss.backward()
+    assert abs(losses[2].item() - loss.item()) < 2e-4 * abs(loss.item())
+    close(dS[:, :J].float() / 0.07, r.grad, 2e-4, 1e-2, "dS")
+    assert dS[:, J:].abs().max().item() == 0
+    assert abs(dtemp.item() - t.grad.item()) < 2e-3 * abs(t.grad.item())
+    assert flag.item() == 0
+
+
+def test_sample_neg_distribution_and_forced(ops):
+    B = 16
+    S = (torch.randn(B, B + 40) * 2).cuda()
+    out = torch.zeros(B, dtype=torch.int64, device="cuda")
+    seed = torch.zeros(1, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(B, B)
+    n = 400
+    for i in range(n):
+        seed.fill_(i * 7919 + 1)
+        ops.sample_neg(S, B, out, seed=seed, salt=3)
+        o = out.cpu()
+        assert (o != torch.arange(B)).all() and (o >= 0).all() and (o < B).all()
+        counts[torch.arange(B), o] += 1
+    w = torch.softmax(S[:, :B].cpu(), dim=1)
+    w.fill_diagonal_(0)
+    w = w / w.sum(1, keepdim=True)
+    assert (counts / n - w).abs().max().item() < 0.12
+    forced = torch.arange(B, device="cuda").roll(1)
+    ops.sample_neg(S, B, out, forced=forced, offset=B)
+    assert torch.equal(out, forced + B)
+
+
+def test_lm_loss(ops):
+    nseq, L, V, Vpad = 5, 12, 300, 320
+    ids = torch.randint(1, V, (nseq, L))
+    ids[2, 7:] = 0
+    ids[4, 3:] = 0
+    logits = torch.randn(nseq * L, V).cuda()
+    logits_m = torch.randn(nseq * L, V).cuda()
+    alpha = torch.tensor([0.3], device="cuda")
+    losses = torch.zeros(8, device="cuda")
+    ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+    dl = torch.full((nseq * L, Vpad), 5.0, dtype=BF, device="cuda")
+    gs = torch.tensor([2.0], device="cuda")
+    ops.lm_loss(logits, logits_m, ids.int().cuda(), nseq=nseq, L=L, V=V, alpha=alpha, ws=ws, losses=losses, slot=0,
+                dlogits=dl, gscale=gs)
+    x = logits.view(nseq, L, V).clone().requires_grad_(True)
+    out = x[:, :-1]
+    lm = logits_m.view(nseq, L, V)[:, :-1]
+    labels = ids[:, 1:].cuda()
+    ce = torch.nn.functional.cross_entropy(out.permute(0, 2, 1), labels)
+    dist = -(torch.log_softmax(out, -1) * torch.softmax(lm, -1)).sum(-1)
+    loss = 0.7 * ce + 0.3 * dist[labels != 0].mean()
+    (2.0 * loss).backward()
+    assert abs(losses[0].item() - loss.item()) < 1e-4
+    close(dl.view(nseq, L, Vpad)[:, :, :V], x.grad, 1e-5, 1e-2, "dlogits")
+    assert dl[:, V:].abs().max().item() == 0
+
+
+def test_itm_and_mpm_heads(ops):
+    B, H = 6, 128
+    n = 3 * B
+    La, Lb = 54, 20
+    xa, xb = rnd(n * La, H, seed=80), rnd(n * Lb, H, seed=81)
+    W, bias = (torch.randn(2, 2 * H) * 0.1).cuda(), torch.randn(2).cuda()
+    losses = torch.zeros(8, device="cuda")
+    dxa, dxb = torch.zeros_like(xa), torch.zeros_like(xb)
+    dW, db = torch.zeros_like(W), torch.zeros_like(bias)
+    logits = torch.empty(n, 2, device="cuda")
+    ops.itm_head(xa, La * H, xb, Lb * H, H, W, bias, n=n, B=B, losses=losses, slot=3, logits=logits, dxa=dxa, dxb=dxb, dW=dW, db=db)
+    a = xa.float().view(n, La, H)[:, 0].clone().requires_grad_(True)
+    b2 = xb.float().view(n, Lb, H)[:, 0].clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    lg = torch.cat([a, b2], -1) @ Wr.t() + br
+    lab = torch.cat([torch.ones(B), torch.zeros(2 * B)]).long().cuda()
+    loss = torch.nn.functional.cross_entropy(lg, lab)
+    loss.backward()
+    assert abs(losses[3].item() - loss.item()) < 1e-4
+    close(logits, lg, 1e-3, 1e-4, "itm logits")
+    close(dxa.view(n, La, H)[:, 0], a.grad, 1e-4, 1e-2, "itm dxa")
+    close(dxb.view(n, Lb, H)[:, 0], b2.grad, 1e-4, 1e-2, "itm dxb")
+    assert dxa.view(n, La, H)[:, 1:].abs().max().item() == 0
+    close(dW, Wr.grad, 1e-4, 1e-3, "itm dW")
+    close(db, br.grad, 1e-5, 1e-3, "itm db")
+    # MPM
+    Lp = 54
+    h = rnd(B * Lp, H, seed=82)
+    w3, b3 = (torch.randn(H) * 0.1).cuda(), torch.randn(1).cuda()
+    target = torch.randn(B, 53).cuda()
+    mask = torch.bernoulli(torch.full((B, 53), 0.5)).cuda()
+    ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+    dh = torch.full_like(h, 3.0)
+    dw, dbb = torch.zeros_like(w3), torch.zeros_like(b3)
+    pred = torch.zeros(B, 53, device="cuda")
+    ops.mpm_head(h, Lp, H, w3, b3, target, mask, B=B, ws=ws, losses=losses, slot=1, pred=pred, dh=dh, dw=dw, db=dbb)
+    hr = h.float().view(B, Lp, H).clone().requires_grad_(True)
+    wr, brr = w3.clone().requires_grad_(True), b3.clone().requires_grad_(True)
+    pr = (hr[:, :-1] @ wr) + brr
+    keep = mask == 0
+    lossm = torch.nn.functional.mse_loss(pr[keep], target[keep]) * 5
+    lossm.backward()
+    assert abs(losses[1].item() - lossm.item()) < 1e-4 * max(1, lossm.item())
+    close(pred, pr, 1e-3, 1e-4, "mpm pred")
+    close(dh.view(B, Lp, H), hr.grad, 1e-4 * hr.grad.abs().max().item() + 1e-6, 1e-2, "mpm dh")
+    close(dw, wr.grad, 1e-3 * wr.grad.abs().max().item(), 1e-3, "mpm dw")
+    close(dbb, brr.grad, 1e-4, 1e-3, "mpm db")
+
+
+def test_enqueue_and_shadows(ops):
+    E, Q, B, n = 64, 32, 4, 8
+    queue = torch.nn.functional.normalize(torch.randn(E, Q), dim=0).cuda()
+    ldt = 64
+    w3 = torch.zeros(B + Q, 3 * E, dtype=BF, device="cuda")
+    qT = torch.zeros(E, ldt, dtype=BF, device="cuda")
+    ops.queue_shadow(queue, w3, qT, Bloc=B)
+    assert torch.equal(qT[:, B:B + Q], queue.to(BF))
+    hi = queue.t().to(BF)
+    assert torch.equal(w3[B:, :E], hi) and torch.equal(w3[B:, 2 * E:], (queue.t() - hi.float()).to(BF))
+    ptr = torch.tensor([24], device="cuda")
+    ref = queue.clone()
+    for _ in range(2):                      # second call wraps around
+        feats = torch.nn.functional.normalize(torch.randn(n, E), dim=1).cuda()
+        p0 = int(ptr.item())
+        ops.enqueue(feats, queue, w3, qT, ptr, Bloc=B)
+        ref[:, p0:p0 + n] = feats.t()
+        assert int(ptr.item()) == (p0 + n) % Q
+        assert torch.equal(queue, ref) and torch.equal(qT[:, B:B + Q], ref.to(BF)) and torch.equal(w3[B:, :E], ref.t().to(BF))
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def test_adamw_clip_ema_match_torch(ops):
+    n = 4096 * 3 + 64
+    p0 = torch.randn(n)
+    p = p0.clone().cuda()
+    pr = p0.clone().cuda().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.02)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.zeros(n, dtype=BF, device="cuda")
+    lr = torch.tensor([1e-3], device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    scal = torch.zeros(ops.adam_scalars_bytes() // 4, device="cuda")
+    for it in range(4):
+        g = torch.randn(n).cuda() * (10.0 if it % 2 == 0 else 0.01)     # clipped and un-clipped steps
+        nsq = torch.zeros(1, device="cuda")
+        ops.grad_sqnorm(g, nsq)
+        assert abs(nsq.item() - (g.double() ** 2).sum().item()) < 1e-3 * nsq.item()
+        ops.adamw_step(p, g, m, v, shadow, lr=lr, normsq=nsq, step=step, scalars=scal)
+        pr.grad = g.clone()
+        gn = torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        assert abs(scal[4].item() - gn.item()) < 1e-3 * gn.item()
+        close(p, pr.detach(), 1e-6, 1e-5, f"adamw step {it}")
+        assert torch.equal(shadow, p.to(BF))
+    assert step.item() == 4
+    # non-finite gradient: nothing moves
+    before = p.clone()
+    g = torch.full((n,), float("nan"), device="cuda")
+    nsq = torch.zeros(1, device="cuda")
+    ops.grad_sqnorm(g, nsq)
+    ops.adamw_step(p, g, m, v, shadow, lr=lr, normsq=nsq, step=step, scalars=scal)
+    assert torch.equal(p, before) and step.item() == 4
+    pm = torch.randn(n).cuda()
+    ref = pm * 0.995 + p * 0.005
+    ops.ema_update(pm, p, shadow, 0.995)
+    close(pm, ref, 1e-6, 1e-6, "ema")
+    assert torch.equal(shadow, pm.to(BF))
