@@ -1,0 +1,367 @@
+"""Step engine: schedules the HIP kernels of one SPMM pretraining step (forward, backward) on the current stream.
+
+The twelve encoder passes of SPMM.forward (SPMM_models.py:79-256, table in SURVEY.md section 3.1) are merged into six
+token-major batches that share weights, so every GEMM sees a large M and weights are streamed once per layer:
+
+  S1  PV student      layers 0..n   : P1 | P11(causal)                        2B x 54 tokens
+  S2  text student    layers 0..f-1 : P2 | P10a(causal)                       2B x Lt
+  S3  PV momentum                   : P3                                       B x 54          (no grad)
+  S4  text momentum   layers 0..f-1 : P4 | P9a(causal)                        2B x Lt          (no grad)
+  S5  text momentum   layers f..n-1 : P9b(causal, cross -> prop_embeds_m) + LM head            (no grad)
+  S6  text student    layers f..n-1 : [P5 | P7 | P12(causal)] query-PV rows (4B x 54) ++
+                                      [P6 | P8 | P10b(causal)] query-text rows (4B x Lt), cross-attending each other
+
+There is no autograd inside: forward keeps an explicit tape of the activations backward needs, backward walks it.
+Everything that changes between steps (alpha, lr, dropout seed, loss-gradient scales, queue pointer) is read from
+device memory, so the same launch sequence can be captured once into a hipGraph and replayed."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .config import BertConfig, SPMMConfig
+from .params import ParamStore
+
+BF = torch.bfloat16
+LOSS_MLM, LOSS_MPM, LOSS_ITA, LOSS_ITM = 0, 1, 2, 3
+
+
+def _ceil(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Group:
+    """A run of `nseq` equal-length sequences inside a token-major batch, attended independently."""
+    row0: int
+    nseq: int
+    L: int
+    kmask: Optional[torch.Tensor]          # int32 [nseq, L] (1 = attend) or None
+    causal_from: int                       # sequences >= causal_from (within the group) are causal
+    kv: Optional[torch.Tensor] = None      # cross-attention source, bf16 [nseq*Lkv, H]
+    Lkv: int = 0
+    kv_mask: Optional[torch.Tensor] = None
+
+    @property
+    def rows(self):
+        return slice(self.row0, self.row0 + self.nseq * self.L)
+
+
+class Engine:
+    def __init__(self, cfg: SPMMConfig, params: ParamStore, device):
+        self.cfg, self.P, self.dev = cfg, params, device
+        f32 = dict(dtype=torch.float32, device=device)
+        self.alpha = torch.zeros(1, **f32)
+        self.lr = torch.zeros(1, **f32)
+        self.gscale = torch.ones(4, **f32)                 # d(total)/d(loss_k), order (mlm, mpm, ita, itm)
+        self.losses = torch.zeros(8, **f32)
+        self.loss_scratch = torch.zeros(8, **f32)
+        self.seed = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.icount = torch.zeros(4, dtype=torch.int32, device=device)
+        self.dtemp_ita = torch.zeros(1, **f32)
+        self.train_mode = True
+        self._salt = 0
+        self.tape = None
+        E, Q = cfg.embed_dim, cfg.queue_size
+        self._bank = None          # queue GEMM shadows, sized on first use (depend on the local batch)
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _new(self, *shape, dtype=BF):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def _zeros(self, *shape, dtype=BF):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def _next_salt(self):
+        self._salt += 1
+        return self._salt * 0x9E3779B97F4A7C15 % (1 << 63)
+
+    def _p_hidden(self, c: BertConfig):
+        return c.hidden_dropout_prob if self.train_mode else 0.0
+
+    def _p_attn(self, c: BertConfig):
+        return c.attention_probs_dropout_prob if self.train_mode else 0.0
+
+    def _wT(self, key, src_fp32):
+        return self.P.wT(key, src_fp32)
+
+    def _wgrad(self, dY, X, gW, gb=None):
+        """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY.  (transposes feed the NT GEMM)"""
+        M, N = dY.shape
+        K = X.shape[1]
+        Mp = _ceil(M, 64)
+        dYT, XT = self._new(N, Mp), self._new(K, Mp)
+        ops.transpose_bf16(dY, dYT, colsum=gb)
+        ops.transpose_bf16(X, XT)
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min(Mp // 64, (768 + tiles - 1) // tiles))
+        ops.gemm_nt(dYT, XT, gW, epi=ops.EPI_F32_ATOMIC, splits=splits)
+
+    # ---------------------------------------------------------------------------------------- attention block
+    def _attn_block_fwd(self, pfx, c, X, groups, save, cross):
+        """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source."""
+        P, H, nH, M = self.P, c.hidden_size, c.num_attention_heads, X.shape[0]
+        pa, ph = self._p_attn(c), self._p_hidden(c)
+        sv = {"X": X, "lse": [], "salt_a": [], "cross": cross}
+        ctx = self._new(M, H)
+        if not cross:
+            Wqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "weight")
+            bqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="w")
+            QKV = self._new(M, 3 * H)
+            ops.gemm_nt(X, Wqkv, QKV, bias=bqkv)
+            sv["QKV"] = QKV
+            for g in groups:
+                lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
+                salt = self._next_salt()
+                r = g.rows
+                ops.attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
+                             kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt)
+                sv["lse"].append(lse)
+                sv["salt_a"].append(salt)
+        else:
+            Qc = self._new(M, H)
+            ops.gemm_nt(X, P.wb(pfx + ".self.query.weight"), Qc, bias=P.w(pfx + ".self.query.bias"))
+            Wkv = P.fused(pfx + ".self.", ("key", "value"), "weight")
+            bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
+            sv["Qc"], sv["KV"] = Qc, []
+            for g in groups:
+                KV = self._new(g.nseq * g.Lkv, 2 * H)
+                ops.gemm_nt(g.kv, Wkv, KV, bias=bkv)
+                lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
+                salt = self._next_salt()
+                r = g.rows
+                ops.attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
+                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt)
+                sv["KV"].append(KV)
+                sv["lse"].append(lse)
+                sv["salt_a"].append(salt)
+        x = self._new(M, H)
+        ops.gemm_nt(ctx, P.wb(pfx + ".output.dense.weight"), x, bias=P.w(pfx + ".output.dense.bias"))
+        y = self._new(M, H)
+        mean = self._new(M, dtype=torch.float32) if save else None
+        rstd = self._new(M, dtype=torch.float32) if save else None
+        salt = self._next_salt()
+        ops.ln_fwd(x, X, P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y, zout=x if save else None,
+                   mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt)
+        sv.update(ctx=ctx, z=x, mean=mean, rstd=rstd, salt_h=salt)
+        return y, (sv if save else None)
+
+    def _attn_block_bwd(self, pfx, c, sv, dY, groups, dkv_acc):
+        """-> dX (bf16).  Parameter gradients accumulate into the flat grad arena; cross-attention key/value source
+        gradients accumulate (fp32) into dkv_acc[i] for group i."""
+        P, H, nH = self.P, c.hidden_size, c.num_attention_heads
+        X, M = sv["X"], sv["X"].shape[0]
+        pa, ph = self._p_attn(c), self._p_hidden(c)
+        dz = self._new(M, H)
+        dx = self._new(M, H) if ph > 0 else dz
+        ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + ".output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
+                   dgamma=P.g(pfx + ".output.LayerNorm.weight"), dbeta=P.g(pfx + ".output.LayerNorm.bias"), dropout_p=ph,
+                   seed=self.seed, salt=sv["salt_h"])
+        self._wgrad(dx, sv["ctx"], P.g(pfx + ".output.dense.weight"), P.g(pfx + ".output.dense.bias"))
+        dctx = self._new(M, H)
+        ops.gemm_nt(dx, self._wT(pfx + ".output.dense", P.w(pfx + ".output.dense.weight")), dctx)
+        dX = self._new(M, H)
+        if not sv["cross"]:
+            QKV = sv["QKV"]
+            dQKV = self._new(M, 3 * H)
+            for i, g in enumerate(groups):
+                r = g.rows
+                ops.attn_bwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H],
+                             dQKV[r, H:2 * H], dQKV[r, 2 * H:], nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L, kmask=g.kmask,
+                             causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=sv["salt_a"][i])
+            self._wgrad(dQKV, X, P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="g"),
+                        P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="g"))
+            WT = self._wT(pfx + ".self.qkv", P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="w"))
+            ops.gemm_nt(dQKV, WT, dX, R=dz)
+        else:
+            Qc = sv["Qc"]
+            dQc = self._new(M, H)
+            gWkv = P.fused(pfx + ".self.", ("key", "value"), "weight", what="g")
+            gbkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="g")
+            WkvT = self._wT(pfx + ".self.kv", P.fused(pfx + ".self.", ("key", "value"), "weight", what="w"))
+            for i, g in enumerate(groups):
+                r = g.rows
+                KV = sv["KV"][i]
+                dKV = self._new(g.nseq * g.Lkv, 2 * H)
+                ops.attn_bwd(Qc[r], KV[:, :H], KV[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQc[r], dKV[:, :H], dKV[:, H:],
+                             nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask, is_cross=True, dropout_p=pa, seed=self.seed,
+                             salt=sv["salt_a"][i])
+                self._wgrad(dKV, g.kv, gWkv, gbkv)
+                ops.gemm_nt(dKV, WkvT, dkv_acc[i], epi=ops.EPI_F32_ACC)
+            self._wgrad(dQc, X, P.g(pfx + ".self.query.weight"), P.g(pfx + ".self.query.bias"))
+            ops.gemm_nt(dQc, self._wT(pfx + ".self.query", P.w(pfx + ".self.query.weight")), dX, R=dz)
+        return dX
+
+    # ------------------------------------------------------------------------------------------------- layers
+    def _layer_fwd(self, lp, c, has_cross, X, groups, save):
+        """BertLayer.forward xbert.py:469-534."""
+        P, H, I, M = self.P, c.hidden_size, c.intermediate_size, X.shape[0]
+        a, sv1 = self._attn_block_fwd(lp + "attention", c, X, groups, save, cross=False)
+        sv2 = None
+        if has_cross:
+            a, sv2 = self._attn_block_fwd(lp + "crossattention", c, a, groups, save, cross=True)
+        h, pre = self._new(M, I), self._new(M, I)
+        ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"), epi=ops.EPI_GELU, C2=pre)
+        x = self._new(M, H)
+        ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x, bias=P.w(lp + "output.dense.bias"))
+        y = self._new(M, H)
+        mean = self._new(M, dtype=torch.float32) if save else None
+        rstd = self._new(M, dtype=torch.float32) if save else None
+        salt = self._next_salt()
+        ops.ln_fwd(x, a, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
+                   mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
+        sv = dict(att=sv1, cross=sv2, a=a, h=h, pre=pre, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
+        return y, sv
+
+    def _layer_bwd(self, lp, c, sv, dY, groups, dkv_acc):
+        P, H, I, M = self.P, c.hidden_size, c.intermediate_size, dY.shape[0]
+        ph = self._p_hidden(c)
+        dz = self._new(M, H)
+        dx = self._new(M, H) if ph > 0 else dz
+        ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(lp + "output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
+                   dgamma=P.g(lp + "output.LayerNorm.weight"), dbeta=P.g(lp + "output.LayerNorm.bias"), dropout_p=ph,
+                   seed=self.seed, salt=sv["salt"])
+        self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"), P.g(lp + "output.dense.bias"))
+        dpre = self._new(M, I)
+        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_GELU_GRAD, G=sv["pre"])
+        self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"), P.g(lp + "intermediate.dense.bias"))
+        da = self._new(M, H)
+        ops.gemm_nt(dpre, self._wT(lp + "intermediate.dense", P.w(lp + "intermediate.dense.weight")), da, R=dz)
+        if sv["cross"] is not None:
+            da = self._attn_block_bwd(lp + "crossattention", c, sv["cross"], da, groups, dkv_acc)
+        return self._attn_block_bwd(lp + "attention", c, sv["att"], da, groups, None)
+
+    def stack_fwd(self, pfx, c, layers, has_cross, X, groups, save):
+        tape = []
+        for i in layers:
+            X, sv = self._layer_fwd(f"{pfx}encoder.layer.{i}.", c, has_cross and i >= c.fusion_layer, X, groups, save)
+            tape.append(sv)
+        return X, tape
+
+    def stack_bwd(self, pfx, c, layers, tape, dY, groups, dkv_acc=None):
+        for i, sv in zip(reversed(list(layers)), reversed(tape)):
+            dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
+        return dY
+
+    # --------------------------------------------------------------------------------------------- embeddings
+    def embed_text(self, pfx, c, ids32, nseq, L, save):
+        P, H = self.P, c.hidden_size
+        y = self._new(nseq * L, H)
+        z = self._new(nseq * L, H) if save else None
+        mean = self._new(nseq * L, dtype=torch.float32) if save else None
+        rstd = self._new(nseq * L, dtype=torch.float32) if save else None
+        salt = self._next_salt()
+        ops.embed_ln_fwd(0, y, nseq=nseq, L=L, H=H, pos=P.w(pfx + "embeddings.position_embeddings.weight"),
+                         type0=P.w(pfx + "embeddings.token_type_embeddings.weight"), gamma=P.w(pfx + "embeddings.LayerNorm.weight"),
+                         beta=P.w(pfx + "embeddings.LayerNorm.bias"), ids=ids32, word=P.w(pfx + "embeddings.word_embeddings.weight"),
+                         zout=z, mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
+        return y, dict(z=z, mean=mean, rstd=rstd, salt=salt)
+
+    def embed_pv(self, pfx, c, prop, mpm_mask, nseq, src_mod, save):
+        P, H, L = self.P, c.hidden_size, self.cfg.n_props + 1
+        y = self._new(nseq * L, H)
+        z = self._new(nseq * L, H) if save else None
+        mean = self._new(nseq * L, dtype=torch.float32) if save else None
+        rstd = self._new(nseq * L, dtype=torch.float32) if save else None
+        salt = self._next_salt()
+        ops.embed_ln_fwd(1, y, nseq=nseq, L=L, H=H, pos=P.w(pfx + "embeddings.position_embeddings.weight"),
+                         type0=P.w(pfx + "embeddings.token_type_embeddings.weight"), gamma=P.w(pfx + "embeddings.LayerNorm.weight"),
+                         beta=P.w(pfx + "embeddings.LayerNorm.bias"), pv_x=prop, pv_mask=mpm_mask, pv_w=P.w("property_embed.weight"),
+                         pv_b=P.w("property_embed.bias"), pv_cls=P.w("property_cls"), pv_masktok=P.w("property_mask"),
+                         src_mod=src_mod, zout=z, mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c),
+                         seed=self.seed, salt=salt)
+        return y, dict(z=z, mean=mean, rstd=rstd, salt=salt)
+
+    def _embed_ln_bwd(self, pfx, c, sv, dY):
+        P = self.P
+        dz = self._new(*dY.shape)
+        ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + "embeddings.LayerNorm.weight"), dz,
+                   dgamma=P.g(pfx + "embeddings.LayerNorm.weight"), dbeta=P.g(pfx + "embeddings.LayerNorm.bias"),
+                   dropout_p=self._p_hidden(c), seed=self.seed, salt=sv["salt"], drop_on_dy=True)
+        return dz
+
+    # ------------------------------------------------------------------------------------------------ LM head
+    def lm_head_fwd(self, pfx, c, X, save):
+        """BertOnlyMLMHead xbert.py:662-706 -> fp32 logits [M, V]."""
+        P, H, V, M = self.P, c.hidden_size, c.vocab_size, X.shape[0]
+        t, pre = self._new(M, H), self._new(M, H)
+        ops.gemm_nt(X, P.wb(pfx + "cls.predictions.transform.dense.weight"), t, bias=P.w(pfx + "cls.predictions.transform.dense.bias"),
+                    epi=ops.EPI_GELU, C2=pre)
+        y = self._new(M, H)
+        mean = self._new(M, dtype=torch.float32) if save else None
+        rstd = self._new(M, dtype=torch.float32) if save else None
+        ops.ln_fwd(t, None, P.w(pfx + "cls.predictions.transform.LayerNorm.weight"), P.w(pfx + "cls.predictions.transform.LayerNorm.bias"),
+                   y, zout=t if save else None, mean=mean, rstd=rstd, eps=c.layer_norm_eps)
+        logits = self._new(M, V, dtype=torch.float32)
+        ops.gemm_nt(y, P.wb(pfx + "cls.predictions.decoder.weight"), logits, bias=P.w(pfx + "cls.predictions.bias"), epi=ops.EPI_F32)
+        return logits, dict(X=X, pre=pre, z=t, mean=mean, rstd=rstd, y=y)
+
+    def lm_head_bwd(self, pfx, c, sv, dlogits):
+        """dlogits bf16 [M, Vpad] (zero padded) -> dX bf16 [M,H]; the decoder is tied to the word embeddings."""
+        P, H, V, M = self.P, c.hidden_size, c.vocab_size, dlogits.shape[0]
+        Vp = dlogits.shape[1]
+        # wgrad of the tied decoder: dWord[V,H] += dlogits^T y ; dbias += colsum
+        self._wgrad(dlogits[:, :V], sv["y"], P.g(pfx + "bert.embeddings.word_embeddings.weight"), P.g(pfx + "cls.predictions.bias"))
+        key = pfx + "cls.decoderT"
+        if key not in self.P._wT:           # [H, Vpad] zero-padded transposed shadow (K of the dgrad GEMM must be %64)
+            self.P._wT[key] = torch.zeros(H, Vp, dtype=BF, device=self.dev)
+            self.P._wT_pad = getattr(self.P, "_wT_pad", {})
+            self.P._wT_pad[key] = (pfx + "bert.embeddings.word_embeddings.weight", V)
+            self.refresh_padded_shadows()
+        dy = self._new(M, H)
+        ops.gemm_nt(dlogits, self.P._wT[key], dy)
+        dz = self._new(M, H)
+        ops.ln_bwd(dy, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + "cls.predictions.transform.LayerNorm.weight"), dz,
+                   dgamma=P.g(pfx + "cls.predictions.transform.LayerNorm.weight"), dbeta=P.g(pfx + "cls.predictions.transform.LayerNorm.bias"))
+        # through the erf-GELU: dpre = dz * gelu'(pre)  (identity GEMM would be wasteful: reuse the GELU-grad epilogue of the dgrad)
+        dpre = self._gelu_bwd(dz, sv["pre"])
+        self._wgrad(dpre, sv["X"], P.g(pfx + "cls.predictions.transform.dense.weight"), P.g(pfx + "cls.predictions.transform.dense.bias"))
+        dX = self._new(M, H)
+        ops.gemm_nt(dpre, self._wT(pfx + "cls.transform", P.w(pfx + "cls.predictions.transform.dense.weight")), dX)
+        return dX
+
+    def refresh_padded_shadows(self):
+        for key, (name, V) in getattr(self.P, "_wT_pad", {}).items():
+            self.P._wT[key][:, :V].copy_(self.P.w(name).t())
+
+    def _gelu_bwd(self, dz, pre):
+        """elementwise dz * gelu'(pre) (small head tensors only) -- torch elementwise ops as plumbing."""
+        x = pre.float()
+        cdf = 0.5 * (1.0 + torch.erf(x * 0.7071067811865476))
+        pdf = torch.exp(-0.5 * x * x) * 0.3989422804014327
+        return (dz.float() * (cdf + x * pdf)).to(BF)
+
+    # ---------------------------------------------------------------------------------------------- features
+    def _feat_fwd(self, proj, X, L, B, save):
+        """normalize(proj(X[:, 0, :])) SPMM_models.py:92,95,101,105 -> (feat f32 [B,E], tape)."""
+        P, E, H = self.P, self.cfg.embed_dim, self.cfg.text.hidden_size
+        cls = X.view(-1, L * H)[:B, :H]                     # strided CLS rows, row stride L*H
+        raw = self._new(B, E, dtype=torch.float32)
+        ops.gemm_nt(cls, P.wb(proj + ".weight"), raw, bias=P.w(proj + ".bias"), epi=ops.EPI_F32)
+        feat = self._new(B, E, dtype=torch.float32)
+        nrm = self._new(B, dtype=torch.float32)
+        return raw, feat, nrm, cls
+
+    # ------------------------------------------------------------------------------------------------- banks
+    def _banks(self, B):
+        """bf16 GEMM shadows of the two feature banks [feat_m^T | queue] (SPMM_models.py:102,106)."""
+        if self._bank is not None and self._bank["B"] == B:
+            return self._bank
+        E, Q = self.cfg.embed_dim, self.cfg.queue_size
+        J = B + Q
+        Jp = _ceil(J, 64)
+        bank = {"B": B, "J": J, "Jp": Jp}
+        for nm in ("prop", "text"):
+            w3 = torch.zeros(J, 3 * E, dtype=BF, device=self.dev)
+            qT = torch.zeros(E, Jp, dtype=BF, device=self.dev)
+            ops.queue_shadow(self.P.buffers[nm + "_queue"], w3, qT, Bloc=B)
+            bank[nm] = (w3, qT)
+        self._bank = bank
+        return bank
+
+    def invalidate_banks(self):
+        self._bank = None

@@ -1,0 +1,267 @@
+"""`SPMM` -- drop-in for the reference's SPMM_models.SPMM on the pretraining path.
+
+Same constructor (`SPMM(tokenizer=None, config=None, loader_len=0, no_train=False)`, SPMM_models.py:17), same
+`forward(property_original, text_input_ids, text_attention_mask, alpha=0)` -> `(loss_mlm, loss_mpm*5, loss_ita, loss_itm)`
+(:79,:256), same `state_dict()` keys / [out,in] fp32 layout, same `training_step` /
+`configure_optimizers` semantics (:338-380) without the pytorch_lightning dependency (not installed on the target image).
+All arithmetic runs in the HIP kernels of libspmm_hip.so; there is no eager / CPU fallback."""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import SPMMConfig, is_buffer, student_of
+from .params import ParamStore
+from .step import PretrainStep
+
+
+class _CosineSchedule:
+    """scheduler/cosine_lr.py:69-96 as configured by scheduler_factory.py:27-42 for SPMM_pretrain.py:62-63
+    (t_mul=1, decay_rate=1, cycle_limit=1, warmup_prefix=True, t_in_epochs=True): only `step(epoch)` is used."""
+
+    def __init__(self, sched: dict):
+        self.s = sched
+
+    def lr_at(self, t: int) -> float:
+        s = self.s
+        warm, base = s["warmup_epochs"], s["lr"]
+        if t < warm:
+            return s["warmup_lr"] + t * (base - s["warmup_lr"]) / warm
+        t -= warm
+        if t // s["epochs"] < 1:
+            return s["min_lr"] + 0.5 * (base - s["min_lr"]) * (1 + math.cos(math.pi * t / s["epochs"]))
+        return s["min_lr"]
+
+
+class _FusedAdamW:
+    """AdamW(lr, weight_decay on all params, betas (0.9,0.999), eps 1e-8) SPMM_models.py:340 + clip_grad_norm_(5.) :361
+    as three launches over the flat arena; exposes `param_groups[0]['lr']` like a torch optimizer."""
+
+    def __init__(self, store: ParamStore, eng: PretrainStep, lr: float, weight_decay: float):
+        self.store, self.eng = store, eng
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": (0.9, 0.999), "eps": 1e-8}]
+        dev = store.device
+        self.normsq = torch.zeros(1, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scalars = torch.zeros(ops.adam_scalars_bytes() // 4, device=dev)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.store.grad.zero_()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.eng.lr.fill_(g["lr"])
+        self.normsq.zero_()
+        ops.grad_sqnorm(self.store.grad, self.normsq)
+        ops.adamw_step(self.store.flat, self.store.grad, self.store.adam_m, self.store.adam_v, self.store.shadow, lr=self.eng.lr,
+                       beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], normsq=self.normsq,
+                       max_norm=5.0, step=self.step_count, nan_flag=self.eng.nan_flag, scalars=self.scalars)
+        self.store.refresh_shadows(transposed_only=True)
+        self.eng.refresh_padded_shadows()
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        return self.scalars[4]
+
+
+class _StepFn(torch.autograd.Function):
+    """Autograd boundary: the four losses are functions of every trainable parameter; backward runs the engine's own
+    backward with the incoming loss gradients as device-side scales and hands back views of the flat gradient arena."""
+
+    @staticmethod
+    def forward(ctx, model, prop, ids, mask, kw, *params):
+        losses = model.engine.forward(prop, ids, mask, **kw)
+        ctx.model = model
+        return tuple(losses[i].clone() for i in range(4))
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        m = ctx.model
+        m.engine.gscale.copy_(torch.stack([g.reshape(()).to(torch.float32) for g in (g0, g1, g2, g3)]))
+        m.store.grad.zero_()
+        m.engine.backward()
+        grads = tuple(m.store.g(n) for n in m._param_names)
+        return (None, None, None, None, None) + grads
+
+
+class SPMM(nn.Module):
+    def __init__(self, tokenizer=None, config=None, loader_len=0, no_train=False, device=None, spmm_config: Optional[SPMMConfig] = None):
+        super().__init__()
+        if not torch.cuda.is_available() and not ops._DRY_RUN:
+            raise RuntimeError("spmm_amd.SPMM needs an MI355X (HIP device); there is no CPU fallback")
+        self.automatic_optimization = False
+        self.config = config
+        self.tokenizer = tokenizer
+        self.training_step_outputs = []
+        if device is None:
+            device = "cpu" if ops._DRY_RUN else f"cuda:{torch.cuda.current_device()}"
+        self.device_ = torch.device(device)
+        self.cfg = spmm_config if spmm_config is not None else SPMMConfig.from_reference_dict(config)
+        self.no_train = no_train
+        self.store = ParamStore(self.cfg, self.device_, train=not no_train)
+        self.engine = PretrainStep(self.cfg, self.store, self.device_)
+        self._param_names = []
+        # register every tensor under the reference's state_dict name (dots are legal in _parameters/_buffers keys)
+        for name, t in self.store.named_tensors():
+            if is_buffer(name):
+                self._buffers[name] = t
+            elif self.store.kind[name] in ("tied_w", "tied_b"):
+                continue                                            # added to state_dict() as aliases
+            else:
+                p = nn.Parameter(t, requires_grad=(student_of(name) is None) and not no_train)
+                self._parameters[name] = p
+                if p.requires_grad:
+                    self._param_names.append(name)
+        self._init_weights()
+        if not no_train and config is not None:
+            self.mlm_probability = config.get("mlm_probability", 0.15)
+            self.warmup_steps = config["schedular"]["warmup_epochs"]
+            self.loader_len = loader_len
+            self.momentum = config["momentum"]
+            self.queue_size = config["queue_size"]
+        self.current_epoch = 0
+        self.global_rank = 0
+        self._optimizer = None
+        self._scheduler = None
+        self.logged = {}
+
+    # ---- init (xbert.py:742-752, SPMM_models.py:31-44, :62, :66, :72-77) ------------------------------------------------
+    @torch.no_grad()
+    def _init_weights(self):
+        st, cfg = self.store, self.cfg
+        g = torch.Generator(device="cpu").manual_seed(torch.initial_seed() % (2 ** 31))
+        for name, shape, kind in st.spec:
+            if student_of(name) is not None or is_buffer(name) or kind in ("tied_w", "tied_b"):
+                continue
+            t = st.w(name)
+            in_bert = ("encoder." in name) or (".bert." in name) or (".cls." in name)
+            if kind in ("emb",) or (kind == "lin_w" and in_bert):
+                t.copy_(torch.randn(shape, generator=g) * cfg.text.initializer_range)
+            elif kind == "lin_w":
+                t.copy_((torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(shape[-1]))
+            elif kind == "lin_b":
+                if in_bert:
+                    t.zero_()
+                else:
+                    fan_in = {"property_embed.bias": 1, "itm_head.bias": 2 * cfg.text.hidden_size}.get(name, cfg.text.hidden_size)
+                    t.copy_((torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in))
+            elif kind == "ln_w":
+                t.fill_(1.0)
+            elif kind in ("ln_b", "zero"):
+                t.zero_()
+            elif kind == "temp":
+                t.fill_(cfg.temp)
+        for nm in ("prop_queue", "text_queue"):
+            q = torch.randn(st.shape[nm], generator=g)
+            st.buffers[nm].copy_(torch.nn.functional.normalize(q, dim=0))
+        st.refresh_shadows()
+        st.copy_params()
+        self.engine.invalidate_banks()
+
+    # ---- state_dict with the reference's 758 keys ------------------------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        for name, t in self.store.named_tensors():
+            out[prefix + name] = t if keep_vars else t.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        missing, unexpected = self.store.load_state_dict(state_dict, strict=strict)
+        self.engine.refresh_padded_shadows()
+        self.engine.invalidate_banks()
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    @property
+    def temp(self):
+        return self._parameters["temp"]
+
+    @property
+    def queue_ptr(self):
+        return self.store.buffers["queue_ptr"]
+
+    # ---- forward / training_step -------------------------------------------------------------------------------------------
+    def forward(self, property_original, text_input_ids, text_attention_mask, alpha=0, *, mpm_mask=None, neg_idx=None, aux=None):
+        """SPMM.forward SPMM_models.py:79-256.  Extra keyword-only arguments inject the reference's recorded random draws."""
+        eng = self.engine
+        eng.train_mode = self.training
+        eng.alpha.fill_(float(alpha))
+        kw = dict(mpm_mask=mpm_mask, neg_idx=neg_idx, aux=aux, gather=self._gather_fn())
+        dev = self.device_
+        args = (property_original.to(dev), text_input_ids.to(dev), text_attention_mask.to(dev))
+        if torch.is_grad_enabled() and not self.no_train:
+            params = [self._parameters[n] for n in self._param_names]
+            losses = _StepFn.apply(self, *args, kw, *params)
+        else:
+            kw["save"] = False
+            l = eng.forward(*args, **kw)
+            losses = tuple(l[i].clone() for i in range(4))
+        return losses
+
+    def _gather_fn(self):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .parallel import all_gather_features
+            return all_gather_features
+        return None
+
+    def configure_optimizers(self):
+        """SPMM_models.py:338-343."""
+        opt = _FusedAdamW(self.store, self.engine, lr=self.config["optimizer"]["lr"], weight_decay=self.config["optimizer"]["weight_decay"])
+        sch = _CosineSchedule(self.config["schedular"])
+        opt.param_groups[0]["lr"] = sch.lr_at(0)          # Scheduler.__init__ installs the warm-up start value
+        self._optimizer, self._scheduler = opt, sch
+        return [opt], [sch]
+
+    def optimizers(self):
+        if self._optimizer is None:
+            self.configure_optimizers()
+        return self._optimizer
+
+    def lr_schedulers(self):
+        if self._scheduler is None:
+            self.configure_optimizers()
+        return self._scheduler
+
+    def fused_step(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None, grad_sync=None):
+        """zero_grad -> forward -> backward (unit loss weights, SPMM_models.py:358) -> [grad all-reduce] -> clip -> AdamW,
+        with no host synchronisation.  Returns the device tensor of the four losses."""
+        eng, opt = self.engine, self.optimizers()
+        eng.train_mode = self.training
+        eng.alpha.fill_(float(alpha))
+        eng.seed.add_(1)
+        eng.gscale.fill_(1.0)
+        self.store.grad.zero_()
+        dev = self.device_
+        losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn())
+        eng.backward()
+        if grad_sync is not None:
+            grad_sync(self.store.grad)
+        opt.step()
+        return losses
+
+    def training_step(self, train_batch, batch_idx):
+        """SPMM_models.py:348-380 (tokenisation :353 is the caller's job when `text` is already a tensor pair)."""
+        prop, text = train_batch
+        if isinstance(text, (tuple, list)) and torch.is_tensor(text[0]):
+            ids, mask = text
+        else:
+            ti = self.tokenizer(text, padding="longest", truncation=True, max_length=100, return_tensors="pt")
+            ids, mask = ti.input_ids[:, 1:], ti.attention_mask[:, 1:]
+        alpha = self.config["alpha"] if self.current_epoch > 0 else self.config["alpha"] * min(1., batch_idx / self.loader_len)
+        opt, sch = self.optimizers(), self.lr_schedulers()
+        from .parallel import grad_sync_fn
+        losses = self.fused_step(prop, ids, mask, alpha, grad_sync=grad_sync_fn())
+        if self.global_rank == 0:
+            self.logged = {"lr": opt.param_groups[0]["lr"], "losses": losses}
+        step_size, warm = 100, self.warmup_steps
+        if self.current_epoch > 0 and batch_idx == 0:
+            opt.param_groups[0]["lr"] = sch.lr_at(self.current_epoch + warm)
+        elif self.current_epoch == 0 and batch_idx % step_size == 0 and batch_idx <= warm * step_size:
+            opt.param_groups[0]["lr"] = sch.lr_at(batch_idx // step_size)
+        out = losses.detach().clone()
+        self.training_step_outputs.append(out)
+        return out

@@ -10,12 +10,34 @@ EPI_BF16, EPI_GELU, EPI_F32, EPI_F32_ATOMIC, EPI_GELU_GRAD, EPI_F32_ACC = range(
 BF16 = torch.bfloat16
 
 
+_DRY_RUN = False        # tests only: validate every call against the header's prototype without launching anything
+_dry_log = []
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
 def _st():
+    if _DRY_RUN:
+        return None
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _call(name, *args):
+    if not _DRY_RUN:
+        return lib().call(name, *args)
+    res, argtypes = lib().protos[name]
+    if len(args) != len(argtypes):
+        raise TypeError(f"{name}: {len(args)} arguments, header declares {len(argtypes)}")
+    for i, (a, t) in enumerate(zip(args, argtypes)):
+        try:
+            t(a) if not isinstance(a, ctypes.c_void_p) else None
+        except Exception as e:   # noqa: BLE001
+            raise TypeError(f"{name}: argument {i} = {a!r} is not a {t.__name__}") from e
+        if t is ctypes.c_void_p and not (a is None or isinstance(a, (ctypes.c_void_p, int))):
+            raise TypeError(f"{name}: argument {i} must be a pointer, got {type(a)}")
+    _dry_log.append(name)
 
 
 def _row_stride(t):
@@ -33,7 +55,7 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
         assert C.dtype == BF16
     else:
         assert C.dtype == torch.float32
-    lib().call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
+    _call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
                float(alpha), _p(R), 0 if R is None else _row_stride(R), _p(G), 0 if G is None else _row_stride(G),
                _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _st())
     return C
@@ -43,7 +65,7 @@ def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None
              seed=None, salt=0):
     """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]."""
     cf = nseq if causal_from is None else causal_from
-    lib().call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
+    _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
                _row_stride(O), _p(lse), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
     return O
 
@@ -51,14 +73,14 @@ def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None
 def attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False,
              dropout_p=0.0, seed=None, salt=0):
     cf = nseq if causal_from is None else causal_from
-    lib().call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
+    _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
                _row_stride(O), _p(lse), _p(dO), _row_stride(dO), _p(dQ), _row_stride(dQ), _p(dK), _row_stride(dK), _p(dV),
                _row_stride(dV), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
 
 
 def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0):
     rows, H = x.shape
-    lib().call("spmm_ln_fwd", _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(zout), _p(mean), _p(rstd), rows, H, float(eps),
+    _call("spmm_ln_fwd", _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(zout), _p(mean), _p(rstd), rows, H, float(eps),
                float(dropout_p), _p(seed), salt, _st())
     return y
 
@@ -66,7 +88,7 @@ def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12
 def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbeta=None, dropout_p=0.0, seed=None, salt=0,
            drop_on_dy=False):
     rows, H = dy.shape
-    lib().call("spmm_ln_bwd", _p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
+    _call("spmm_ln_bwd", _p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
                rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _st())
     return dz
 
@@ -74,7 +96,7 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbet
 def embed_ln_fwd(mode, y, *, nseq, L, H, pos, type0, gamma, beta, ids=None, word=None, pv_x=None, pv_mask=None, pv_w=None,
                  pv_b=None, pv_cls=None, pv_masktok=None, src_mod=1, zout=None, mean=None, rstd=None, eps=1e-12,
                  dropout_p=0.0, seed=None, salt=0):
-    lib().call("spmm_embed_ln_fwd", mode, _p(ids), _p(word), _p(pos), _p(type0), _p(pv_x), _p(pv_mask), _p(pv_w), _p(pv_b),
+    _call("spmm_embed_ln_fwd", mode, _p(ids), _p(word), _p(pos), _p(type0), _p(pv_x), _p(pv_mask), _p(pv_w), _p(pv_b),
                _p(pv_cls), _p(pv_masktok), src_mod, _p(gamma), _p(beta), _p(y), _p(zout), _p(mean), _p(rstd), nseq, L, H,
                float(eps), float(dropout_p), _p(seed), salt, _st())
     return y
@@ -82,66 +104,66 @@ def embed_ln_fwd(mode, y, *, nseq, L, H, pos, type0, gamma, beta, ids=None, word
 
 def embed_bwd(mode, dz, *, nseq, L, H, dpos, dtype0, ids=None, dword=None, pv_x=None, pv_mask=None, src_mod=1, d_w=None,
               d_b=None, d_cls=None, d_masktok=None):
-    lib().call("spmm_embed_bwd", mode, _p(dz), _p(ids), _p(pv_x), _p(pv_mask), src_mod, _p(dword), _p(dpos), _p(dtype0),
+    _call("spmm_embed_bwd", mode, _p(dz), _p(ids), _p(pv_x), _p(pv_mask), src_mod, _p(dword), _p(dpos), _p(dtype0),
                _p(d_w), _p(d_b), _p(d_cls), _p(d_masktok), nseq, L, H, _st())
 
 
 def transpose_bf16(x, out, *, Rpad=None, colsum=None):
     R, C = x.shape
     Rpad = out.shape[1] if Rpad is None else Rpad
-    lib().call("spmm_transpose_bf16", _p(x), _row_stride(x), _p(out), _row_stride(out), R, C, Rpad, _p(colsum), _st())
+    _call("spmm_transpose_bf16", _p(x), _row_stride(x), _p(out), _row_stride(out), R, C, Rpad, _p(colsum), _st())
     return out
 
 
 def cast_transpose(w32, out, outT):
     R, C = w32.shape
-    lib().call("spmm_cast_transpose", _p(w32), _p(out), _p(outT), R, C, _st())
+    _call("spmm_cast_transpose", _p(w32), _p(out), _p(outT), R, C, _st())
 
 
 def cast_f32_bf16(x, out):
-    lib().call("spmm_cast_f32_bf16", _p(x), _p(out), x.numel(), _st())
+    _call("spmm_cast_f32_bf16", _p(x), _p(out), x.numel(), _st())
     return out
 
 
 def cast_bf16_f32(x, out):
-    lib().call("spmm_cast_bf16_f32", _p(x), _p(out), x.numel(), _st())
+    _call("spmm_cast_bf16_f32", _p(x), _p(out), x.numel(), _st())
     return out
 
 
 def acc_rows(dst, src, *, idx=None, atomic=False):
     rows, H = src.shape
-    lib().call("spmm_acc_rows", _p(dst), _row_stride(dst), _p(src), _row_stride(src), _p(idx), rows, H, int(atomic), _st())
+    _call("spmm_acc_rows", _p(dst), _row_stride(dst), _p(src), _row_stride(src), _p(idx), rows, H, int(atomic), _st())
 
 
 def gather_rows(dst, src, idx):
     rows, H = dst.shape
-    lib().call("spmm_gather_rows", _p(dst), _p(src), _p(idx), rows, H, _st())
+    _call("spmm_gather_rows", _p(dst), _p(src), _p(idx), rows, H, _st())
     return dst
 
 
 def l2norm_fwd(x, y, nrm, *, a3=None, w3=None, yT=None):
     rows, E = y.shape
-    lib().call("spmm_l2norm_fwd", _p(x), _row_stride(x), _p(y), _p(nrm), _p(a3), _p(w3), _p(yT),
+    _call("spmm_l2norm_fwd", _p(x), _row_stride(x), _p(y), _p(nrm), _p(a3), _p(w3), _p(yT),
                0 if yT is None else _row_stride(yT), rows, E, _st())
 
 
 def l2norm_bwd(dy, y, nrm, dx, *, gscale=None):
     rows, E = y.shape
-    lib().call("spmm_l2norm_bwd", _p(dy), _p(y), _p(nrm), _p(gscale), _p(dx), rows, E, _st())
+    _call("spmm_l2norm_bwd", _p(dy), _p(y), _p(nrm), _p(gscale), _p(dx), rows, E, _st())
 
 
 def ita_rows(S, SM, dS, *, B, J, alpha, temp, losses, slot, dtemp, nan_flag=None):
     nrows = S.shape[0]
-    lib().call("spmm_ita_rows", _p(S), _p(SM), _row_stride(S), nrows, B, J, _p(alpha), _p(temp), _p(dS), _row_stride(dS),
+    _call("spmm_ita_rows", _p(S), _p(SM), _row_stride(S), nrows, B, J, _p(alpha), _p(temp), _p(dS), _row_stride(dS),
                dS.shape[1], _p(losses), slot, _p(dtemp), _p(nan_flag), _st())
 
 
 def sample_neg(S, B, out, *, forced=None, seed=None, salt=0, offset=0):
-    lib().call("spmm_sample_neg", _p(S), _row_stride(S), B, _p(forced), _p(seed), salt, _p(out), offset, _st())
+    _call("spmm_sample_neg", _p(S), _row_stride(S), B, _p(forced), _p(seed), salt, _p(out), offset, _st())
 
 
 def lm_loss(logits, logits_m, ids, *, nseq, L, V, alpha, ws, losses, slot, dlogits=None, gscale=None):
-    lib().call("spmm_lm_loss", _p(logits), _p(logits_m), _row_stride(logits), _p(ids), nseq, L, V, _p(alpha), _p(ws),
+    _call("spmm_lm_loss", _p(logits), _p(logits_m), _row_stride(logits), _p(ids), nseq, L, V, _p(alpha), _p(ws),
                _p(gscale), _p(dlogits), 0 if dlogits is None else _row_stride(dlogits),
                V if dlogits is None else dlogits.shape[1], _p(losses), slot, _st())
 
@@ -149,29 +171,29 @@ def lm_loss(logits, logits_m, ids, *, nseq, L, V, alpha, ws, losses, slot, dlogi
 def itm_head(xa, stride_a, xb, stride_b, H, W, bias, *, n, B, losses, slot, logits=None, dxa=None, dxb=None, dW=None,
              db=None, gscale=None):
     do_bwd = dxa is not None
-    lib().call("spmm_itm_head", _p(xa), stride_a, _p(xb), stride_b, H, _p(W), _p(bias), n, B, _p(gscale), _p(losses), slot,
+    _call("spmm_itm_head", _p(xa), stride_a, _p(xb), stride_b, H, _p(W), _p(bias), n, B, _p(gscale), _p(losses), slot,
                _p(logits), _p(dxa), _p(dxb), _p(dW), _p(db), int(do_bwd), _st())
 
 
 def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None, dh=None, dw=None, db=None, gscale=None):
     do_bwd = dh is not None
-    lib().call("spmm_mpm_head", _p(h), Lp, H, _p(w), _p(bias), _p(target), _p(mask), B, _p(ws), _p(gscale), _p(losses), slot,
+    _call("spmm_mpm_head", _p(h), Lp, H, _p(w), _p(bias), _p(target), _p(mask), B, _p(ws), _p(gscale), _p(losses), slot,
                _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), _st())
 
 
 def enqueue(feats, queue, w3, qT, ptr, *, Bloc, advance=True):
     n, E = feats.shape
-    lib().call("spmm_enqueue", _p(feats), n, E, _p(queue), queue.shape[1], _p(w3), _p(qT), _row_stride(qT), Bloc, _p(ptr),
+    _call("spmm_enqueue", _p(feats), n, E, _p(queue), queue.shape[1], _p(w3), _p(qT), _row_stride(qT), Bloc, _p(ptr),
                int(advance), _st())
 
 
 def queue_shadow(queue, w3, qT, *, Bloc):
     E, Q = queue.shape
-    lib().call("spmm_queue_shadow", _p(queue), E, Q, _p(w3), _p(qT), _row_stride(qT), Bloc, _st())
+    _call("spmm_queue_shadow", _p(queue), E, Q, _p(w3), _p(qT), _row_stride(qT), Bloc, _st())
 
 
 def clamp_scalar(p, lo, hi):
-    lib().call("spmm_clamp_scalar", _p(p), float(lo), float(hi), _st())
+    _call("spmm_clamp_scalar", _p(p), float(lo), float(hi), _st())
 
 
 def adam_scalars_bytes():
@@ -179,18 +201,18 @@ def adam_scalars_bytes():
 
 
 def grad_sqnorm(g, out):
-    lib().call("spmm_grad_sqnorm", _p(g), g.numel(), _p(out), _st())
+    _call("spmm_grad_sqnorm", _p(g), g.numel(), _p(out), _st())
 
 
 def adamw_step(p, g, m, v, shadow, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.02, normsq, max_norm=5.0, step,
                nan_flag=None, scalars):
-    lib().call("spmm_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(lr), beta1, beta2, eps, weight_decay,
+    _call("spmm_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(lr), beta1, beta2, eps, weight_decay,
                _p(normsq), max_norm, _p(step), _p(nan_flag), _p(scalars), _st())
 
 
 def ema_update(pm, p, shadow, momentum):
-    lib().call("spmm_ema_update", _p(pm), _p(p), _p(shadow), pm.numel(), float(momentum), _st())
+    _call("spmm_ema_update", _p(pm), _p(p), _p(shadow), pm.numel(), float(momentum), _st())
 
 
 def axpy_scalar(dst, src, *, scale_ptr=None, scale=1.0):
-    lib().call("spmm_axpy_scalar", _p(dst), _p(src), _p(scale_ptr), float(scale), dst.numel(), _st())
+    _call("spmm_axpy_scalar", _p(dst), _p(src), _p(scale_ptr), float(scale), dst.numel(), _st())

@@ -1,0 +1,247 @@
+"""One SPMM pretraining step on the engine: SPMM.forward (SPMM_models.py:79-256) and its backward."""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import ops
+from .engine import BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, _ceil
+
+
+class PretrainStep(Engine):
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, prop: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, *, mpm_mask: Optional[torch.Tensor] = None,
+                neg_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, gather: Optional[Callable] = None,
+                save: bool = True, aux: Optional[dict] = None) -> torch.Tensor:
+        """Returns the device tensor losses[0:4] = (loss_mlm, 5*loss_mpm, loss_ita, loss_itm).  `alpha` is read from
+        self.alpha (device).  Mutates temp (clamp), the momentum arena (EMA), the queues and the queue pointer exactly as
+        the reference's forward does."""
+        cfg, P = self.cfg, self.P
+        ct, cp = cfg.text, cfg.prop
+        H, E, Lp, f, n = ct.hidden_size, cfg.embed_dim, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
+        B, Lt = ids.shape
+        if B % 4 or cfg.queue_size % 4:
+            raise ValueError("batch size and queue size must be multiples of 4")
+        self._salt = 0
+        self.losses.zero_()
+        self.dtemp_ita.zero_()
+        self.nan_flag.zero_()
+        temp = P.w("temp").view(1)
+        ops.clamp_scalar(temp, 0.01, 0.5)                                             # :80-81
+        ids32 = ids.to(torch.int32).contiguous()
+        mask32 = mask.to(torch.int32).contiguous()
+        prop = prop.to(torch.float32).contiguous()
+        if mpm_mask is None:                                                          # :85 bernoulli(0.5)
+            mpm_mask = (torch.rand(B, cfg.n_props, device=self.dev) < 0.5).to(torch.float32)
+        mpm_mask = mpm_mask.to(torch.float32).contiguous()
+
+        # ---- S1 / S2: student unimodal encoders (:90-95) batched with their causal twins (:224, :242)
+        x1, esv1 = self.embed_pv("property_encoder.", cp, prop, mpm_mask, 2 * B, B, save)
+        g1 = [Group(0, 2 * B, Lp, None, B)]
+        y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save)
+        prop_embeds, prop_embeds_causal = y1[:B * Lp], y1[B * Lp:]
+        ids2, mask2 = torch.cat([ids32, ids32]), torch.cat([mask32, mask32])
+        x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
+        g2 = [Group(0, 2 * B, Lt, mask2, B)]
+        y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
+        text_embeds, hidden10 = y2[:B * Lt], y2[B * Lt:]
+
+        # ---- momentum branch (:98-106, :215-222), no tape
+        ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)                     # :99 / :266-269
+        x3, _ = self.embed_pv("property_encoder_m.", cp, prop, mpm_mask, B, B, False)
+        prop_embeds_m, _ = self.stack_fwd("property_encoder_m.", cp, range(cp.num_hidden_layers), False, x3,
+                                          [Group(0, B, Lp, None, B)], False)
+        x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
+        y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g2, False)
+        text_embeds_m, hidden9 = y4[:B * Lt], y4[B * Lt:]
+        g5 = [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
+        y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
+        logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
+
+        # ---- features, similarity banks, ITA loss and its gradient w.r.t. the student features (:92-131)
+        bank = self._banks(B)
+        J, Jp = bank["J"], bank["Jp"]
+        A3 = self._new(4 * B, 3 * E)
+        feats = {}
+        for k, (proj, X, L, w3, qT) in enumerate((("property_proj", prop_embeds, Lp, None, None),
+                                                  ("text_proj", text_embeds, Lt, None, None),
+                                                  ("property_proj_m", prop_embeds_m, Lp, *bank["prop"]),
+                                                  ("text_proj_m", text_embeds_m, Lt, *bank["text"]))):
+            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save)
+            ops.l2norm_fwd(raw, feat, nrm, a3=A3[k * B:(k + 1) * B], w3=None if w3 is None else w3[:B], yT=qT)
+            feats[proj] = (feat, nrm, cls)
+        S_text = self._new(4 * B, J, dtype=torch.float32)     # rows: i2t | t2t | i2t_m | t2t_m
+        S_prop = self._new(4 * B, J, dtype=torch.float32)     # rows: i2i | t2i | i2i_m | t2i_m
+        ops.gemm_nt(A3, bank["text"][0], S_text, epi=ops.EPI_F32, div=temp)
+        ops.gemm_nt(A3, bank["prop"][0], S_prop, epi=ops.EPI_F32, div=temp)
+        dS_text, dS_prop = self._new(2 * B, Jp), self._new(2 * B, Jp)
+        for S, dS in ((S_text, dS_text), (S_prop, dS_prop)):
+            ops.ita_rows(S[:2 * B], S[2 * B:], dS, B=B, J=J, alpha=self.alpha, temp=temp, losses=self.losses, slot=LOSS_ITA,
+                         dtemp=self.dtemp_ita, nan_flag=self.nan_flag)
+        dfeat = None
+        if save:   # d loss_ita / d [prop_feat ; text_feat], before the queue is overwritten (:208)
+            dfeat = self._zeros(2 * B, E, dtype=torch.float32)
+            sp = max(1, min(Jp // 64, 64))
+            ops.gemm_nt(dS_text, bank["text"][1], dfeat, epi=ops.EPI_F32_ATOMIC, splits=sp, div=temp)
+            ops.gemm_nt(dS_prop, bank["prop"][1], dfeat, epi=ops.EPI_F32_ATOMIC, splits=sp, div=temp)
+
+        # ---- hard negatives (:154-178): prop negatives from sim_t2i rows, text negatives from sim_i2t rows
+        neg = self._zeros(2 * B, dtype=torch.int64)
+        fp, ft = (None, None) if neg_idx is None else (neg_idx[0].to(torch.int64).contiguous(), neg_idx[1].to(torch.int64).contiguous())
+        ops.sample_neg(S_prop[B:2 * B], B, neg[:B], forced=fp, seed=self.seed, salt=self._next_salt())
+        ops.sample_neg(S_text[:B], B, neg[B:], forced=ft, seed=self.seed, salt=self._next_salt())
+
+        # ---- S6: the fusion layers over all seven student fusion passes at once (:137-198, :224-231, :243-250)
+        pe, te = prop_embeds.view(B, Lp * H), text_embeds.view(B, Lt * H)
+        pe_neg = ops.gather_rows(self._new(B, Lp * H), pe, neg[:B])
+        te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
+        mask_neg = mask32.index_select(0, neg[B:])
+        qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
+        qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
+        kv_qpv = torch.cat([te, te, te_neg, te]).view(4 * B * Lt, H)
+        kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
+        kv_qtext = torch.cat([pe, pe_neg, pe, pe]).view(4 * B * Lp, H)
+        X6 = torch.cat([qpv, qtext])
+        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv=kv_qpv, Lkv=Lt, kv_mask=kvmask_qpv),
+              Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B, kv=kv_qtext, Lkv=Lp, kv_mask=None)]
+        y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save)
+        ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
+
+        # ---- ITM head (:199-206)
+        vl_logits = self._new(3 * B, 2, dtype=torch.float32) if aux is not None else None
+        ops.itm_head(ypv, Lp * H, ytext, Lt * H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
+                     slot=LOSS_ITM, logits=vl_logits)
+
+        # ---- queue (:208, :272-286)
+        feat_pm, feat_tm = feats["property_proj_m"][0], feats["text_proj_m"][0]
+        if gather is not None:
+            feat_pm, feat_tm = gather(feat_pm), gather(feat_tm)
+        ptr = P.buffers["queue_ptr"]
+        ops.enqueue(feat_pm, P.buffers["prop_queue"], *bank["prop"], ptr, Bloc=B, advance=False)
+        ops.enqueue(feat_tm, P.buffers["text_queue"], *bank["text"], ptr, Bloc=B, advance=True)
+
+        # ---- LM loss (:211-238)
+        hid10 = ytext[3 * B * Lt:]
+        logits, lmsv = self.lm_head_fwd("text_encoder.", ct, hid10, save)
+        ops.lm_loss(logits, logits_m, ids32, nseq=B, L=Lt, V=ct.vocab_size, alpha=self.alpha, ws=self.icount[0:1], losses=self.losses,
+                    slot=LOSS_MLM)
+
+        # ---- MPM (:241-256)
+        hp12 = ypv[3 * B * Lp:]
+        mt, mpre = self._new(B * Lp, H), self._new(B * Lp, H)
+        ops.gemm_nt(hp12, P.wb("property_mtr_head.0.weight"), mt, bias=P.w("property_mtr_head.0.bias"), epi=ops.EPI_GELU, C2=mpre)
+        mln = self._new(B * Lp, H)
+        mmean, mrstd = self._new(B * Lp, dtype=torch.float32), self._new(B * Lp, dtype=torch.float32)
+        ops.ln_fwd(mt, None, P.w("property_mtr_head.2.weight"), P.w("property_mtr_head.2.bias"), mln, zout=mt, mean=mmean, rstd=mrstd,
+                   eps=ct.layer_norm_eps)
+        pred = self._new(B, cfg.n_props, dtype=torch.float32) if aux is not None else None
+        ops.mpm_head(mln, Lp, H, P.w("property_mtr_head.3.weight"), P.w("property_mtr_head.3.bias"), prop, mpm_mask, B=B,
+                     ws=self.icount[1:2], losses=self.losses, slot=LOSS_MPM, pred=pred)
+
+        if aux is not None:
+            aux.update(prop_embeds=prop_embeds, text_embeds=text_embeds, prop_embeds_m=prop_embeds_m, text_embeds_m=text_embeds_m,
+                       prop_feat=feats["property_proj"][0], text_feat=feats["text_proj"][0], prop_feat_m=feats["property_proj_m"][0],
+                       text_feat_m=feats["text_proj_m"][0], sim_i2t=S_text[:B], sim_t2i=S_prop[B:2 * B], sim_i2t_m=S_text[2 * B:3 * B],
+                       vl_output=vl_logits, mlm_output=logits.view(B, Lt, -1)[:, :-1], logits_m=logits_m.view(B, Lt, -1)[:, :-1],
+                       pred=pred, prop_neg_idx=neg[:B], text_neg_idx=neg[B:], mpm_mask=mpm_mask,
+                       prop_embeds_causal=prop_embeds_causal)
+        if save:
+            self.tape = dict(B=B, Lt=Lt, prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
+                             esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv,
+                             ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln,
+                             mmean=mmean, mrstd=mrstd)
+        return self.losses[:4]
+
+    # ----------------------------------------------------------------------------------------------- backward
+    def backward(self):
+        """Accumulates d(sum_k gscale[k] * loss_k)/d(param) into the flat gradient arena (self.P.grad)."""
+        T = self.tape
+        if T is None:
+            raise RuntimeError("backward() without a taped forward()")
+        cfg, P = self.cfg, self.P
+        ct, cp = cfg.text, cfg.prop
+        H, E, Lp, f, n = ct.hidden_size, cfg.embed_dim, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
+        B, Lt = T["B"], T["Lt"]
+        gs = self.gscale
+        scratch = self.loss_scratch
+        M6 = 4 * B * (Lp + Lt)
+        dY6 = self._zeros(M6, H)
+        dYpv, dYtext = dY6[:4 * B * Lp], dY6[4 * B * Lp:]
+
+        # ---- MPM head
+        dmln = self._new(B * Lp, H)
+        ops.mpm_head(T["mln"], Lp, H, P.w("property_mtr_head.3.weight"), P.w("property_mtr_head.3.bias"), T["prop"], T["mpm_mask"], B=B,
+                     ws=self.icount[1:2], losses=scratch, slot=LOSS_MPM, dh=dmln, dw=P.g("property_mtr_head.3.weight"),
+                     db=P.g("property_mtr_head.3.bias"), gscale=gs[1:2])
+        dmz = self._new(B * Lp, H)
+        ops.ln_bwd(dmln, T["mt"], T["mmean"], T["mrstd"], P.w("property_mtr_head.2.weight"), dmz,
+                   dgamma=P.g("property_mtr_head.2.weight"), dbeta=P.g("property_mtr_head.2.bias"))
+        dmpre = self._gelu_bwd(dmz, T["mpre"])
+        self._wgrad(dmpre, T["hp12"], P.g("property_mtr_head.0.weight"), P.g("property_mtr_head.0.bias"))
+        ops.gemm_nt(dmpre, self._wT("property_mtr_head.0", P.w("property_mtr_head.0.weight")), dYpv[3 * B * Lp:])
+
+        # ---- LM head
+        V = ct.vocab_size
+        dlogits = self._new(B * Lt, _ceil(V, 64))
+        ops.lm_loss(T["logits"], T["logits_m"], T["ids32"], nseq=B, L=Lt, V=V, alpha=self.alpha, ws=self.icount[0:1], losses=scratch,
+                    slot=LOSS_MLM, dlogits=dlogits, gscale=gs[0:1])
+        dYtext[3 * B * Lt:].copy_(self.lm_head_bwd("text_encoder.", ct, T["lmsv"], dlogits))
+
+        # ---- ITM head: writes the CLS rows of the first 3B sequences of both halves
+        ops.itm_head(T["ypv"], Lp * H, T["ytext"], Lt * H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
+                     slot=LOSS_ITM, dxa=dYpv, dxb=dYtext, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
+
+        # ---- S6 backward
+        dkv_text = self._zeros(4 * B * Lt, H, dtype=torch.float32)
+        dkv_prop = self._zeros(4 * B * Lp, H, dtype=torch.float32)
+        dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"], dkv_acc=[dkv_text, dkv_prop])
+        dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:].view(4 * B, Lt * H)
+        neg_p, neg_t = T["neg"][:B], T["neg"][B:]
+        d_pe = self._zeros(B, Lp * H, dtype=torch.float32)
+        d_te = self._zeros(B, Lt * H, dtype=torch.float32)
+        ops.acc_rows(d_pe, dXpv[0:B])
+        ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
+        ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
+        ops.acc_rows(d_te, dXt[0:B])
+        ops.acc_rows(d_te, dXt[B:2 * B])
+        ops.acc_rows(d_te, dXt[2 * B:3 * B], idx=neg_t, atomic=True)
+        kt, kp = dkv_text.view(4 * B, Lt * H), dkv_prop.view(4 * B, Lp * H)
+        d_te.add_(kt[0:B]).add_(kt[B:2 * B]).add_(kt[3 * B:])
+        d_te.index_add_(0, neg_t, kt[2 * B:3 * B])
+        d_pe.add_(kp[0:B]).add_(kp[2 * B:3 * B]).add_(kp[3 * B:])
+        d_pe.index_add_(0, neg_p, kp[B:2 * B])
+
+        # ---- ITA: stored d loss / d features -> projections -> CLS rows
+        for k, (proj, d_hub, L) in enumerate((("property_proj", d_pe, Lp), ("text_proj", d_te, Lt))):
+            feat, nrm, cls = T["feats"][proj]
+            dproj = self._new(B, E)
+            ops.l2norm_bwd(T["dfeat"][k * B:(k + 1) * B], feat, nrm, dproj, gscale=gs[2:3])
+            self._wgrad(dproj, cls, P.g(proj + ".weight"), P.g(proj + ".bias"))
+            dcls = self._new(B, H)
+            ops.gemm_nt(dproj, self._wT(proj, P.w(proj + ".weight")), dcls)
+            ops.acc_rows(d_hub[:, :H], dcls)
+        ops.axpy_scalar(P.g("temp").view(1), self.dtemp_ita, scale_ptr=gs[2:3])
+
+        # ---- S2 backward (text layers 0..f-1 on P2 | P10a) and the text embeddings
+        dY2 = self._new(2 * B * Lt, H)
+        ops.cast_f32_bf16(d_te.view(-1), dY2[:B * Lt].view(-1))
+        dY2[B * Lt:].copy_(dXt[3 * B:].reshape(B * Lt, H))
+        dX2 = self.stack_bwd("text_encoder.bert.", ct, range(0, f), T["tape2"], dY2, T["g2"])
+        dz2 = self._embed_ln_bwd("text_encoder.bert.", ct, T["esv2"], dX2)
+        tp = "text_encoder.bert.embeddings."
+        ops.embed_bwd(0, dz2, nseq=2 * B, L=Lt, H=H, dpos=P.g(tp + "position_embeddings.weight"),
+                      dtype0=P.g(tp + "token_type_embeddings.weight"), ids=T["ids2"], dword=P.g(tp + "word_embeddings.weight"))
+
+        # ---- S1 backward (PV encoder on P1 | P11) and the PV embedding
+        dY1 = self._new(2 * B * Lp, H)
+        ops.cast_f32_bf16(d_pe.view(-1), dY1[:B * Lp].view(-1))
+        dY1[B * Lp:].copy_(dXpv[3 * B:].reshape(B * Lp, H))
+        dX1 = self.stack_bwd("property_encoder.", cp, range(cp.num_hidden_layers), T["tape1"], dY1, T["g1"])
+        dz1 = self._embed_ln_bwd("property_encoder.", cp, T["esv1"], dX1)
+        pp = "property_encoder.embeddings."
+        ops.embed_bwd(1, dz1, nseq=2 * B, L=Lp, H=H, dpos=P.g(pp + "position_embeddings.weight"),
+                      dtype0=P.g(pp + "token_type_embeddings.weight"), pv_x=T["prop"], pv_mask=T["mpm_mask"], src_mod=B,
+                      d_w=P.g("property_embed.weight"), d_b=P.g("property_embed.bias"), d_cls=P.g("property_cls"),
+                      d_masktok=P.g("property_mask"))
+        self.tape = None

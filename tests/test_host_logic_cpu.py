@@ -1,0 +1,114 @@
+"""Host-side logic on CPU: the engine's launch schedule is run in DRY-RUN mode (every C-ABI call is checked against the
+prototype parsed from include/spmm_hip.h; nothing is launched), plus parameter-arena / state_dict / schedule checks."""
+import math
+
+import pytest
+import torch
+
+import spmm_oracle as O
+
+
+@pytest.fixture()
+def dry():
+    from spmm_amd import ops
+    ops._DRY_RUN = True
+    ops._dry_log.clear()
+    yield ops
+    ops._DRY_RUN = False
+
+
+def _tiny_model(train_cfg=None):
+    from spmm_amd.config import tiny_config
+    from spmm_amd.model import SPMM
+    return SPMM(config=train_cfg, spmm_config=tiny_config(), loader_len=4)
+
+
+def test_state_dict_keys_shapes_and_order_match_reference_layout(dry):
+    m = _tiny_model()
+    sd = m.state_dict()
+    spec = O.state_spec(O.tiny_cfg())
+    assert list(sd.keys()) == [n for n, _, _ in spec]
+    for n, shape, _ in spec:
+        assert tuple(sd[n].shape) == tuple(shape), n
+    # tied tensors alias their sources (xbert.py:691, :1362-1368)
+    assert sd["text_encoder.cls.predictions.decoder.weight"].data_ptr() == sd["text_encoder.bert.embeddings.word_embeddings.weight"].data_ptr()
+    assert sd["text_encoder_m.cls.predictions.decoder.bias"].data_ptr() == sd["text_encoder_m.cls.predictions.bias"].data_ptr()
+    # trainable set = the reference's (momentum twins frozen, buffers excluded)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert sorted(names) == sorted(O.trainable_names(O.tiny_cfg()))
+
+
+def test_full_size_arena_counts(dry):
+    from spmm_amd.config import SPMMConfig, state_spec
+    from spmm_amd.params import _layout_order
+    cfg = SPMMConfig()
+    spec = state_spec(cfg)
+    assert len(spec) == 758
+    order = _layout_order(spec)
+    shapes = {n: s for n, s, _ in spec}
+    assert sum(math.prod(shapes[n]) if shapes[n] else 1 for n in order) == 144_374_064
+
+
+def test_load_state_dict_roundtrip_and_fused_views(dry):
+    m = _tiny_model()
+    sd = O.closed_form_state_dict(O.tiny_cfg())
+    m.load_state_dict(sd)
+    out = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(out[k].cpu(), v), k
+    P = m.store
+    pfx = "text_encoder.bert.encoder.layer.1.crossattention"
+    kv = P.fused(pfx + ".self.", ("key", "value"), "weight", what="w")
+    assert torch.equal(kv, torch.cat([sd[pfx + ".self.key.weight"], sd[pfx + ".self.value.weight"]]))
+    qkvb = P.fused("property_encoder.encoder.layer.0.attention.self.", ("query", "key", "value"), "bias", what="w")
+    assert torch.equal(qkvb, torch.cat([sd[f"property_encoder.encoder.layer.0.attention.self.{n}.bias"] for n in ("query", "key", "value")]))
+    with pytest.raises(KeyError):
+        m.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_step_schedule_dry_run(dry):
+    """forward + backward + optimiser launch sequence with argument validation against the header."""
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20,
+             'cooldown_epochs': 0}
+    tc = {'embed_dim': 64, 'temp': 0.07, 'queue_size': 16, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
+          'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
+    m = _tiny_model(tc).train()
+    prop, ids, mask = O.synthetic_batch(4, 16, seed=7)
+    losses = m.training_step((prop, (ids, mask)), batch_idx=0)
+    assert losses.shape == (4,)
+    log = list(dry._dry_log)
+    for needed in ("spmm_gemm_nt", "spmm_attn_fwd", "spmm_attn_bwd", "spmm_ln_fwd", "spmm_ln_bwd", "spmm_embed_ln_fwd", "spmm_embed_bwd",
+                   "spmm_ita_rows", "spmm_sample_neg", "spmm_lm_loss", "spmm_itm_head", "spmm_mpm_head", "spmm_enqueue",
+                   "spmm_ema_update", "spmm_grad_sqnorm", "spmm_adamw_step", "spmm_clamp_scalar", "spmm_l2norm_fwd", "spmm_l2norm_bwd"):
+        assert needed in log, needed
+    # 2 text layers (1 fusion) + 1 PV layer: self-attention launches in forward = S1(1) + S2(1) + S3(1) + S4(1) + S5(1) + S6(2 groups)
+    assert log.count("spmm_attn_bwd") == 1 + 1 + 2 + 2          # S1, S2 self; S6: 2 groups x (self + cross)
+    # autograd-boundary path
+    dry._dry_log.clear()
+    out = m(prop, ids, mask, alpha=0.1)
+    sum(out).backward()
+    assert "spmm_attn_bwd" in dry._dry_log
+    m.eval()
+    with torch.no_grad():
+        out = m(prop, ids, mask, alpha=0.1)
+    assert len(out) == 4
+
+
+def test_cosine_schedule_matches_oracle_table():
+    from spmm_amd.model import _CosineSchedule
+    for sc in ({'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'warmup_lr': 5e-5, 'warmup_epochs': 20},
+               {'lr': 1e-3, 'epochs': 4, 'min_lr': 1e-5, 'warmup_lr': 1e-4, 'warmup_epochs': 2}):
+        s = _CosineSchedule(sc)
+        for t in range(60):
+            assert abs(s.lr_at(t) - O.cosine_lr(t, sc)) < 1e-15
+
+
+def test_bert_config_accepts_string_true(tmp_path):
+    import json
+    from spmm_amd.config import BertConfig
+    p = tmp_path / "c.json"
+    json.dump({"hidden_size": 768, "num_attention_heads": 12, "add_cross_attention": "True", "fusion_layer": 6}, open(p, "w"))
+    assert BertConfig.from_json_file(str(p)).add_cross_attention is True
+    json.dump({"hidden_size": 100, "num_attention_heads": 3}, open(p, "w"))
+    with pytest.raises(ValueError):
+        BertConfig.from_json_file(str(p))

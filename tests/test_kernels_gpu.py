@@ -400,7 +400,7 @@ def test_l2norm_and_split(ops):
 
 
 def test_ita_rows(ops):
-    B, Q = 8, 120
+    B, Q = 8, 100
     J = B + Q
     Jpad = 128
     temp = torch.tensor([0.07], device="cuda")
