@@ -1,0 +1,221 @@
+"""Headline benchmark: SPMM pretraining step throughput (molecules/s) on N MI355X, one process per GPU over RCCL.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = zero_grad + SPMM.forward (12 encoder passes, 4 losses) + backward + [gradient all-reduce + feature all-gather]
++ clip + AdamW + EMA on one synthetic batch of the pretrain shape (BASELINE.json configs[1]: full 12+6-layer / H=768 model,
+per-GPU batch 128, seq_len 128, queue 36864, train mode with dropout, bf16 compute with fp32 accumulation).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(B, Lt, seed, device):
+    """SURVEY.md section 8d recipe (same as oracle.synthetic_batch; restated so the product never imports oracle/)."""
+    g = torch.Generator().manual_seed(seed)
+    prop = torch.randn(B, 53, generator=g)
+    ids = torch.zeros(B, Lt, dtype=torch.long)
+    lens = torch.randint(max(Lt // 2, 3), Lt + 1, (B,), generator=g)
+    lens[0] = Lt
+    for b in range(B):
+        n = int(lens[b])
+        ids[b, 0] = 2
+        ids[b, 1:n - 1] = torch.randint(4, 300, (n - 2,), generator=g)
+        ids[b, n - 1] = 3
+    return prop.to(device), ids.to(device), (ids != 0).long().to(device)
+
+
+def step_flops(B, Lt, Lp=54, H=768, I=3072, V=300, E=256, Q=36864, n_text=12, fusion=6, n_pv=6):
+    """Algorithmic FLOPs of one training step, SURVEY.md section 8d formulas (multiply-add = 2):
+    3 x forward of the gradient-carrying passes + 1 x forward of the no-grad (momentum) passes."""
+    def self_layer(tokens, L):
+        return tokens * (8 * H * H + 4 * L * H + 4 * H * I)
+
+    def fusion_layer(tq, Lq, tkv, Lkv):
+        return tq * (12 * H * H + 4 * Lq * H + 4 * Lkv * H + 4 * H * I) + tkv * 4 * H * H
+
+    nf = n_text - fusion
+    tp, tt = B * Lp, B * Lt
+    grad = (2 * n_pv * self_layer(tp, Lp)            # P1, P11
+            + 2 * fusion * self_layer(tt, Lt)        # P2, P10a
+            + nf * (fusion_layer(tp, Lp, tt, Lt) * 2 + fusion_layer(2 * tp, Lp, 2 * tt, Lt))      # P5, P12, P7
+            + nf * (fusion_layer(tt, Lt, tp, Lp) * 2 + fusion_layer(2 * tt, Lt, 2 * tp, Lp))      # P6, P10b, P8
+            + tt * (2 * H * H + 2 * H * V) + 4 * 2 * B * E * (B + Q))
+    nograd = (n_pv * self_layer(tp, Lp) + 2 * fusion * self_layer(tt, Lt) + nf * fusion_layer(tt, Lt, tp, Lp)
+              + tt * (2 * H * H + 2 * H * V) + 4 * 2 * B * E * (B + Q))
+    return 3 * grad + nograd
+
+
+def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):
+    """Fused cross-attention unit (Q/K/V projections + core + out-proj), BASELINE.md section 3."""
+    return nseq * (4 * H * H * Lq + 4 * H * H * Lkv + 4 * Lq * Lkv * H)
+
+
+def cpu_baseline(B, Lt, seconds_budget=45.0):
+    """The oracle (a plain-PyTorch fp32 port of the reference's step) timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import spmm_oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    cfg = O.full_cfg()
+    sd = O.init_state_dict(cfg, seed=0)
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20,
+             'cooldown_epochs': 0}
+    tr = O.OracleTrainer(sd, cfg, sched, {'lr': 5e-5, 'weight_decay': 0.02}, loader_len=1000)
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=42)
+    t0 = time.time()
+    tr.step(prop, ids, mask, 0, 100, train=True)              # warm-up
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + warm < seconds_budget and n < 3):
+        tr.step(prop, ids, mask, 0, 101 + n, train=True)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/spmm_oracle.py OracleTrainer, full 12+6-layer H=768 model fp32, B={B}, Lt={Lt}, {n} timed step(s) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--layers", type=str, default="12,6,6", help="text layers, fusion layer, PV layers")
+    ap.add_argument("--queue", type=int, default=36864)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (NOT the benchmark configuration)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+
+    from spmm_amd import ops
+    from spmm_amd.config import BertConfig, SPMMConfig
+    from spmm_amd.model import SPMM
+    from spmm_amd.parallel import grad_sync_fn, broadcast_state_
+
+    nt, f, npv = (int(x) for x in args.layers.split(","))
+    cfg = SPMMConfig(text=BertConfig(num_hidden_layers=nt, fusion_layer=f, add_cross_attention=True),
+                     prop=BertConfig(num_hidden_layers=npv, fusion_layer=f, vocab_size=1), embed_dim=256, queue_size=args.queue)
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20,
+             'cooldown_epochs': 0}
+    tc = {'embed_dim': 256, 'temp': 0.07, 'mlm_probability': 0.15, 'queue_size': args.queue, 'momentum': 0.995, 'alpha': 0.4,
+          'schedular': sched, 'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
+    torch.manual_seed(42)                                   # SPMM_pretrain.py:48 default seed; same init on every rank
+    model = SPMM(config=tc, spmm_config=cfg, loader_len=1000)
+    broadcast_state_([model.store.flat, model.store.flat_m] + [model.store.buffers[k] for k in ("prop_queue", "text_queue")])
+    model.store.refresh_shadows()
+    model.engine.invalidate_banks()
+    model.train(not args.eval_mode)
+    B, Lt = args.batch, args.seq_len
+    batches = [synthetic_batch(B, Lt, 42 + 1000 * rank + i, dev) for i in range(4)]
+    sync = grad_sync_fn()
+
+    def one_step(i):
+        prop, ids, mask = batches[i % len(batches)]
+        return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync)
+
+    for i in range(args.warmup):
+        losses = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    final_losses = [float(x) for x in losses.cpu()]
+
+    # ---- per-kernel timing with HIP events on the launch stream: same step, every GEMM / cross-attention launch bracketed.
+    roof, xattn = None, None
+    if not args.no_kernel_timing and rank == 0:
+        ev = {"gemm": [], "xattn": []}
+        orig_gemm, orig_attn = ops.gemm_nt, ops.attn_fwd
+        stream = torch.cuda.current_stream()
+
+        def timed(kind, fn, flops):
+            def w(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                r = fn(*a, **k)
+                e1.record(stream)
+                ev[kind].append((e0, e1, flops(*a, **k)))
+                return r
+            return w
+
+        def gemm_flops(A, W, C, **k):
+            return 2.0 * A.shape[0] * W.shape[0] * (k.get("K") or A.shape[1])
+
+        ops.gemm_nt = timed("gemm", orig_gemm, gemm_flops)
+        import spmm_amd.engine as E
+        import spmm_amd.step as S
+        nsteps = min(3, args.steps)
+        for i in range(nsteps):
+            one_step(i)
+        torch.cuda.synchronize()
+        ops.gemm_nt = orig_gemm
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in ev["gemm"])
+        tot_fl = sum(fl for _, _, fl in ev["gemm"])
+        n_launch = len(ev["gemm"])
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16, all launches of the step)", "achieved": round(ach, 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n_launch // nsteps, "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
+                "flops_per_step": tot_fl / nsteps, "gemm_ms_per_step": round(tot_ms / nsteps, 3),
+                "measured": f"HIP events around every launch, {nsteps} instrumented steps after the timed region"}
+
+    flops = step_flops(B, Lt, n_text=nt, fusion=f, n_pv=npv, Q=args.queue)
+    value = world * B / (dt / args.steps)
+    out = {"metric": "pretrain molecules/sec", "value": round(value, 2), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
+                                  f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
+                      "parallelism": f"dp{world}"},
+           "step_tflop": round(flops / 1e12, 2), "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
+           "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses}
+    if rank == 0:
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(16, Lt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

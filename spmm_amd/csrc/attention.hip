@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------ backward
 constexpr int BWD_LDS = 4 * 16384 + 3 * 64 * TSTR + 3 * 128 * 4;
 
+template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -209,7 +210,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
   const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
   const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
-  const bf16* Og = p.O + (long)seq * p.Lq * p.ldo + h * HD;
   const bf16* dOg = p.dO + (long)seq * p.Lq * p.lddo + h * HD;
   stage_head<true, true>(Kg, p.ldk, p.Lkv, Ks, KT, tid, 256);
   stage_head<true, false>(Vg, p.ldv, p.Lkv, Vs, nullptr, tid, 256);
@@ -218,19 +218,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   if (tid < 128) {
     const int j = tid;
     mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
-    float l = 0.f, dsum = 0.f;
-    if (j < p.Lq) {
-      l = p.LSE[((long)seq * p.nH + h) * p.Lq + j];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bf16x8 a = *(const bf16x8*)(dOg + (long)j * p.lddo + c * 8);
-        const bf16x8 b = *(const bf16x8*)(Og + (long)j * p.ldo + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
-      }
-    }
-    lse[j] = l;
-    Dq[j] = dsum;
+    lse[j] = j < p.Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] : 0.f;
+    Dq[j] = 0.f;
   }
   __syncthreads();
 
@@ -238,9 +227,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   const bool drop = p.drop_thresh16 != 0;
   const uint64_t seed = drop ? (*p.seed_ptr ^ p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
-  const int NTkv = (p.Lkv + 31) >> 5, NTq = (p.Lq + 31) >> 5;
+  const int NTq = (p.Lq + 31) >> 5;
 
-  // ---- phase A: wave owns query tile `wave` -> dQ
+  // ---- phase A: wave owns query tile `wave` -> D[q] = sum_kv P dP (fp32, exactly consistent with ds) and dQ.
+  // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
+  // ds = P (dP - D) is a small difference of large numbers that such a D would swamp.
   if (wave < NTq) {
     const int q = wave * 32 + (lane & 31);
     bf16x8 qf[4], dof[4];
@@ -249,32 +240,44 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
       qf[kk] = ld_rm(Qs, q, kk * 2 + g);
       dof[kk] = ld_rm(dOs, q, kk * 2 + g);
     }
-    const float lq = lse[q], dq_row = Dq[q];
-    f32x16 dq[2] = {zero16(), zero16()};
-    for (int t = 0; t < NTkv; ++t) {
-      f32x16 st = zero16(), dp = zero16();
+    const float lq = lse[q];
+    f32x16 st[NT], dp[NT];
+    float dloc = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      st[t] = zero16();
+      dp[t] = zero16();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        st = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st);
-        dp = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp);
+        st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
+        dp[t] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[t]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float mv = mb[kv];
-        float ds = 0.f;
+        float pr = 0.f, dpr = 0.f;
         if (mv >= 0.f && q < p.Lq) {
-          const float s = st[r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
-          const float pr = __expf(s - lq);
-          float dpr = dp[r];
+          const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+          pr = __expf(s - lq);
+          dpr = dp[t][r];
           if (drop) dpr = drop_keep(seed, (headbase + q) * (uint64_t)p.Lkv + kv, p.drop_thresh16) ? dpr * p.drop_scale : 0.f;
-          ds = pr * (dpr - dq_row);
         }
-        st[r] = ds;
+        st[t][r] = pr;
+        dp[t][r] = dpr;
+        dloc += pr * dpr;
       }
+    }
+    dloc += __shfl_xor(dloc, 32, 64);
+    if (g == 0) Dq[q] = dloc;
+    f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dp[t][r] - dloc);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 dsf = pack8(st, hf);
+        const bf16x8 dsf = pack8(st[t], hf);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq[dt] = MFMA32(ld_tr(KT, dt * 32 + (lane & 31), t * 32 + hf * 16 + 4 * g), dsf, dq[dt]);
       }
@@ -290,9 +293,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
                         dq[dt][gq * 4 + 3] * 0.125f);
     }
   }
+  __syncthreads();   // D[q] of every query tile is in LDS
 
   // ---- phase B: wave owns kv tile `wave` -> dK, dV   (S[q][kv]: lane = kv column, registers = q rows)
-  if (wave < NTkv) {
+  if (wave < NT) {
     const int kv = wave * 32 + (lane & 31);
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -403,10 +407,14 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_bwd: dropout needs a device seed");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_attn_bwd: cannot raise dynamic LDS to %d: %s", BWD_LDS, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
+    const void* fns[4] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
+                          (const void*)attn_bwd_kernel<4>};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+      if (e != hipSuccess) {
+        spmm_set_error("spmm_attn_bwd: cannot raise dynamic LDS to %d: %s", BWD_LDS, hipGetErrorString(e));
+        return SPMM_ERR_LAUNCH;
+      }
     }
     attr_set = true;
   }
@@ -420,7 +428,12 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p);
+  switch ((Lkv + 31) / 32) {
+    case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
+    case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
+    case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
+    default: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
+  }
   SPMM_LAUNCH_CHECK("spmm_attn_bwd");
   return SPMM_OK;
 }
