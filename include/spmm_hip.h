@@ -49,6 +49,14 @@ const char* spmm_last_error(void);
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
                  void* C2, long ldc2, int epi, spmm_stream_t stream);
+/* Weight-gradient GEMM C[N,K] += alpha * A[M,N]^T . B[M,K] straight from the token-major activations (LDS transpose reads,
+ * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
+ * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
+long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
+int spmm_gemm_tn_splits(int M, int N, int K);
+int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
+                 long ldc, float* workspace, spmm_stream_t stream);
+int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 /* 1 = stage tiles with LDS-DMA (global_load_lds_dwordx4, default), 0 = through registers */
 void spmm_gemm_set_staging(int use_lds_dma);
 

@@ -1,0 +1,264 @@
+// bf16 "TN" GEMM for gfx950 -- the weight-gradient GEMM:  C[N,K] += A[M,N]^T * B[M,K]  (reduction over the ROW index m
+// of both operands, A = dY and B = X token-major exactly as the forward pass left them: no transposed copies).
+//
+// Replaces autograd's weight-gradient matmul for every nn.Linear on the path (the backward of xbert.py:280-300,
+// :370, :435, :448, :673, :695 and SPMM_models.py:31-42).
+//
+// v_mfma_f32_32x32x16_bf16 wants, per lane, 8 consecutive REDUCTION elements of one row of its operand; here the
+// reduction index is the memory row, so fragments are fetched with the gfx950 LDS transpose read
+// ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of 4 contiguous bf16 (row i>>2,
+// columns 4*(i&3)..+3 of a [4 x 16] block) and receives column i of that block (4 reduction rows).  Two such reads
+// give the 8 k-slot values of a lane; MFMA sums its k-slots in any order and A and B use the same order.
+// Tiles: 64 (reduction rows) x 128 (columns) per operand, 256-B LDS rows; the 16-B chunk index is XOR-swizzled with
+// (row&3)<<2 so the four rows a read group touches sit in different 32-B bank spans (conflict-free for the 2x32-lane
+// service groups of ds_read_b64_tr_b16).  Full tiles are staged by LDS-DMA (global_load_lds_dwordx4) with the
+// swizzle applied on the source address; the ragged last tile goes through registers with zero fill.
+// Output tile 128x128 per 256-thread workgroup (4 waves as 2x2), MFMA issued as D[k][n] so a lane owns 4 consecutive
+// k -> 16-byte fp32 stores.  Split over M: every split writes its partial tile to a slab with plain stores (fp32
+// atomics measured 20x slower than the same bytes as plain stores), a second pass reduces the slabs into C.
+#include "common.h"
+#include "../../include/spmm_hip.h"
+
+namespace {
+
+constexpr int BR = 64;                      // reduction rows per stage
+constexpr int BT = 128;                     // output tile edge
+constexpr int TILE_BYTES = BR * BT * 2;     // 16 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+struct TnP {
+  const bf16* A; long lda;    // [M, N]
+  const bf16* B; long ldb;    // [M, K]
+  int M, N, K;
+  int rsplit;                 // reduction rows per grid.z slice (multiple of 64)
+  float* C; long ldc;         // direct mode: C[n*ldc + k] += ...
+  float* slab;                // slab mode: slab[z][n][k] (dense N*K)
+  float alpha;
+};
+
+// physical byte offset of logical 16-B chunk `c16` (8 columns) of row `row`
+__device__ __forceinline__ int tn_off(int row, int c16) { return row * 256 + ((c16 ^ ((row & 3) << 2)) << 4); }
+
+__device__ __forceinline__ void tn_stage_dma(const bf16* __restrict__ src, long ld, int m0, int col0, int ncols, char* tile, int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = c * 256 + tid;
+    const int row = id >> 4, pc = id & 15;
+    const int lc = pc ^ ((row & 3) << 2);
+    int col = col0 + lc * 8;
+    col = col + 8 <= ncols ? col : (ncols - 8 > 0 ? (ncols - 8) & ~7 : 0);      // clamp: columns >= ncols are never stored
+    const bf16* g = src + (long)(m0 + row) * ld + col;
+    const int wave_base = __builtin_amdgcn_readfirstlane((c * 256 + (tid & ~63)) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void tn_stage_regs(const bf16* __restrict__ src, long ld, int m0, int M, int col0, int ncols, char* tile, int tid) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = c * 256 + tid;
+    const int row = id >> 4, pc = id & 15;
+    const int lc = pc ^ ((row & 3) << 2);
+    int col = col0 + lc * 8;
+    col = col + 8 <= ncols ? col : (ncols - 8 > 0 ? (ncols - 8) & ~7 : 0);
+    bf16x8 v;
+    if (m0 + row < M) {
+      v = *(const bf16x8*)(src + (long)(m0 + row) * ld + col);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    }
+    *(bf16x8*)(tile + id * 16) = v;
+  }
+}
+
+// LDS byte address this lane SUPPLIES for the transpose read of rows mb..mb+3 (h=0) / mb+4..mb+7 (h=1), columns colb..colb+15
+__device__ __forceinline__ unsigned tn_addr(const char* tile, int mb, int colb, int i16, int h) {
+  const int col = colb + (i16 & 3) * 4;
+  const int r = mb + 4 * h + (i16 >> 2);
+  return (unsigned)(size_t)(tile + tn_off(r, col >> 3) + (col & 7) * 2);
+}
+__device__ __forceinline__ bf16x8 tn_join(bf16x4 lo, bf16x4 hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+// All fragments of one 16-row k-step for this wave: two 32-column blocks of A (n) and two of B (k): 8 transpose reads,
+// one wait.  Lane i of a 16-lane group receives column i, 4 reduction rows per read.
+__device__ __forceinline__ void tn_frags(const char* As, const char* Bs, int mb, int ncol, int kcol, int i16, bf16x8 (&af)[2],
+                                         bf16x8 (&bfr)[2]) {
+  const unsigned a00 = tn_addr(As, mb, ncol, i16, 0), a01 = tn_addr(As, mb, ncol, i16, 1);
+  const unsigned a10 = tn_addr(As, mb, ncol + 32, i16, 0), a11 = tn_addr(As, mb, ncol + 32, i16, 1);
+  const unsigned b00 = tn_addr(Bs, mb, kcol, i16, 0), b01 = tn_addr(Bs, mb, kcol, i16, 1);
+  const unsigned b10 = tn_addr(Bs, mb, kcol + 32, i16, 0), b11 = tn_addr(Bs, mb, kcol + 32, i16, 1);
+  bf16x4 r0, r1, r2, r3, r4, r5, r6, r7;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11)
+      : "memory");
+  af[0] = tn_join(r0, r1); af[1] = tn_join(r2, r3); bfr[0] = tn_join(r4, r5); bfr[1] = tn_join(r6, r7);
+}
+
+template <bool SLAB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int i16 = lane & 15, j = lane >> 4;
+  const int ntn = (p.N + BT - 1) / BT, ntk = (p.K + BT - 1) / BT, nt = ntn * ntk;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int n0 = (t / ntk) * BT, k0 = (t % ntk) * BT;
+  const int mbeg = blockIdx.z * p.rsplit;
+  const int mend = min(p.M, mbeg + p.rsplit);
+  const int nsteps = (mend - mbeg + BR - 1) / BR;
+
+  f32x16 acc[2][2];   // [ki][ni]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto stage = [&](int s, char* buf) {
+    const int m0 = mbeg + s * BR;
+    if (m0 + BR <= p.M) {
+      tn_stage_dma(p.A, p.lda, m0, n0, p.N, buf, tid);
+      tn_stage_dma(p.B, p.ldb, m0, k0, p.K, buf + TILE_BYTES, tid);
+    } else {
+      tn_stage_regs(p.A, p.lda, m0, p.M, n0, p.N, buf, tid);
+      tn_stage_regs(p.B, p.ldb, m0, p.M, k0, p.K, buf + TILE_BYTES, tid);
+    }
+  };
+  if (nsteps > 0) stage(0, smem);
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();
+    char* cur = smem + (s & 1) * STAGE_BYTES;
+    if (s + 1 < nsteps) stage(s + 1, smem + ((s + 1) & 1) * STAGE_BYTES);
+    const char* As = cur;
+    const char* Bs = cur + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int mb = kk * 16 + (j >> 1) * 8;
+      bf16x8 af[2], bfr[2];
+      tn_frags(As, Bs, mb, wn * 64 + (j & 1) * 16, wk * 64 + (j & 1) * 16, i16, af, bfr);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[ki][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ki], af[ni], acc[ki][ni], 0, 0, 0);
+    }
+  }
+  // acc[ki][ni][r] = D[k][n]: n = lane&31 (column), k = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = SLAB ? p.slab + (long)blockIdx.z * p.N * p.K : p.C;
+  const long ldo = SLAB ? p.K : p.ldc;
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = k0 + wk * 64 + ki * 32 + 8 * g + 4 * (lane >> 5);
+        if (k >= p.K) continue;
+        f32x4* dst = (f32x4*)(out + (long)n * ldo + k);
+        f32x4 v = {acc[ki][ni][g * 4] * p.alpha, acc[ki][ni][g * 4 + 1] * p.alpha, acc[ki][ni][g * 4 + 2] * p.alpha,
+                   acc[ki][ni][g * 4 + 3] * p.alpha};
+        if constexpr (!SLAB) {
+          const f32x4 o = *dst;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        *dst = v;
+      }
+    }
+}
+
+// C[n*ldc + k] += sum_z slab[z][n][k]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int N, int K4, float* __restrict__ C,
+                                                          long ldc) {
+  const long total = (long)N * K4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / K4), k = (int)(i - (long)n * K4) * 4;
+    f32x4 s = *(const f32x4*)(slab + i * 4);
+    for (int z = 1; z < splits; ++z) {
+      const f32x4 v = *(const f32x4*)(slab + (long)z * total * 4 + i * 4);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    f32x4* d = (f32x4*)(C + (long)n * ldc + k);
+    f32x4 o = *d;
+    o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
+    *d = o;
+  }
+}
+
+// out[c] += sum_r x[r][c]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, int rows_per_block, float* __restrict__ out) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const bf16x4 v = *(const bf16x4*)(x + (long)r * ld + c);
+    s0 += (float)v[0]; s1 += (float)v[1]; s2 += (float)v[2]; s3 += (float)v[3];
+  }
+  atomicAdd(out + c, s0); atomicAdd(out + c + 1, s1); atomicAdd(out + c + 2, s2); atomicAdd(out + c + 3, s3);
+}
+
+}  // namespace
+
+extern "C" long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits) {
+  (void)M;
+  return splits > 1 ? (long)splits * N * K * 4 : 0;
+}
+
+extern "C" int spmm_gemm_tn_splits(int M, int N, int K) {
+  const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
+  int s = (640 + tiles - 1) / tiles;
+  const int maxs = (M / BR) / 8 > 0 ? (M / BR) / 8 : 1;     // at least 8 reduction steps per split
+  if (s > maxs) s = maxs;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha,
+                            float* C, long ldc, float* workspace, spmm_stream_t stream) {
+  SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
+  SPMM_CHECK_SHAPE(N % 4 == 0 && K % 4 == 0 && ldc % 4 == 0, "spmm_gemm_tn: N=%d K=%d ldc=%ld must be multiples of 4", N, K, ldc);
+  SPMM_CHECK_SHAPE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((N + 7) & ~7) && ldb >= ((K + 7) & ~7),
+                   "spmm_gemm_tn: lda=%ld / ldb=%ld must be multiples of 8 covering the 8-column chunks of N=%d / K=%d", lda, ldb, N, K);
+  SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "spmm_gemm_tn: A/B must be 16-B aligned");
+  if (splits < 1) splits = 1;
+  SPMM_CHECK_SHAPE(splits == 1 || workspace != nullptr, "spmm_gemm_tn: split reduction needs a workspace");
+  int rsplit = (((M + BR - 1) / BR + splits - 1) / splits) * BR;
+  splits = (M + rsplit - 1) / rsplit;
+  TnP p;
+  p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.rsplit = rsplit;
+  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha;
+  const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
+  dim3 grid(tiles, 1, splits);
+  if (splits > 1) {
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, stream, p);
+    long blocks = ((long)N * (K / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, splits, N, K / 4, C, ldc);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, stream, p);
+  }
+  SPMM_LAUNCH_CHECK("spmm_gemm_tn");
+  return SPMM_OK;
+}
+
+extern "C" int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream) {
+  SPMM_CHECK_SHAPE(R > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0, "spmm_colsum_bf16: R=%d C=%d ld=%ld", R, C, ld);
+  const int rpb = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 255) / 256, (R + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16*)x, ld, R, C, rpb, out);
+  SPMM_LAUNCH_CHECK("spmm_colsum_bf16");
+  return SPMM_OK;
+}

@@ -90,16 +90,10 @@ class Engine:
         return self.P.wT(key, src_fp32)
 
     def _wgrad(self, dY, X, gW, gb=None):
-        """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY.  (transposes feed the NT GEMM)"""
-        M, N = dY.shape
-        K = X.shape[1]
-        Mp = _ceil(M, 64)
-        dYT, XT = self._new(N, Mp), self._new(K, Mp)
-        ops.transpose_bf16(dY, dYT, colsum=gb)
-        ops.transpose_bf16(X, XT)
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min(Mp // 64, (768 + tiles - 1) // tiles))
-        ops.gemm_nt(dYT, XT, gW, epi=ops.EPI_F32_ATOMIC, splits=splits)
+        """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY (TN GEMM: no transposed copies)."""
+        if gb is not None:
+            ops.colsum_bf16(dY, gb)
+        ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
 
     # ---------------------------------------------------------------------------------------- attention block
     def _attn_block_fwd(self, pfx, c, X, groups, save, cross):

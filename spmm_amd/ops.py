@@ -61,6 +61,24 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
     return C
 
 
+def gemm_tn(A, B, C, *, alpha=1.0, splits=None):
+    """C[N,K] (fp32) += alpha * A[M,N]^T @ B[M,K]  -- weight gradients straight from token-major activations."""
+    M, N = A.shape
+    K = B.shape[1]
+    assert A.dtype == BF16 and B.dtype == BF16 and C.dtype == torch.float32 and B.shape[0] == M and tuple(C.shape) == (N, K)
+    if splits is None:
+        splits = 1 if _DRY_RUN else lib().cdll.spmm_gemm_tn_splits(M, N, K)
+    ws = torch.empty(splits * N * K, dtype=torch.float32, device=C.device) if splits > 1 else None
+    _call("spmm_gemm_tn", _p(A), _row_stride(A), _p(B), _row_stride(B), M, N, K, splits, float(alpha), _p(C), _row_stride(C), _p(ws), _st())
+    return C
+
+
+def colsum_bf16(x, out):
+    R, C = x.shape
+    _call("spmm_colsum_bf16", _p(x), _row_stride(x), R, C, _p(out), _st())
+    return out
+
+
 def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
              seed=None, salt=0):
     """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]."""

@@ -99,6 +99,22 @@ def test_gemm_f32_epilogues_and_splitk(ops):
         close(C, ref + 2.0, 2e-3, 1e-4, f"atomic split {splits}")
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (216, 128, 256, 1), (216, 128, 256, 3), (6912, 768, 768, None),
+                                          (4096, 2304, 768, None), (1000, 300, 128, 2), (130, 64, 192, 1), (8192, 768, 3072, None)])
+def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
+    lda = (N + 7) // 8 * 8 + 16
+    Abig = rnd(M, lda, seed=14)
+    A = Abig[:, :N]                            # strided dY (e.g. dlogits[:, :V] inside a padded buffer)
+    B = rnd(M, K, scale=0.5, seed=15)
+    C = torch.full((N, K), 3.0, device="cuda")
+    ops.gemm_tn(A, B, C, alpha=0.5, splits=splits)
+    ref = 3.0 + 0.5 * (A.float().t() @ B.float())
+    close(C, ref, 2e-3 * math.sqrt(M), 1e-4, "gemm_tn")
+    cs = torch.ones(N, device="cuda")
+    ops.colsum_bf16(A, cs) if N % 4 == 0 else None
+    close(cs, 1.0 + A.float().sum(0), 1e-3 * math.sqrt(M), 1e-5, "colsum")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     A, W = rnd(64, 96), rnd(64, 96)
     with pytest.raises(RuntimeError, match="multiple of 64"):
