@@ -24,14 +24,14 @@ namespace {
 
 constexpr int HD = 64;            // head dim
 constexpr int ROWB = 128;         // bytes per row of a row-major [L][64] bf16 LDS tile
-constexpr int TSTR = 264;         // bytes per row of a transposed [64][128] bf16 LDS tile (+8 B pad: conflict-free)
+constexpr int TILE = 128 * ROWB;  // 16 KiB
 
 struct AttnP {
   const bf16* Q; long ldq;
   const bf16* K; long ldk;
   const bf16* V; long ldv;
   const int* kmask;               // [nseq, Lkv] 1 = attend, or null (all ones)
-  bf16* O; long ldo;              // fwd output / bwd input
+  bf16* O; long ldo;              // fwd output (unused by backward)
   float* LSE;                     // [nseq, nH, Lq]
   const bf16* dO; long lddo;
   bf16* dQ; long lddq;
@@ -46,7 +46,12 @@ struct AttnP {
   uint64_t seed_salt;             // per-call-site salt
 };
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+// Row-major [128][64] bf16 tile, 16-B chunk index XOR-swizzled with rotr3((row>>1)&7):
+//  * ds_read_b128 of 16 rows (distinct mod 16) at one k-slot -> 16 distinct 16-B slots of the 256-B bank window;
+//  * ds_read_b64_tr_b16 of 4 rows x 64 B per 32-lane half -> rows r,r+1 sit in different window halves and rows r,r+2 in
+//    different 64-B spans (bit 2 of the chunk index flips with bit 1 of the row): conflict-free as well.
+__device__ __forceinline__ int frot(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int swz(int row, int c16) { return row * ROWB + ((c16 ^ frot(row)) << 4); }
 
 // reference mask arithmetic: (1 - causal*mask) * -10000 (self) / (1 - mask) * finfo.min (cross)
 __device__ __forceinline__ float score_bias(int mask_kv, bool causal, int q, int kv, float mask_neg) {
@@ -54,36 +59,43 @@ __device__ __forceinline__ float score_bias(int mask_kv, bool causal, int q, int
   return ok ? 0.f : mask_neg;
 }
 
-// Stage rows [0,L) of a [L][64] head slice into a swizzled row-major LDS tile (zero rows up to 128) and,
-// optionally, into a transposed [64][132] image.
-template <bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_head(const bf16* __restrict__ src, long ld, int L, char* rm, char* tr, int tid,
-                                           int nthreads) {
+// LDS-DMA staging of the [L][64] head slice: global_load_lds_dwordx4 writes lane-linear, so the swizzle is applied on
+// the SOURCE chunk.  Rows >= L re-read row L-1 (finite data; such rows are masked / never stored).
+__device__ __forceinline__ void stage_head(const bf16* __restrict__ src, long ld, int L, char* tile, int tid, int nthreads) {
   for (int id = tid; id < 128 * 8; id += nthreads) {
-    const int row = id >> 3, sl = id & 7;
-    bf16x8 v;
-    if (row < L) {
-      v = *(const bf16x8*)(src + (long)row * ld + sl * 8);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-    }
-    if constexpr (ROWMAJOR) *(bf16x8*)(rm + swz(row, sl)) = v;
-    if constexpr (TRANSPOSED) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) *(bf16*)(tr + (sl * 8 + e) * TSTR + row * 2) = v[e];
-    }
+    const int row = id >> 3, pc = id & 7;
+    const int lc = pc ^ frot(row);
+    const int grow = row < L ? row : L - 1;
+    const bf16* g = src + (long)grow * ld + lc * 8;
+    const int wave_base = __builtin_amdgcn_readfirstlane((id & ~63) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
   }
 }
 
 __device__ __forceinline__ bf16x8 ld_rm(const char* tile, int row, int slot) { return *(const bf16x8*)(tile + swz(row, slot)); }
-// transposed tile: 8 values X^T[d][base+{0..3}], X^T[d][base+8+{0..3}]
-__device__ __forceinline__ bf16x8 ld_tr(const char* tile, int d, int base) {
-  const bf16x4 a = *(const bf16x4*)(tile + d * TSTR + base * 2);
-  const bf16x4 b = *(const bf16x4*)(tile + d * TSTR + base * 2 + 16);
+
+__device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
   bf16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
+}
+// A-operand fragments X^T[d][rows] for both 32-wide d blocks, straight from the row-major tile with the LDS transpose read:
+// lane l (d = dt*32 + (l&31), g = l>>5) receives X[rb + 4g + {0..3, 8..11}][d] -- the k-slot order the probabilities use.
+__device__ __forceinline__ void ld_tr2(const char* tile, int rb, int lane, bf16x8 (&out)[2]) {
+  const int i16 = lane & 15, j = lane >> 4;
+  const int row0 = rb + 4 * (j >> 1) + (i16 >> 2);
+  const int col = (j & 1) * 16 + (i16 & 3) * 4;
+  const unsigned a00 = (unsigned)(size_t)(tile + swz(row0, col >> 3) + (col & 7) * 2);
+  const unsigned a01 = (unsigned)(size_t)(tile + swz(row0 + 8, col >> 3) + (col & 7) * 2);
+  const unsigned a10 = (unsigned)(size_t)(tile + swz(row0, (col + 32) >> 3) + (col & 7) * 2);
+  const unsigned a11 = (unsigned)(size_t)(tile + swz(row0 + 8, (col + 32) >> 3) + (col & 7) * 2);
+  bf16x4 r0, r1, r2, r3;
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a00), "v"(a01), "v"(a10), "v"(a11) : "memory");
+  out[0] = join8(r0, r1);
+  out[1] = join8(r2, r3);
+  __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int hf) {
   bf16x8 r;
@@ -100,19 +112,21 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ------------------------------------------------------------------------------------------ forward
+constexpr int FWD_LDS = 2 * TILE + 128 * 4;
+
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                        // 16 KiB  row-major swizzled K
-  char* VT = smem + 16384;                // 64 x 264 B transposed V
-  float* mb = (float*)(smem + 16384 + 64 * TSTR);   // 128 floats: mask value per kv (1/0), -1 = padding
+  char* Ks = smem;
+  char* Vs = smem + TILE;
+  float* mb = (float*)(smem + 2 * TILE);   // mask value per kv (1/0), -1 = padding
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
   const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
   const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
   const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
-  stage_head<true, false>(Kg, p.ldk, p.Lkv, Ks, nullptr, tid, nthreads);
-  stage_head<false, true>(Vg, p.ldv, p.Lkv, nullptr, VT, tid, nthreads);
+  stage_head(Kg, p.ldk, p.Lkv, Ks, tid, nthreads);
+  stage_head(Vg, p.ldv, p.Lkv, Vs, tid, nthreads);
   for (int j = tid; j < 128; j += nthreads)
     mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
@@ -173,8 +187,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const bf16x8 pf = pack8(st[t], hf);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) ot[dt] = MFMA32(ld_tr(VT, dt * 32 + (lane & 31), t * 32 + hf * 16 + 4 * g), pf, ot[dt]);
+      bf16x8 vf[2];
+      ld_tr2(Vs, t * 32 + hf * 16, lane, vf);
+      ot[0] = MFMA32(vf[0], pf, ot[0]);
+      ot[1] = MFMA32(vf[1], pf, ot[1]);
     }
   if (q < p.Lq) {
     bf16* Og = p.O + ((long)seq * p.Lq + q) * p.ldo + h * HD;
@@ -190,19 +206,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward
-constexpr int BWD_LDS = 4 * 16384 + 3 * 64 * TSTR + 3 * 128 * 4;
+constexpr int BWD_LDS = 4 * TILE + 3 * 128 * 4;
 
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + 16384;
-  char* Qs = smem + 2 * 16384;
-  char* dOs = smem + 3 * 16384;
-  char* KT = smem + 4 * 16384;
-  char* QT = KT + 64 * TSTR;
-  char* dOT = QT + 64 * TSTR;
-  float* mb = (float*)(dOT + 64 * TSTR);
+  char* Vs = smem + TILE;
+  char* Qs = smem + 2 * TILE;
+  char* dOs = smem + 3 * TILE;
+  float* mb = (float*)(smem + 4 * TILE);
   float* lse = mb + 128;
   float* Dq = lse + 128;
   const int h = blockIdx.x, seq = blockIdx.y;
@@ -211,10 +224,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
   const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
   const bf16* dOg = p.dO + (long)seq * p.Lq * p.lddo + h * HD;
-  stage_head<true, true>(Kg, p.ldk, p.Lkv, Ks, KT, tid, 256);
-  stage_head<true, false>(Vg, p.ldv, p.Lkv, Vs, nullptr, tid, 256);
-  stage_head<true, true>(Qg, p.ldq, p.Lq, Qs, QT, tid, 256);
-  stage_head<true, true>(dOg, p.lddo, p.Lq, dOs, dOT, tid, 256);
+  stage_head(Kg, p.ldk, p.Lkv, Ks, tid, 256);
+  stage_head(Vg, p.ldv, p.Lkv, Vs, tid, 256);
+  stage_head(Qg, p.ldq, p.Lq, Qs, tid, 256);
+  stage_head(dOg, p.lddo, p.Lq, dOs, tid, 256);
   if (tid < 128) {
     const int j = tid;
     mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
@@ -278,8 +291,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 dsf = pack8(st[t], hf);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = MFMA32(ld_tr(KT, dt * 32 + (lane & 31), t * 32 + hf * 16 + 4 * g), dsf, dq[dt]);
+        bf16x8 kf[2];
+        ld_tr2(Ks, t * 32 + hf * 16, lane, kf);
+        dq[0] = MFMA32(kf[0], dsf, dq[0]);
+        dq[1] = MFMA32(kf[1], dsf, dq[1]);
       }
     }
     if (q < p.Lq) {
@@ -335,11 +350,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 pf = pack8(s, hf), dsf = pack8(dp, hf);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = MFMA32(ld_tr(dOT, dt * 32 + (lane & 31), qt * 32 + hf * 16 + 4 * g), pf, dv[dt]);
-          dk[dt] = MFMA32(ld_tr(QT, dt * 32 + (lane & 31), qt * 32 + hf * 16 + 4 * g), dsf, dk[dt]);
-        }
+        bf16x8 dof[2], qf[2];
+        ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
+        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
+        dv[0] = MFMA32(dof[0], pf, dv[0]);
+        dv[1] = MFMA32(dof[1], pf, dv[1]);
+        dk[0] = MFMA32(qf[0], dsf, dk[0]);
+        dk[1] = MFMA32(qf[1], dsf, dk[1]);
       }
     }
     if (kv < p.Lkv) {
@@ -385,7 +402,7 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
   const int nt = (Lkv + 31) / 32, nw = (Lq + 31) / 32;
-  const size_t lds = 16384 + 64 * TSTR + 128 * 4;
+  const size_t lds = FWD_LDS;
   dim3 grid(nH, nseq), block(64 * nw);
   switch (nt) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, stream, p); break;

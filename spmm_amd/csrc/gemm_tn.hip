@@ -46,7 +46,7 @@ __device__ __forceinline__ void tn_stage_dma(const bf16* __restrict__ src, long 
     const int row = id >> 4, pc = id & 15;
     const int lc = pc ^ ((row & 3) << 2);
     int col = col0 + lc * 8;
-    col = col + 8 <= ncols ? col : (ncols - 8 > 0 ? (ncols - 8) & ~7 : 0);      // clamp: columns >= ncols are never stored
+    col = col < ncols ? col : ((ncols - 1) & ~7);      // chunks wholly past the last column re-read the last valid chunk (never stored)
     const bf16* g = src + (long)(m0 + row) * ld + col;
     const int wave_base = __builtin_amdgcn_readfirstlane((c * 256 + (tid & ~63)) * 16);
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
@@ -59,7 +59,7 @@ __device__ __forceinline__ void tn_stage_regs(const bf16* __restrict__ src, long
     const int row = id >> 4, pc = id & 15;
     const int lc = pc ^ ((row & 3) << 2);
     int col = col0 + lc * 8;
-    col = col + 8 <= ncols ? col : (ncols - 8 > 0 ? (ncols - 8) & ~7 : 0);
+    col = col < ncols ? col : ((ncols - 1) & ~7);
     bf16x8 v;
     if (m0 + row < M) {
       v = *(const bf16x8*)(src + (long)(m0 + row) * ld + col);
@@ -199,17 +199,42 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-// out[c] += sum_r x[r][c]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, int rows_per_block, float* __restrict__ out) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= C) return;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const bf16x4 v = *(const bf16x4*)(x + (long)r * ld + c);
-    s0 += (float)v[0]; s1 += (float)v[1]; s2 += (float)v[2]; s3 += (float)v[3];
+// out[c] += sum_r x[r][c]   (bias gradients).  A workgroup reduces a 256-row x 128-column strip: 16 column groups of
+// 8 bf16 (16-byte loads) x 16 row lanes, 16 rows per thread, LDS tree over the row lanes, one atomicAdd per column.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, float* __restrict__ out) {
+  __shared__ float red[16][129];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 128 + cg * 8;
+  const int r0 = blockIdx.y * 256;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const bool full = c + 8 <= C;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + rl + i * 16;
+      if (r < R) {
+        if (full) {
+          const bf16x8 v = *(const bf16x8*)(x + (long)r * ld + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        } else {
+          for (int e = 0; e < 8 && c + e < C; ++e) s[e] += (float)x[(long)r * ld + c + e];
+        }
+      }
+    }
   }
-  atomicAdd(out + c, s0); atomicAdd(out + c + 1, s1); atomicAdd(out + c + 2, s2); atomicAdd(out + c + 3, s3);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int cc = blockIdx.x * 128 + threadIdx.x;
+    if (cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+      atomicAdd(out + cc, t);
+    }
+  }
 }
 
 }  // namespace
@@ -256,9 +281,8 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
 }
 
 extern "C" int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream) {
-  SPMM_CHECK_SHAPE(R > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0, "spmm_colsum_bf16: R=%d C=%d ld=%ld", R, C, ld);
-  const int rpb = 128;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 255) / 256, (R + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16*)x, ld, R, C, rpb, out);
+  SPMM_CHECK_SHAPE(R > 0 && C > 0 && ld % 8 == 0 && ((uintptr_t)x % 16 == 0), "spmm_colsum_bf16: R=%d C=%d ld=%ld (ld %% 8, 16-B aligned)", R, C, ld);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128, (R + 255) / 256), dim3(256), 0, stream, (const bf16*)x, ld, R, C, out);
   SPMM_LAUNCH_CHECK("spmm_colsum_bf16");
   return SPMM_OK;
 }
