@@ -73,6 +73,79 @@ __device__ __forceinline__ void stage_tile_write(char* lds_tile, int tid, const 
   for (int c = 0; c < 4; ++c) *(bf16x8*)(lds_tile + (c * 256 + tid) * 16) = r[c];
 }
 
+
+// Coalesced bf16 epilogue: the wave's 64x64 output tile goes through LDS (8 KiB per wave per output) so that global
+// stores are 16 B per lane along rows (8 lanes = one 128-B row segment) instead of 8-B fragments scattered over 32 rows.
+// acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5).   Tile rows are 128 B; the 16-B chunk index is
+// XOR-ed with (row & 7) so the row-parallel writes and the row-major reads both spread over the banks.
+template <int EPI>
+__device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane) {
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+  char* t0 = wtile;                 // main output
+  char* t1 = wtile + 8192;          // EPI_GELU: pre-activation
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = mi * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = ni * 32 + 8 * g + 4 * (lane >> 5);       // 4 consecutive n
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][g * 4 + j] * scale;
+        if (p.bias) {
+          const int n = n_base + col;
+          if (n < p.N) {
+            const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += b[j];
+          }
+        }
+        const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
+        if constexpr (EPI == EPI_GELU) {
+          *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+          *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else {
+          *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  // same-wave LDS round trip: the waits the compiler inserts (lgkmcnt) are enough, no barrier needed
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+    const int m = m_base + row, n = n_base + c16 * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const int off = row * 128 + ((c16 ^ (row & 7)) << 4);
+    bf16x8 o = *(const bf16x8*)(t0 + off);
+    const bool full = n + 8 <= p.N;
+    if (p.R) {
+      bf16x8 r = {};
+      if (full) r = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
+      else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); r[0] = h4[0]; r[1] = h4[1]; r[2] = h4[2]; r[3] = h4[3]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)r[e]);
+    }
+    if constexpr (EPI == EPI_GELU_GRAD) {
+      bf16x8 x = {};
+      if (full) x = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
+      else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); x[0] = h4[0]; x[1] = h4[1]; x[2] = h4[2]; x[3] = h4[3]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)x[e]));
+    }
+    if (full) {
+      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+      if constexpr (EPI == EPI_GELU) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off);
+    } else {   // ragged last chunk (N % 8 == 4)
+      bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
+      *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = lo4;
+      if constexpr (EPI == EPI_GELU) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off);
+    }
+  }
+}
+
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -152,6 +225,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     }
   }
 
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELU_GRAD) {
+    __syncthreads();                                  // every wave is done reading the staging buffers
+    epilogue_bf16<EPI>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
   // ---- epilogue: acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float scale = p.alpha;
   if (p.div_ptr) scale /= *p.div_ptr;
@@ -206,6 +284,170 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v2: 256x128x64 tile, 512 threads (8 waves as 4x2, 64x64 per wave), THREE LDS stages (3 x 48 KiB) filled by LDS-DMA.
+// PMC on v1 (93184x3072x768): MFMA pipe 27 % busy, waves parked 55 % of their cycles at the vmcnt(0)+barrier of the
+// 2-stage loop.  Here two tiles are always in flight: the wait before the barrier is a COUNTED s_waitcnt vmcnt(6)
+// (= the 6 DMA instructions of the newest tile may still be pending) and the barrier is the raw s_barrier, so the
+// compiler does not drain the DMA queue (cdna_hip_programming.md: pipelining across barriers).
+constexpr int BM2 = 256;
+constexpr int A2_BYTES = BM2 * BK * 2;              // 32 KiB
+constexpr int STAGE2_BYTES = A2_BYTES + TILE_BYTES; // 48 KiB
+constexpr int LDS2_BYTES = 3 * STAGE2_BYTES;        // 144 KiB
+
+__device__ __forceinline__ void stage2_dma(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0, char* lds_tile, int tid,
+                                           int nchunks_per_thread) {
+  for (int c = 0; c < nchunks_per_thread; ++c) {
+    const int id = c * 512 + tid;
+    const int row = id >> 3, ps = id & 7;
+    const int ls = ps ^ ((row >> 1) & 7);
+    int grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;
+    const bf16* g = src + (long)grow * ld + k0 + ls * 8;
+    const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem2[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntm = (p.M + BM2 - 1) / BM2, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tile_m = t / ntn, tile_n = t % ntn;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN;
+  const int nk = p.K / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define STAGE2(kt_)                                                                           \
+  do {                                                                                        \
+    char* b_ = smem2 + ((kt_) % 3) * STAGE2_BYTES;                                            \
+    stage2_dma(p.A, p.lda, m0, p.M, (kt_) * BK, b_, tid, 4);                                  \
+    stage2_dma(p.W, p.ldw, n0, p.N, (kt_) * BK, b_ + A2_BYTES, tid, 2);                       \
+  } while (0)
+
+  STAGE2(0);
+  if (nk > 1) STAGE2(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) STAGE2(kt + 2);
+    const char* As = smem2 + (kt % 3) * STAGE2_BYTES;
+    const char* Ws = As + A2_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+#undef STAGE2
+
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELU_GRAD) {
+    __builtin_amdgcn_s_barrier();                     // no DMA pending (vmcnt(0) above); all waves done with the ring
+    epilogue_bf16<EPI>(p, acc, smem2 + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][g * 4 + j] * scale;
+        if (p.bias) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += b[j];
+        }
+        if (p.R) {
+          const bf16x4 r = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+        if constexpr (EPI == EPI_BF16) {
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (EPI == EPI_GELU) {
+          *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else if constexpr (EPI == EPI_GELU_GRAD) {
+          const bf16x4 x = *(const bf16x4*)(p.G + (long)m * p.ldg + n);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(v[0] * gelu_erf_grad((float)x[0]), v[1] * gelu_erf_grad((float)x[1]),
+                        v[2] * gelu_erf_grad((float)x[2]), v[3] * gelu_erf_grad((float)x[3]));
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o;
+        } else {  // EPI_F32_ACC
+          f32x4* dst = (f32x4*)((float*)p.C + (long)m * p.ldc + n);
+          f32x4 o = *dst;
+          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+          *dst = o;
+        }
+      }
+    }
+}
+
+template <int EPI>
+int launch_v2_one(const GemmP& p, dim3 grid, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS2_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI>), grid, dim3(512), LDS2_BYTES, st, p);
+  return SPMM_OK;
+}
+int launch_v2(int epi, const GemmP& p, hipStream_t st) {
+  dim3 grid(((p.M + BM2 - 1) / BM2) * ((p.N + BN - 1) / BN));
+  switch (epi) {
+    case EPI_BF16: return launch_v2_one<EPI_BF16>(p, grid, st);
+    case EPI_GELU: return launch_v2_one<EPI_GELU>(p, grid, st);
+    case EPI_F32: return launch_v2_one<EPI_F32>(p, grid, st);
+    case EPI_GELU_GRAD: return launch_v2_one<EPI_GELU_GRAD>(p, grid, st);
+    case EPI_F32_ACC: return launch_v2_one<EPI_F32_ACC>(p, grid, st);
+    default: return -1;
+  }
+}
+
 template <bool GLDS>
 int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
   switch (epi) {
@@ -222,7 +464,7 @@ int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-static int g_gemm_use_glds = 1;
+static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v1 only), 2: force the v1 kernel with LDS-DMA
 extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
 
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
@@ -234,6 +476,8 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   SPMM_CHECK_SHAPE(N % 4 == 0, "spmm_gemm_nt: N=%d must be a multiple of 4", N);
   SPMM_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "spmm_gemm_nt: lda/ldw must be multiples of 8 elements");
   SPMM_CHECK_SHAPE(ldc % 4 == 0, "spmm_gemm_nt: ldc must be a multiple of 4");
+  SPMM_CHECK_SHAPE(epi == EPI_F32 || epi == EPI_F32_ATOMIC || epi == EPI_F32_ACC || (ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!G || ldg % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0),
+                   "spmm_gemm_nt: bf16 outputs need 16-B aligned rows (ldc/ldr/ldg/ldc2 multiples of 8)");
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
@@ -246,6 +490,14 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2;
+  if (g_gemm_use_glds == 1 && splits == 1 && epi != EPI_F32_ATOMIC && M >= 512) {   // v2: 256x128 tile, 3-stage ring
+    int rc2 = launch_v2(epi, p, stream);
+    if (rc2 > 0) return rc2;
+    if (rc2 == 0) {
+      SPMM_LAUNCH_CHECK("spmm_gemm_nt(v2)");
+      return SPMM_OK;
+    }
+  }
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, splits);
   int rc = g_gemm_use_glds ? launch<true>(epi, p, grid, stream) : launch<false>(epi, p, grid, stream);

@@ -43,10 +43,12 @@ def test_gemm_bf16_bias(ops, staging, M, N, K):
     try:
         A, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
         bias = rnd(N, seed=3, dtype=torch.float32)
-        C = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")     # bf16 rows must be 16-B aligned
+        C = Cbuf[:, :N]
         ops.gemm_nt(A, W, C, bias=bias)
         ref = A.float() @ W.float().t() + bias
         close(C, ref, 2e-2, 1e-2, "gemm bf16")
+        assert (Cbuf[:, N:] == 7.0).all()
     finally:
         lib().cdll.spmm_gemm_set_staging(1)
 
