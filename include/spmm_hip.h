@@ -59,6 +59,9 @@ int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N,
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 /* 1 = stage tiles with LDS-DMA (global_load_lds_dwordx4, default), 0 = through registers */
 void spmm_gemm_set_staging(int use_lds_dma);
+/* schedule variant of the 3-stage NT kernel: bit0 s_setprio around MFMA clusters, bit1 DMA issue after the first k-slice,
+ * bit2 explicit fragment double-buffering (tuning knob; the default is chosen from measurements) */
+void spmm_gemm_set_variant(int v);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.
  * Replaces BertSelfAttention.forward xbert.py:305-354 incl. the additive masks of :889-948 (self: 0/-10000, causal

@@ -309,7 +309,7 @@ __device__ __forceinline__ void stage2_dma(const bf16* __restrict__ src, long ld
   }
 }
 
-template <int EPI>
+template <int EPI, int VAR>
 __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -345,25 +345,57 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) STAGE2(kt + 2);
+    constexpr bool PRIO = (VAR & 1) != 0, LATE_DMA = (VAR & 2) != 0, PREFETCH = (VAR & 4) != 0;
+    if (!LATE_DMA && kt + 2 < nk) STAGE2(kt + 2);
     const char* As = smem2 + (kt % 3) * STAGE2_BYTES;
     const char* Ws = As + A2_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    const int ar0 = wm * 64 + (lane & 31), wr0 = wn * 64 + (lane & 31);
+    auto ldfrag = [&](int kk, bf16x8 (&af)[2], bf16x8 (&wf)[2]) {
       const int s = kk * 2 + (lane >> 5);
-      bf16x8 af[2], wf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ar = wm * 64 + i * 32 + (lane & 31);
+        const int ar = ar0 + i * 32, wr = wr0 + i * 32;
         af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-        const int wr = wn * 64 + i * 32 + (lane & 31);
         wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
       }
+    };
+    if constexpr (PREFETCH) {
+      bf16x8 afA[2], wfA[2], afB[2], wfB[2];
+      ldfrag(0, afA, wfA);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int kk = 0; kk < 4; kk += 2) {
+        ldfrag(kk + 1, afB, wfB);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfA[ni], afA[mi], acc[ni][mi], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (LATE_DMA && kk == 0 && kt + 2 < nk) STAGE2(kt + 2);
+        if (kk + 2 < 4) ldfrag(kk + 2, afA, wfA);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfB[ni], afB[mi], acc[ni][mi], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 af[2], wf[2];
+        ldfrag(kk, af, wf);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (LATE_DMA && kk == 0 && kt + 2 < nk) STAGE2(kt + 2);
+      }
     }
   }
 #undef STAGE2
@@ -422,19 +454,135 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v3: 256x256x64 tile, 512 threads (8 waves as 2(m) x 4(n), 128x64 per wave = 4x2 MFMA tiles, 128 fp32 accumulators),
+// two 64-KiB LDS stages.  Rationale: a k-step of the 256x128 tile pulls 48 KiB through the ~64 B/clk/CU L2->LDS path for
+// 1024 MFMA cycles (75 % of the MFMA time at the PEAK L2 rate); 256x256 pulls 64 KiB for 2048 MFMA cycles (37 %), so
+// the DMA stream stops being the bottleneck.  One barrier per k-step; the next tile's 8 DMA instructions per thread are
+// issued right after it and have a full 2048-cycle compute phase to land.
+constexpr int BM3 = 256, BN3 = 256;
+constexpr int T3_BYTES = 256 * BK * 2;              // 32 KiB per operand tile
+constexpr int STAGE3_BYTES = 2 * T3_BYTES;          // 64 KiB
+constexpr int LDS3_BYTES = 2 * STAGE3_BYTES;        // 128 KiB
+
 template <int EPI>
-int launch_v2_one(const GemmP& p, dim3 grid, hipStream_t st) {
+__global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves, wave tile 128 (m) x 64 (n)
+  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int m0 = (t / ntn) * BM3, n0 = (t % ntn) * BN3;
+  const int nk = p.K / BK;
+
+  f32x16 acc[2][2][2];      // [m half][ni][mi]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+#define STAGE3(kt_)                                                                           \
+  do {                                                                                        \
+    char* b_ = smem3 + ((kt_) & 1) * STAGE3_BYTES;                                            \
+    stage2_dma(p.A, p.lda, m0, p.M, (kt_) * BK, b_, tid, 4);                                  \
+    stage2_dma(p.W, p.ldw, n0, p.N, (kt_) * BK, b_ + T3_BYTES, tid, 4);                       \
+  } while (0)
+
+  STAGE3(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
+    if (kt + 1 < nk) STAGE3(kt + 1);
+    const char* As = smem3 + (kt & 1) * STAGE3_BYTES;
+    const char* Ws = As + T3_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 128 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+    }
+  }
+#undef STAGE3
+  __syncthreads();                                     // all waves done with the staging buffers
+  char* wt = smem3 + wave * 16384;                     // 16 KiB private epilogue region per wave
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
+
+template <int EPI>
+int launch_v3_one(const GemmP& p, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI>), grid, dim3(512), LDS3_BYTES, st, p);
+  return SPMM_OK;
+}
+int launch_v3(int epi, const GemmP& p, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_v3_one<EPI_BF16>(p, st);
+    case EPI_GELU: return launch_v3_one<EPI_GELU>(p, st);
+    case EPI_GELU_GRAD: return launch_v3_one<EPI_GELU_GRAD>(p, st);
+    default: return -1;
+  }
+}
+
+static int g_v2_variant = 0;
+template <int EPI, int VAR>
+int launch_v2_var(const GemmP& p, dim3 grid, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) {
       spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS2_BYTES, hipGetErrorString(e));
       return SPMM_ERR_LAUNCH;
     }
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI>), grid, dim3(512), LDS2_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, VAR>), grid, dim3(512), LDS2_BYTES, st, p);
   return SPMM_OK;
+}
+template <int EPI>
+int launch_v2_one(const GemmP& p, dim3 grid, hipStream_t st) {
+  switch (g_v2_variant) {
+    case 1: return launch_v2_var<EPI, 1>(p, grid, st);
+    case 2: return launch_v2_var<EPI, 2>(p, grid, st);
+    case 3: return launch_v2_var<EPI, 3>(p, grid, st);
+    case 4: return launch_v2_var<EPI, 4>(p, grid, st);
+    case 5: return launch_v2_var<EPI, 5>(p, grid, st);
+    case 7: return launch_v2_var<EPI, 7>(p, grid, st);
+    default: return launch_v2_var<EPI, 0>(p, grid, st);
+  }
 }
 int launch_v2(int epi, const GemmP& p, hipStream_t st) {
   dim3 grid(((p.M + BM2 - 1) / BM2) * ((p.N + BN - 1) / BN));
@@ -466,6 +614,7 @@ int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
 
 static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v1 only), 2: force the v1 kernel with LDS-DMA
 extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
+extern "C" void spmm_gemm_set_variant(int v) { g_v2_variant = v; }
 
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
                             const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
@@ -490,6 +639,17 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2;
+  if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
+    const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);
+    if ((tiles3 >= 96 || g_v2_variant == 101) && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {
+      int rc3 = launch_v3(epi, p, stream);
+      if (rc3 > 0) return rc3;
+      if (rc3 == 0) {
+        SPMM_LAUNCH_CHECK("spmm_gemm_nt(v3)");
+        return SPMM_OK;
+      }
+    }
+  }
   if (g_gemm_use_glds == 1 && splits == 1 && epi != EPI_F32_ATOMIC && M >= 512) {   // v2: 256x128 tile, 3-stage ring
     int rc2 = launch_v2(epi, p, stream);
     if (rc2 > 0) return rc2;

@@ -82,23 +82,30 @@ __device__ __forceinline__ bf16x8 tn_join(bf16x4 lo, bf16x4 hi) {
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
-// All fragments of one 16-row k-step for this wave: two 32-column blocks of A (n) and two of B (k): 8 transpose reads,
-// one wait.  Lane i of a 16-lane group receives column i, 4 reduction rows per read.
-__device__ __forceinline__ void tn_frags(const char* As, const char* Bs, int mb, int ncol, int kcol, int i16, bf16x8 (&af)[2],
-                                         bf16x8 (&bfr)[2]) {
+// Fragments of one 16-row k-slice for this wave (two 32-column blocks of A and of B = 8 transpose reads), software
+// pipelined: tn_issue() only ISSUES the reads; tn_wait<N>() waits until at most N LDS operations are outstanding (LDS
+// returns in order, so N = 8 means "the older slice has landed") and names the destination registers so that no consumer
+// is scheduled above it.  Lane i of a 16-lane group receives column i, 4 reduction rows per read.
+struct TnFrag { bf16x4 r[8]; };
+__device__ __forceinline__ void tn_issue(const char* As, const char* Bs, int mb, int ncol, int kcol, int i16, TnFrag& f) {
   const unsigned a00 = tn_addr(As, mb, ncol, i16, 0), a01 = tn_addr(As, mb, ncol, i16, 1);
   const unsigned a10 = tn_addr(As, mb, ncol + 32, i16, 0), a11 = tn_addr(As, mb, ncol + 32, i16, 1);
   const unsigned b00 = tn_addr(Bs, mb, kcol, i16, 0), b01 = tn_addr(Bs, mb, kcol, i16, 1);
   const unsigned b10 = tn_addr(Bs, mb, kcol + 32, i16, 0), b11 = tn_addr(Bs, mb, kcol + 32, i16, 1);
-  bf16x4 r0, r1, r2, r3, r4, r5, r6, r7;
   asm volatile(
       "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
-      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
+      : "=&v"(f.r[0]), "=&v"(f.r[1]), "=&v"(f.r[2]), "=&v"(f.r[3]), "=&v"(f.r[4]), "=&v"(f.r[5]), "=&v"(f.r[6]), "=&v"(f.r[7])
       : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11)
       : "memory");
-  af[0] = tn_join(r0, r1); af[1] = tn_join(r2, r3); bfr[0] = tn_join(r4, r5); bfr[1] = tn_join(r6, r7);
+}
+template <int N>
+__device__ __forceinline__ void tn_wait(TnFrag& f) {
+  if constexpr (N == 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.r[4]), "+v"(f.r[5]), "+v"(f.r[6]), "+v"(f.r[7]) :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.r[4]), "+v"(f.r[5]), "+v"(f.r[6]), "+v"(f.r[7]) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <bool SLAB>
@@ -143,17 +150,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
     if (s + 1 < nsteps) stage(s + 1, smem + ((s + 1) & 1) * STAGE_BYTES);
     const char* As = cur;
     const char* Bs = cur + TILE_BYTES;
+    const int ncol = wn * 64 + (j & 1) * 16, kcol = wk * 64 + (j & 1) * 16, mg = (j >> 1) * 8;
+    TnFrag fa, fb;
+    tn_issue(As, Bs, mg, ncol, kcol, i16, fa);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int mb = kk * 16 + (j >> 1) * 8;
-      bf16x8 af[2], bfr[2];
-      tn_frags(As, Bs, mb, wn * 64 + (j & 1) * 16, wk * 64 + (j & 1) * 16, i16, af, bfr);
+    for (int kk = 0; kk < 4; kk += 2) {
+      tn_issue(As, Bs, (kk + 1) * 16 + mg, ncol, kcol, i16, fb);
+      tn_wait<8>(fa);
+      {
+        const bf16x8 a0 = tn_join(fa.r[0], fa.r[1]), a1 = tn_join(fa.r[2], fa.r[3]), b0 = tn_join(fa.r[4], fa.r[5]), b1 = tn_join(fa.r[6], fa.r[7]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[ki][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ki], af[ni], acc[ki][ni], 0, 0, 0);
+      if (kk + 2 < 4) {
+        tn_issue(As, Bs, (kk + 2) * 16 + mg, ncol, kcol, i16, fa);
+        tn_wait<8>(fb);
+      } else {
+        tn_wait<0>(fb);
+      }
+      {
+        const bf16x8 a0 = tn_join(fb.r[0], fb.r[1]), a1 = tn_join(fb.r[2], fb.r[3]), b0 = tn_join(fb.r[4], fb.r[5]), b1 = tn_join(fb.r[6], fb.r[7]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // acc[ki][ni][r] = D[k][n]: n = lane&31 (column), k = (r&3) + 8*(r>>2) + 4*(lane>>5)

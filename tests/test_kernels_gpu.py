@@ -53,6 +53,29 @@ def test_gemm_bf16_bias(ops, staging, M, N, K):
         lib().cdll.spmm_gemm_set_staging(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072)])
+def test_gemm_v3_256x256_tile(ops, M, N, K):
+    """The 256x256-tile kernel is only picked for large problems; force it (variant 101) on small/ragged shapes too."""
+    from spmm_amd._lib import lib
+    lib().cdll.spmm_gemm_set_variant(101)
+    try:
+        A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
+        bias = rnd(N, seed=23, dtype=torch.float32)
+        R = rnd(M, (N + 7) // 8 * 8, seed=24)[:, :N]
+        Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")
+        ops.gemm_nt(A, W, Cbuf[:, :N], bias=bias, R=R)
+        ref = A.float() @ W.float().t() + bias + R.float()
+        close(Cbuf[:, :N], ref, 3e-2, 1e-2, "gemm v3")
+        assert (Cbuf[:, N:] == 7.0).all()
+        C, C2 = torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda"), torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda")
+        ops.gemm_nt(A, W, C[:, :N], bias=bias, epi=ops.EPI_GELU, C2=C2[:, :N])
+        pre = A.float() @ W.float().t() + bias
+        close(C2[:, :N], pre, 3e-2, 1e-2, "v3 pre")
+        close(C[:, :N], torch.nn.functional.gelu(pre), 3e-2, 1e-2, "v3 gelu")
+    finally:
+        lib().cdll.spmm_gemm_set_variant(0)
+
+
 def test_gemm_strided_operands_and_residual(ops):
     M, N, K = 300, 128, 256
     big = rnd(M, 3 * K, seed=5)

@@ -44,3 +44,16 @@ if __name__ == "__main__":
         for _ in range(20): torch.matmul(A, W.t())
         torch.cuda.synchronize(); ms = (time.time() - t) / 20 * 1e3
         print(f"torch.matmul {M}x{N}x{K}: {ms:.3f} ms {2.0*M*N*K/ms/1e9:.1f} TF")
+
+
+def bench_tn(M, N, K, iters=20):
+    A = torch.randn(M, N, device="cuda").to(torch.bfloat16); B = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    C = torch.zeros(N, K, device="cuda")
+    for _ in range(3): ops.gemm_tn(A, B, C)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops.gemm_tn(A, B, C)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
