@@ -56,6 +56,7 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
 int spmm_gemm_tn_splits(int M, int N, int K);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
                  long ldc, float* workspace, spmm_stream_t stream);
+void spmm_gemm_tn_set_variant(int v);   /* 1 (default): 128x128 tile; 3: 256x256 tile for large problems; v >= 64: split target (workgroups) */
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 /* 1 = stage tiles with LDS-DMA (global_load_lds_dwordx4, default), 0 = through registers */
 void spmm_gemm_set_staging(int use_lds_dma);

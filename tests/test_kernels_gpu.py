@@ -125,7 +125,8 @@ def test_gemm_f32_epilogues_and_splitk(ops):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (216, 128, 256, 1), (216, 128, 256, 3), (6912, 768, 768, None),
-                                          (4096, 2304, 768, None), (1000, 300, 128, 2), (130, 64, 192, 1), (8192, 768, 3072, None)])
+                                          (4096, 2304, 768, None), (1000, 300, 128, 2), (130, 64, 192, 1), (8192, 768, 3072, None),
+                                          (2100, 300, 520, 2), (13824, 768, 768, None)])
 def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
     lda = (N + 7) // 8 * 8 + 16
     Abig = rnd(M, lda, seed=14)
