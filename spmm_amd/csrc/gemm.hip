@@ -37,6 +37,7 @@ struct GemmP {
   const bf16* G; long ldg;   // EPI_GELU_GRAD: pre-activation
   void* C; long ldc;
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
+  int order;                 // tile order inside an XCD's range: 0 n-fastest, 1 m-fastest, 2 blocked (8 m-panels x GN n-tiles)
 };
 
 // LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
@@ -454,6 +455,25 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
     }
 }
 
+// (tile_m, tile_n) of sequence index t.  Workgroup b runs on XCD b%8 and the remap gives every XCD a contiguous range of t,
+// dispatched in increasing order, so the ~32 tiles an XCD runs concurrently are 32 consecutive t.  order 2 makes those a
+// block of 8 m-panels x GN n-tiles (each A k-slice first-touched by GN CUs instead of by all n-tiles at once, and reused
+// from L2 by the following rounds of the same 8 m-panels).
+__device__ __forceinline__ void tile_of(int t, int ntm, int ntn, int order, int& tm, int& tn) {
+  if (order == 1) { tn = t / ntm; tm = t - tn * ntm; return; }
+  if (order == 2) {
+    const int gn = (ntn % 4 == 0) ? 4 : (ntn % 3 == 0 ? 3 : (ntn % 2 == 0 ? 2 : 1));
+    const int sr = t / (8 * ntn);
+    const int rows = min(8, ntm - sr * 8);
+    const int r = t - sr * 8 * ntn;
+    const int nb = r / (rows * gn), rr = r - nb * rows * gn;
+    tm = sr * 8 + rr % rows;
+    tn = nb * gn + rr / rows;
+    return;
+  }
+  tm = t / ntn; tn = t - tm * ntn;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // v3: 256x256x64 tile, 512 threads (8 waves as 2(m) x 4(n), 128x64 per wave = 4x2 MFMA tiles, 128 fp32 accumulators),
 // two 64-KiB LDS stages.  Rationale: a k-step of the 256x128 tile pulls 48 KiB through the ~64 B/clk/CU L2->LDS path for
@@ -465,7 +485,19 @@ constexpr int T3_BYTES = 256 * BK * 2;              // 32 KiB per operand tile
 constexpr int STAGE3_BYTES = 2 * T3_BYTES;          // 64 KiB
 constexpr int LDS3_BYTES = 2 * STAGE3_BYTES;        // 128 KiB
 
-template <int EPI>
+// one 16-B chunk per lane (one LDS-DMA wave-instruction) of a 256-row operand tile: chunk group c in 0..3
+__device__ __forceinline__ void dma_one(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0, char* lds_tile, int tid, int c) {
+  const int id = c * 512 + tid;
+  const int row = id >> 3, ps = id & 7;
+  const int ls = ps ^ ((row >> 1) & 7);
+  int grow = row0 + row;
+  grow = grow < nrows ? grow : nrows - 1;
+  const bf16* g = src + (long)grow * ld + k0 + ls * 8;
+  const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
+  __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
+}
+
+template <int EPI, bool INTERLEAVE>
 __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -476,7 +508,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
-  const int m0 = (t / ntn) * BM3, n0 = (t % ntn) * BN3;
+  int tile_m, tile_n;
+  tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
+  const int m0 = tile_m * BM3, n0 = tile_n * BN3;
   const int nk = p.K / BK;
 
   f32x16 acc[2][2][2];      // [m half][ni][mi]
@@ -499,9 +533,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   STAGE3(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
-    if (kt + 1 < nk) STAGE3(kt + 1);
+    const bool more = kt + 1 < nk;
+    if (!INTERLEAVE && more) STAGE3(kt + 1);
     const char* As = smem3 + (kt & 1) * STAGE3_BYTES;
     const char* Ws = As + T3_BYTES;
+    char* nxt = smem3 + ((kt + 1) & 1) * STAGE3_BYTES;
+    const int knext = (kt + 1) * BK;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int s = kk * 2 + (lane >> 5);
@@ -517,12 +554,23 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
         wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
             acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+        if constexpr (INTERLEAVE) {
+          // one LDS-DMA instruction of the next tile behind every group of 4 MFMAs: the 64 DMA wave-instructions of a
+          // k-step trickle into the address path while the matrix pipe works instead of blocking all waves up front
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            if (h == 0) dma_one(p.A, p.lda, m0, p.M, knext, nxt, tid, kk);
+            else dma_one(p.W, p.ldw, n0, p.N, knext, nxt + T3_BYTES, tid, kk);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   }
 #undef STAGE3
@@ -533,11 +581,11 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
 }
 
-template <int EPI>
-int launch_v3_one(const GemmP& p, hipStream_t st) {
+template <int EPI, bool IL>
+int launch_v3_il(const GemmP& p, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
     if (e != hipSuccess) {
       spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
       return SPMM_ERR_LAUNCH;
@@ -545,8 +593,14 @@ int launch_v3_one(const GemmP& p, hipStream_t st) {
     attr = true;
   }
   dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI>), grid, dim3(512), LDS3_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, IL>), grid, dim3(512), LDS3_BYTES, st, p);
   return SPMM_OK;
+}
+static int g_tile_order = 0;
+static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
+template <int EPI>
+int launch_v3_one(const GemmP& p, hipStream_t st) {
+  return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
 }
 int launch_v3(int epi, const GemmP& p, hipStream_t st) {
   switch (epi) {
@@ -614,7 +668,12 @@ int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
 
 static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v1 only), 2: force the v1 kernel with LDS-DMA
 extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
-extern "C" void spmm_gemm_set_variant(int v) { g_v2_variant = v; }
+extern "C" void spmm_gemm_set_variant(int v) {
+  if (v >= 300 && v <= 302) { g_tile_order = v - 300; return; }
+  if (v == 200) g_v3_interleave = 0;
+  else if (v == 201) g_v3_interleave = 1;
+  else g_v2_variant = v;
+}
 
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
                             const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
@@ -638,7 +697,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = g_tile_order;
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
     const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);
     if ((tiles3 >= 96 || g_v2_variant == 101) && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {
