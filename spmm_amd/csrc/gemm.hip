@@ -581,6 +581,123 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v4: the 256x256 tile with a FOUR-slot ring of BK=32 stages (4 x 32 KiB = 128 KiB), three stages always in flight.
+// Model behind it (PMC + aliasing experiments): the loop is DMA-latency bound, throughput ~ bytes in flight / latency;
+// v3 keeps 64 KiB in flight per CU (=> ~25 GB/s/CU at the ~2.5 us it takes a stage to land, 39 % MFMA busy), this ring
+// keeps 96 KiB in flight.  LDS rows are 64 B here, so the 16-B slot index is XOR-ed with (row>>2)&3.
+constexpr int BK4 = 32;
+constexpr int T4_BYTES = 256 * BK4 * 2;             // 16 KiB per operand tile
+constexpr int STAGE4_BYTES = 2 * T4_BYTES;          // 32 KiB
+constexpr int LDS4_BYTES = 4 * STAGE4_BYTES;        // 128 KiB
+
+__device__ __forceinline__ void dma4(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0, char* lds_tile, int tid) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = c * 512 + tid;
+    const int row = id >> 2, ps = id & 3;
+    const int ls = ps ^ ((row >> 2) & 3);
+    int grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;
+    const bf16* g = src + (long)grow * ld + k0 + ls * 8;
+    const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_v4_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  int tile_m, tile_n;
+  tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
+  const int m0 = tile_m * BM3, n0 = tile_n * BN3;
+  const int nk = p.K / BK4;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+#define STAGE4(kt_)                                                                       \
+  do {                                                                                    \
+    char* b_ = smem4 + ((kt_) & 3) * STAGE4_BYTES;                                        \
+    dma4(p.A, p.lda, m0, p.M, (kt_) * BK4, b_, tid);                                      \
+    dma4(p.W, p.ldw, n0, p.N, (kt_) * BK4, b_ + T4_BYTES, tid);                           \
+  } while (0)
+
+  STAGE4(0);
+  if (nk > 1) STAGE4(1);
+  if (nk > 2) STAGE4(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt must have landed; the 4 DMA instructions of each younger stage may still be in flight
+    const int younger = min(nk - 1 - kt, 2);
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // also: everyone is done reading slot (kt-1)&3 == (kt+3)&3
+    if (kt + 3 < nk) STAGE4(kt + 3);
+    const char* As = smem4 + (kt & 3) * STAGE4_BYTES;
+    const char* Ws = As + T4_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 128 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 64 + ((s ^ ((ar >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 64 + ((s ^ ((wr >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+    }
+  }
+#undef STAGE4
+  __builtin_amdgcn_s_barrier();
+  char* wt = smem4 + wave * 16384;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
+
+template <int EPI>
+int launch_v4_one(const GemmP& p, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS4_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
+  hipLaunchKernelGGL((gemm_nt_v4_kernel<EPI>), grid, dim3(512), LDS4_BYTES, st, p);
+  return SPMM_OK;
+}
+
 template <int EPI, bool IL>
 int launch_v3_il(const GemmP& p, hipStream_t st) {
   static bool attr = false;
@@ -602,7 +719,16 @@ template <int EPI>
 int launch_v3_one(const GemmP& p, hipStream_t st) {
   return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
 }
+static int g_use_v4 = 0;
 int launch_v3(int epi, const GemmP& p, hipStream_t st) {
+  if (g_use_v4) {
+    switch (epi) {
+      case EPI_BF16: return launch_v4_one<EPI_BF16>(p, st);
+      case EPI_GELU: return launch_v4_one<EPI_GELU>(p, st);
+      case EPI_GELU_GRAD: return launch_v4_one<EPI_GELU_GRAD>(p, st);
+      default: return -1;
+    }
+  }
   switch (epi) {
     case EPI_BF16: return launch_v3_one<EPI_BF16>(p, st);
     case EPI_GELU: return launch_v3_one<EPI_GELU>(p, st);
@@ -670,6 +796,7 @@ static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v
 extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
 extern "C" void spmm_gemm_set_variant(int v) {
   if (v >= 300 && v <= 302) { g_tile_order = v - 300; return; }
+  if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
   else g_v2_variant = v;

@@ -54,10 +54,12 @@ def test_gemm_bf16_bias(ops, staging, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072)])
-def test_gemm_v3_256x256_tile(ops, M, N, K):
+@pytest.mark.parametrize("use_v4", [0, 1])
+def test_gemm_v3_256x256_tile(ops, M, N, K, use_v4):
     """The 256x256-tile kernel is only picked for large problems; force it (variant 101) on small/ragged shapes too."""
     from spmm_amd._lib import lib
     lib().cdll.spmm_gemm_set_variant(101)
+    lib().cdll.spmm_gemm_set_variant(400 + use_v4)
     try:
         A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
         bias = rnd(N, seed=23, dtype=torch.float32)
@@ -74,6 +76,7 @@ def test_gemm_v3_256x256_tile(ops, M, N, K):
         close(C[:, :N], torch.nn.functional.gelu(pre), 3e-2, 1e-2, "v3 gelu")
     finally:
         lib().cdll.spmm_gemm_set_variant(0)
+        lib().cdll.spmm_gemm_set_variant(400)
 
 
 def test_gemm_strided_operands_and_residual(ops):
