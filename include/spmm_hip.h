@@ -45,10 +45,11 @@ const char* spmm_last_error(void);
 /* C[M,N] = A[M,K] . W[N,K]^T on MFMA (bf16 in, fp32 accumulate).  Replaces every nn.Linear on the path
  * (xbert.py:280-300 query/key/value, :370 attention output.dense, :435 intermediate.dense + erf GELU :436,
  * :448 output.dense, :673 transform.dense, :695 tied decoder; SPMM_models.py:31-42 heads) and, with transposed
- * operands, their dgrad/wgrad GEMMs; also the similarity GEMMs SPMM_models.py:108-111,121-124 (split-bf16 K=3E). */
+ * operands, their dgrad/wgrad GEMMs; also the similarity GEMMs SPMM_models.py:108-111,121-124 (split-bf16 K=3E).
+ * colsum (optional, bf16 / GELU-grad epilogues): colsum[n] += sum_m C[m][n] -- the bias gradient when C is a dY. */
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
-                 void* C2, long ldc2, int epi, spmm_stream_t stream);
+                 void* C2, long ldc2, int epi, float* colsum, spmm_stream_t stream);
 /* Weight-gradient GEMM C[N,K] += alpha * A[M,N]^T . B[M,K] straight from the token-major activations (LDS transpose reads,
  * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
  * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
@@ -81,10 +82,11 @@ int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float*
                 float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr, uint64_t salt,
                 spmm_stream_t stream);
 /* dz = dLN(dy + dy2); dx = dropout-mask(dz) when drop_on_dy == 0; drop_on_dy == 1 masks dy instead (embeddings);
- * dgamma/dbeta accumulate with atomics (may be null for frozen parameters). */
+ * dgamma/dbeta accumulate with atomics (may be null for frozen parameters); dxsum (optional) += column sums of dx,
+ * i.e. the bias gradient of the dense layer whose output was normalised. */
 int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H, float dropout_p,
-                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, spmm_stream_t stream);
+                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, spmm_stream_t stream);
 
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings

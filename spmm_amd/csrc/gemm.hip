@@ -37,6 +37,7 @@ struct GemmP {
   const bf16* G; long ldg;   // EPI_GELU_GRAD: pre-activation
   void* C; long ldc;
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
+  float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range: 0 n-fastest, 1 m-fastest, 2 blocked (8 m-panels x GN n-tiles)
 };
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
       }
     }
   // same-wave LDS round trip: the waits the compiler inserts (lgkmcnt) are enough, no barrier needed
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + (lane >> 3), c16 = lane & 7;
@@ -136,6 +138,10 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)x[e]));
     }
+    if (p.colsum) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
+    }
     if (full) {
       *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
       if constexpr (EPI == EPI_GELU) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off);
@@ -143,6 +149,22 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
       bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
       *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = lo4;
       if constexpr (EPI == EPI_GELU) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off);
+    }
+  }
+  if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      cs[e] = v;
+    }
+    if (lane < 8) {
+      const int n = n_base + lane * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) atomicAdd(p.colsum + n + e, cs[e]);
     }
   }
 }
@@ -804,7 +826,7 @@ extern "C" void spmm_gemm_set_variant(int v) {
 
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
                             const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
-                            const void* G, long ldg, void* C, long ldc, void* C2, long ldc2, int epi,
+                            const void* G, long ldg, void* C, long ldc, void* C2, long ldc2, int epi, float* colsum,
                             hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(K % 64 == 0, "spmm_gemm_nt: K=%d must be a multiple of 64", K);
@@ -824,7 +846,8 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = g_tile_order;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = g_tile_order; p.colsum = colsum;
+  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
     const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);
     if ((tiles3 >= 96 || g_v2_variant == 101) && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {

@@ -129,14 +129,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      bf16* __restrict__ dz_o, bf16* __restrict__ dx_o,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H,
                                                      uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt,
-                                                     int drop_on_dy) {
-  __shared__ float red[2][4][MAXC * 256];
+                                                     int drop_on_dy, float* __restrict__ dxsum) {
+  __shared__ float red[3][4][MAXC * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  RowVec gsum, bsum;
+  RowVec gsum, bsum, xsum;       // xsum: column sums of dx = bias gradient of the dense layer that produced x
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gsum.v[i][j] = bsum.v[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) gsum.v[i][j] = bsum.v[i][j] = xsum.v[i][j] = 0.f;
   RowVec gm;
   load_row_f32(gamma, H, lane, gm);
   const uint64_t seed = thresh16 ? (*seed_ptr ^ salt) : 0;
@@ -189,6 +189,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
       for (int j = 0; j < 4; ++j) o.v[i][j] = rstd * (g.v[i][j] - s1 - zz.v[i][j] * s2);
     store_row_bf16(dz_o + row * H, H, lane, o);
+    if (dxsum && !(dx_o && thresh16 && !drop_on_dy)) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xsum.v[i][j] += (float)(bf16)o.v[i][j];
+    }
     if (dx_o) {
       if (thresh16 && !drop_on_dy) {
 #pragma unroll
@@ -203,20 +209,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         }
       }
       store_row_bf16(dx_o + row * H, H, lane, o);
+      if (dxsum && thresh16 && !drop_on_dy) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xsum.v[i][j] += (float)(bf16)o.v[i][j];
+      }
     }
   }
-  if (dgamma == nullptr) return;
+  if (dgamma == nullptr && dxsum == nullptr) return;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       red[0][wave][(lane + 64 * i) * 4 + j] = gsum.v[i][j];
       red[1][wave][(lane + 64 * i) * 4 + j] = bsum.v[i][j];
+      red[2][wave][(lane + 64 * i) * 4 + j] = xsum.v[i][j];
     }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    if (dgamma) {
+      atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+      atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+    if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
   }
 }
 
@@ -458,14 +474,14 @@ extern "C" int spmm_ln_fwd(const void* x, const void* res, const float* gamma, c
 
 extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H,
-                           float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, hipStream_t stream) {
+                           float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_bwd: rows=%ld H=%d", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
                      gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, (uint32_t)(dropout_p * 65536.f + 0.5f),
-                     1.f / (1.f - dropout_p), seed_ptr, salt, drop_on_dy);
+                     1.f / (1.f - dropout_p), seed_ptr, salt, drop_on_dy, dxsum);
   SPMM_LAUNCH_CHECK("spmm_ln_bwd");
   return SPMM_OK;
 }

@@ -154,8 +154,8 @@ class Engine:
         dx = self._new(M, H) if ph > 0 else dz
         ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + ".output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(pfx + ".output.LayerNorm.weight"), dbeta=P.g(pfx + ".output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt_h"])
-        self._wgrad(dx, sv["ctx"], P.g(pfx + ".output.dense.weight"), P.g(pfx + ".output.dense.bias"))
+                   seed=self.seed, salt=sv["salt_h"], dxsum=P.g(pfx + ".output.dense.bias"))
+        self._wgrad(dx, sv["ctx"], P.g(pfx + ".output.dense.weight"))
         dctx = self._new(M, H)
         ops.gemm_nt(dx, self._wT(pfx + ".output.dense", P.w(pfx + ".output.dense.weight")), dctx)
         dX = self._new(M, H)
@@ -218,11 +218,12 @@ class Engine:
         dx = self._new(M, H) if ph > 0 else dz
         ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(lp + "output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(lp + "output.LayerNorm.weight"), dbeta=P.g(lp + "output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt"])
-        self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"), P.g(lp + "output.dense.bias"))
+                   seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"))
+        self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
-        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_GELU_GRAD, G=sv["pre"])
-        self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"), P.g(lp + "intermediate.dense.bias"))
+        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_GELU_GRAD, G=sv["pre"],
+                    colsum=P.g(lp + "intermediate.dense.bias"))
+        self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"))
         da = self._new(M, H)
         ops.gemm_nt(dpre, self._wT(lp + "intermediate.dense", P.w(lp + "intermediate.dense.weight")), da, R=dz)
         if sv["cross"] is not None:

@@ -45,7 +45,7 @@ def _row_stride(t):
     return t.stride(0)
 
 
-def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None):
+def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None):
     """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride)."""
     M, Ka = A.shape
     N = W.shape[0]
@@ -57,7 +57,7 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
         assert C.dtype == torch.float32
     _call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
                float(alpha), _p(R), 0 if R is None else _row_stride(R), _p(G), 0 if G is None else _row_stride(G),
-               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _st())
+               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), _st())
     return C
 
 
@@ -104,10 +104,10 @@ def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbeta=None, dropout_p=0.0, seed=None, salt=0,
-           drop_on_dy=False):
+           drop_on_dy=False, dxsum=None):
     rows, H = dy.shape
     _call("spmm_ln_bwd", _p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
-               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _st())
+               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _p(dxsum), _st())
     return dz
 
 

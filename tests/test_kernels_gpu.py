@@ -104,7 +104,9 @@ def test_gemm_gelu_and_grad_epilogues(ops):
     # GELU-grad epilogue: out = (A W^T) * gelu'(G)
     G = rnd(M, N, seed=11)
     D = torch.empty(M, N, dtype=BF, device="cuda")
-    ops.gemm_nt(A, W, D, epi=ops.EPI_GELU_GRAD, G=G)
+    cs = torch.ones(N, device="cuda")
+    ops.gemm_nt(A, W, D, epi=ops.EPI_GELU_GRAD, G=G, colsum=cs)
+    close(cs, 1.0 + D.float().sum(0), 5e-2, 1e-3, "fused column sums of the GELU-grad output")
     g = G.float().requires_grad_(True)
     torch.nn.functional.gelu(g).sum().backward()
     close(D, (A.float() @ W.float().t()) * g.grad, 3e-2, 1.5e-2, "gelu grad")
@@ -327,8 +329,10 @@ def test_layernorm_fwd_bwd(ops, rows, H):
     yr2.backward(dy.float() + dy2.float())
     dz = torch.empty_like(x)
     dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dy2=dy2, dgamma=dg, dbeta=db)
+    dxs = torch.ones(H, device="cuda")
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dy2=dy2, dgamma=dg, dbeta=db, dxsum=dxs)
     close(dz, zr2.grad, 3e-2, 2e-2, "ln dz")
+    close(dxs, 1.0 + dz.float().sum(0), 2e-3 * math.sqrt(rows), 1e-4, "ln dxsum (bias gradient of the producing dense)")
     close(dg, g.grad, 2e-2 * math.sqrt(rows), 1e-2, "ln dgamma")
     close(db, b.grad, 2e-2 * math.sqrt(rows), 1e-2, "ln dbeta")
 
@@ -346,7 +350,9 @@ def test_layernorm_dropout_masks_match(ops):
     assert torch.allclose(z.float()[keep], torch.full_like(z.float()[keep], 1 / (1 - p)), atol=1e-2)
     dy = rnd(rows, H, seed=54)
     dz, dx = torch.empty_like(x), torch.empty_like(x)
-    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dx=dx, dropout_p=p, seed=seed, salt=5)
+    dxs = torch.zeros(H, device="cuda")
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dx=dx, dropout_p=p, seed=seed, salt=5, dxsum=dxs)
+    close(dxs, dx.float().sum(0), 2e-2, 1e-3, "dxsum with dropout")
     assert ((dx.float() != 0) & ~keep).sum().item() == 0            # dropped inputs get no gradient
     close(dx.float()[keep], dz.float()[keep] / (1 - p), 1e-2, 1e-2, "dropout dx")
 
