@@ -106,6 +106,9 @@ int spmm_embed_bwd(int mode, const void* dz, const int* ids, const float* pv_x, 
 int spmm_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, int Rpad, float* colsum,
                         spmm_stream_t stream);
 int spmm_cast_transpose(const float* in, void* out, void* outT, int R, int C, spmm_stream_t stream);
+/* all transposed bf16 weight shadows in one launch; descs_dev: device array of {const float* src; bf16* dstT; int R, C, tile0, ntc} */
+long spmm_cast_transpose_desc_bytes(void);
+int spmm_cast_transpose_multi(const void* descs_dev, int ndesc, int total_tiles, spmm_stream_t stream);
 int spmm_cast_f32_bf16(const float* in, void* out, long n, spmm_stream_t stream);
 int spmm_cast_bf16_f32(const void* in, float* out, long n, spmm_stream_t stream);
 int spmm_acc_rows(float* dst, long ldd, const void* src, long lds, const long* idx, long rows, int H, int atomic,

@@ -107,7 +107,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
         }
         const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
         if constexpr (EPI == EPI_GELU) {
-          *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+          if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
           *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
         } else {
           *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
@@ -144,11 +144,11 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
     }
     if (full) {
       *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
-      if constexpr (EPI == EPI_GELU) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off);
+      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
     } else {   // ragged last chunk (N % 8 == 4)
       bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
       *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = lo4;
-      if constexpr (EPI == EPI_GELU) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off);
+      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
     }
   }
   if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
@@ -838,7 +838,6 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
-  SPMM_CHECK_SHAPE(epi != EPI_GELU || C2 != nullptr, "spmm_gemm_nt: GELU epilogue needs C2");
   SPMM_CHECK_SHAPE(epi != EPI_GELU_GRAD || G != nullptr, "spmm_gemm_nt: GELU-grad epilogue needs G");
   int ksplit = ((K / 64 + splits - 1) / splits) * 64;
   splits = (K + ksplit - 1) / ksplit;

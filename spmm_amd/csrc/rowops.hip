@@ -321,9 +321,11 @@ struct EmbedBwdP {
 };
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdP p) {
   const int l = blockIdx.x;
+  const long s_per = (p.nseq + gridDim.y - 1) / gridDim.y;
+  const long s_beg = blockIdx.y * s_per, s_end = min(p.nseq, s_beg + s_per);
   for (int c = threadIdx.x; c < p.H; c += 256) {
     float acc = 0.f, accw = 0.f, accb = 0.f, accm = 0.f;
-    for (long s = 0; s < p.nseq; ++s) {
+    for (long s = s_beg; s < s_end; ++s) {
       const long row = s * p.L + l;
       const float g = (float)p.dz[row * p.H + c];
       acc += g;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdP p) {
         accm += g * m;
       }
     }
-    p.dpos[(long)l * p.H + c] += acc;
+    atomicAdd(p.dpos + (long)l * p.H + c, acc);
     atomicAdd(p.dtype0 + c, acc);
     if (p.mode == 1) {
       if (l == 0) {
@@ -405,6 +407,33 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
       const int c = c0 + ty * 16 + i, r = r0 + tx;
       if (c < C && r < R) outT[(long)c * R + r] = tile[tx][ty * 16 + i];
     }
+  }
+}
+
+// All transposed bf16 dgrad shadows in ONE launch: descriptor table (device) of {fp32 src, bf16 dstT, R, C, first tile};
+// workgroup b finds its matrix by binary search over the tile prefix.
+struct CtDesc { const float* src; bf16* dstT; int R, C; int tile0, ntc; };
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CtDesc* __restrict__ descs, int ndesc) {
+  __shared__ bf16 tile[64][66];
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CtDesc d = descs[lo];
+  const int tt = blockIdx.x - d.tile0;
+  const int r0 = (tt / d.ntc) * 64, c0 = (tt % d.ntc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    tile[ty * 16 + i][tx] = (r < d.R && c < d.C) ? (bf16)d.src[(long)r * d.C + c] : (bf16)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (c < d.C && r < d.R) d.dstT[(long)c * d.R + r] = tile[tx][ty * 16 + i];
   }
 }
 
@@ -510,7 +539,7 @@ extern "C" int spmm_embed_bwd(int mode, const void* dz, const int* ids, const fl
                               float* d_masktok, long nseq, int L, int H, hipStream_t stream) {
   SPMM_CHECK_SHAPE(nseq > 0 && L > 0 && H > 0, "spmm_embed_bwd: nseq=%ld L=%d H=%d", nseq, L, H);
   EmbedBwdP p = {(const bf16*)dz, ids, pv_x, pv_mask, src_mod, dword, dpos, dtype0, d_w, d_b, d_cls, d_masktok, nseq, L, H, mode};
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(L), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(L, nseq >= 32 ? 16 : 1), dim3(256), 0, stream, p);
   SPMM_LAUNCH_CHECK("spmm_embed_bwd");
   return SPMM_OK;
 }
@@ -528,6 +557,14 @@ extern "C" int spmm_cast_transpose(const float* in, void* out, void* outT, int R
   SPMM_CHECK_SHAPE(R > 0 && C > 0, "spmm_cast_transpose: R=%d C=%d", R, C);
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, in, (bf16*)out, (bf16*)outT, R, C);
   SPMM_LAUNCH_CHECK("spmm_cast_transpose");
+  return SPMM_OK;
+}
+
+extern "C" long spmm_cast_transpose_desc_bytes(void) { return sizeof(CtDesc); }
+extern "C" int spmm_cast_transpose_multi(const void* descs_dev, int ndesc, int total_tiles, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(ndesc > 0 && total_tiles > 0, "spmm_cast_transpose_multi: ndesc=%d tiles=%d", ndesc, total_tiles);
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(total_tiles), dim3(256), 0, stream, (const CtDesc*)descs_dev, ndesc);
+  SPMM_LAUNCH_CHECK("spmm_cast_transpose_multi");
   return SPMM_OK;
 }
 

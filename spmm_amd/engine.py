@@ -198,7 +198,8 @@ class Engine:
         sv2 = None
         if has_cross:
             a, sv2 = self._attn_block_fwd(lp + "crossattention", c, a, groups, save, cross=True)
-        h, pre = self._new(M, I), self._new(M, I)
+        h = self._new(M, I)
+        pre = self._new(M, I) if save else None          # the pre-activation is only needed by backward
         ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"), epi=ops.EPI_GELU, C2=pre)
         x = self._new(M, H)
         ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x, bias=P.w(lp + "output.dense.bias"))

@@ -138,6 +138,10 @@ def cast_transpose(w32, out, outT):
     _call("spmm_cast_transpose", _p(w32), _p(out), _p(outT), R, C, _st())
 
 
+def cast_transpose_multi(descs_dev, ndesc, total_tiles):
+    _call("spmm_cast_transpose_multi", _p(descs_dev), ndesc, total_tiles, _st())
+
+
 def cast_f32_bf16(x, out):
     _call("spmm_cast_f32_bf16", _p(x), _p(out), x.numel(), _st())
     return out

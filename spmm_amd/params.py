@@ -134,8 +134,21 @@ class ParamStore:
         if not transposed_only:
             ops.cast_f32_bf16(self.flat, self.shadow)
             ops.cast_f32_bf16(self.flat_m, self.shadow_m)
-        for key, src in getattr(self, "_wT_src", {}).items():
-            ops.cast_transpose(src, None, self._wT[key])
+        srcs = getattr(self, "_wT_src", {})
+        if not srcs:
+            return
+        if getattr(self, "_ct_n", -1) != len(srcs):       # (re)build the device descriptor table when shadows were added
+            import struct
+            blob, tile0 = b"", 0
+            for key, src in srcs.items():
+                R, C = src.shape
+                ntr, ntc = (R + 63) // 64, (C + 63) // 64
+                blob += struct.pack("<QQiiii", src.data_ptr(), self._wT[key].data_ptr(), R, C, tile0, ntc)
+                tile0 += ntr * ntc
+            assert len(blob) == len(srcs) * 32
+            self._ct_desc = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            self._ct_n, self._ct_tiles = len(srcs), tile0
+        ops.cast_transpose_multi(self._ct_desc, self._ct_n, self._ct_tiles)
 
     def copy_params(self):
         """copy_params SPMM_models.py:259-263: momentum twins start as copies of the student."""
