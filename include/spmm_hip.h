@@ -90,7 +90,8 @@ int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mea
 
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings
- * (inputs_embeds branch).  Sequence s reads PV source row s % src_mod. */
+ * (inputs_embeds branch).  Sequence s reads PV source row s % src_mod.  mode 2: generic inputs_embeds branch of
+ * BertEmbeddings (pv_x = fp32 inputs_embeds [nseq*L, H]). */
 int spmm_embed_ln_fwd(int mode, const int* ids, const float* word, const float* pos, const float* type0, const float* pv_x,
                       const float* pv_mask, const float* pv_w, const float* pv_b, const float* pv_cls,
                       const float* pv_masktok, int src_mod, const float* gamma, const float* beta, void* y, void* zout,

@@ -246,7 +246,7 @@ struct EmbedP {
   const float* word;         // [V, H]
   const float* pos;          // [P, H]
   const float* type0;        // [H]
-  const float* pv_x;         // [nseq_src, L-1] (mode 1)
+  const float* pv_x;         // [nseq_src, L-1] (mode 1); mode 2: inputs_embeds fp32 [nseq*L, H]
   const float* pv_mask;      // [nseq_src, L-1] 1 = masked
   const float* pv_w; const float* pv_b; const float* pv_cls; const float* pv_masktok;   // [H] each
   int src_mod;               // mode 1: source row = seq % src_mod (P1 and P11 share the batch)
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(EmbedP p) {
   if (p.mode == 0) {
     const int id = p.ids[row];
     load_row_f32(p.word + (long)id * p.H, p.H, lane, t);
+  } else if (p.mode == 2) {
+    load_row_f32(p.pv_x + row * p.H, p.H, lane, t);
   } else if (l == 0) {
     load_row_f32(p.pv_cls, p.H, lane, t);
   } else {
@@ -521,7 +523,7 @@ extern "C" int spmm_embed_ln_fwd(int mode, const int* ids, const float* word, co
                                  const float* beta, void* y, void* zout, float* mean, float* rstd, long nseq, int L, int H,
                                  float eps, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, hipStream_t stream) {
   SPMM_CHECK_SHAPE(nseq > 0 && L > 0 && H % 4 == 0 && H <= 1024, "spmm_embed_ln_fwd: nseq=%ld L=%d H=%d", nseq, L, H);
-  SPMM_CHECK_SHAPE(mode == 0 ? (ids && word) : (pv_x && pv_mask && pv_w && pv_b && pv_cls && pv_masktok && src_mod > 0),
+  SPMM_CHECK_SHAPE(mode == 0 ? (ids && word) : mode == 2 ? (pv_x != nullptr) : (pv_x && pv_mask && pv_w && pv_b && pv_cls && pv_masktok && src_mod > 0),
                    "spmm_embed_ln_fwd: missing inputs for mode %d", mode);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_embed_ln_fwd: dropout needs a device seed");
   EmbedP p = {};

@@ -272,6 +272,16 @@ class Engine:
                          seed=self.seed, salt=salt)
         return y, dict(z=z, mean=mean, rstd=rstd, salt=salt)
 
+    def embed_generic(self, pfx, c, inputs_embeds_f32, nseq, L):
+        """BertEmbeddings on caller-supplied inputs_embeds (xbert.py:199-219), inference only."""
+        P, H = self.P, c.hidden_size
+        y = self._new(nseq * L, H)
+        ops.embed_ln_fwd(2, y, nseq=nseq, L=L, H=H, pos=P.w(pfx + "embeddings.position_embeddings.weight"),
+                         type0=P.w(pfx + "embeddings.token_type_embeddings.weight"), gamma=P.w(pfx + "embeddings.LayerNorm.weight"),
+                         beta=P.w(pfx + "embeddings.LayerNorm.bias"), pv_x=inputs_embeds_f32, eps=c.layer_norm_eps,
+                         dropout_p=self._p_hidden(c), seed=self.seed, salt=self._next_salt())
+        return y
+
     def _embed_ln_bwd(self, pfx, c, sv, dY):
         P = self.P
         dz = self._new(*dY.shape)

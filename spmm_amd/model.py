@@ -124,6 +124,15 @@ class SPMM(nn.Module):
             self.loader_len = loader_len
             self.momentum = config["momentum"]
             self.queue_size = config["queue_size"]
+        # sub-module facades with the reference's call signatures
+        from .facade import BertFacade, LinearFacade, MaskedLMFacade, MtrHeadFacade
+        object.__setattr__(self, "text_encoder", MaskedLMFacade(self, "text_encoder.", self.cfg.text))
+        object.__setattr__(self, "text_encoder_m", MaskedLMFacade(self, "text_encoder_m.", self.cfg.text))
+        object.__setattr__(self, "property_encoder", BertFacade(self, "property_encoder.", self.cfg.prop, False))
+        object.__setattr__(self, "property_encoder_m", BertFacade(self, "property_encoder_m.", self.cfg.prop, False))
+        for nm in ("property_proj", "text_proj", "itm_head", "property_embed", "property_proj_m", "text_proj_m"):
+            object.__setattr__(self, nm, LinearFacade(self, nm))
+        object.__setattr__(self, "property_mtr_head", MtrHeadFacade(self))
         self.current_epoch = 0
         self.global_rank = 0
         self._optimizer = None
@@ -179,6 +188,24 @@ class SPMM(nn.Module):
     @property
     def temp(self):
         return self._parameters["temp"]
+
+    @property
+    def device(self):
+        return self.device_
+
+    # ---- checkpoints in the reference's Lightning layout (SPMM_pretrain.py:24-37; consumers d_pv2smiles_batched.py:133-146,
+    #      d_regression.py:153-162, SPMM_models_rxn.py:16-27) ----------------------------------------------------------------
+    def save_checkpoint(self, path: str, **extra):
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
+        torch.save(dict(state_dict=sd, epoch=self.current_epoch, **extra), path)
+
+    def load_checkpoint(self, path_or_dict, strict: bool = False):
+        """Accepts the Lightning dict ('state_dict'), the legacy 'model' key, or a bare state_dict; applies the legacy
+        `_unk -> _mask` rename and drops nothing the arena knows.  strict=False mirrors SPMM_pretrain.py:26."""
+        ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
+        sd = ck.get("state_dict", ck.get("model", ck))
+        sd = {k.replace("_unk", "_mask"): v for k, v in sd.items()}
+        return self.load_state_dict(sd, strict=strict)
 
     @property
     def queue_ptr(self):

@@ -164,6 +164,9 @@ class ParamStore:
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         missing = [n for n, _, _ in self.spec if n not in sd]
         unexpected = [k for k in sd if k not in self.shape]
+        bad = [k for k in sd if k in self.shape and tuple(sd[k].shape) != tuple(self.shape[k]) and sd[k].numel() != int(math.prod(self.shape[k]) if self.shape[k] else 1)]
+        if bad:
+            raise RuntimeError(f"size mismatch for {bad[:5]}")
         if strict and (missing or unexpected):
             raise KeyError(f"state_dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
         with torch.no_grad():

@@ -112,3 +112,27 @@ def test_bert_config_accepts_string_true(tmp_path):
     json.dump({"hidden_size": 100, "num_attention_heads": 3}, open(p, "w"))
     with pytest.raises(ValueError):
         BertConfig.from_json_file(str(p))
+
+
+def test_checkpoint_roundtrip_and_legacy_layouts(dry, tmp_path):
+    """Lightning-style checkpoint dict ('state_dict'), the legacy 'model' key and the legacy `_unk` names
+    (SPMM_pretrain.py:24-37, SPMM_models_rxn.py:19-21, d_regression.py:157-161)."""
+    m = _tiny_model()
+    sd = O.closed_form_state_dict(O.tiny_cfg())
+    m.load_state_dict(sd)
+    path = str(tmp_path / "checkpoint_epoch=0.ckpt")
+    m.save_checkpoint(path)
+    ck = torch.load(path)
+    assert set(ck) >= {"state_dict", "epoch"} and len(ck["state_dict"]) == 178
+    m2 = _tiny_model()
+    m2.load_checkpoint(path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    legacy = {k.replace("property_mask", "property_unk"): v for k, v in sd.items()}
+    m3 = _tiny_model()
+    res = m3.load_checkpoint({"model": legacy})
+    assert not res.missing_keys and torch.equal(m3.state_dict()["property_mask"], sd["property_mask"])
+    # consumers drop queue / PV word-embedding keys before loading (d_pv2smiles_batched.py:138-142): strict=False tolerates it
+    partial = {k: v for k, v in sd.items() if "queue" not in k and "property_encoder.embeddings.word_embeddings" not in k}
+    res = _tiny_model().load_checkpoint({"state_dict": partial})
+    assert set(res.missing_keys) == {"prop_queue", "text_queue", "queue_ptr", "property_encoder.embeddings.word_embeddings.weight"}
