@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (NOT the benchmark configuration)")
+    ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,8 +107,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("SPMM_DIST_BACKEND", "nccl")          # "gloo" lets two ranks share one GPU in tests
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            torch.distributed.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device(f"cuda:{torch.cuda.current_device()}")
@@ -241,6 +248,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(16, Lt)
         print(json.dumps(out), flush=True)
+    if args.check_replicas and world > 1:
+        from spmm_amd.parallel import assert_replicas_identical
+        assert_replicas_identical(model.store.flat, "student parameters")
+        assert_replicas_identical(model.store.flat_m, "momentum parameters")
+        assert_replicas_identical(model.store.buffers["prop_queue"], "prop_queue")
+        assert_replicas_identical(model.store.buffers["text_queue"], "text_queue")
+        assert_replicas_identical(model.store.buffers["queue_ptr"], "queue_ptr")
+        if rank == 0:
+            print("replicas identical after", args.warmup + args.steps, "steps; queue_ptr =", int(model.queue_ptr), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -149,7 +149,9 @@ int spmm_clamp_scalar(float* p, float lo, float hi, spmm_stream_t stream);
 
 /* clip_grad_norm_(5.) + AdamW SPMM_models.py:340,361-362 and the EMA of the momentum encoders :266-269. */
 long spmm_adam_scalars_bytes(void);
-int spmm_grad_sqnorm(const float* g, long n, float* out_zeroed, spmm_stream_t stream);
+long spmm_grad_sqnorm_workspace_bytes(void);
+/* deterministic (fixed-order) sum of squares: replicas with identical gradients get identical clip coefficients */
+int spmm_grad_sqnorm(const float* g, long n, float* out_zeroed, float* workspace, spmm_stream_t stream);
 int spmm_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, const float* lr_ptr,
                     float beta1, float beta2, float eps, float weight_decay, const float* normsq, float max_norm, int* step,
                     const int* nan_flag, void* scalars_ws, spmm_stream_t stream);

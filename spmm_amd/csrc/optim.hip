@@ -19,7 +19,10 @@ struct AdamScalars {   // written by adamw_prep_kernel, read by adamw_kernel
   float grad_norm;     // for logging
 };
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n4, float* __restrict__ out) {
+// Deterministic two-stage reduction (fixed summation order): data-parallel replicas hold bit-identical gradients after the
+// all-reduce and must derive the SAME clip coefficient, otherwise their parameters drift apart in the last bits.
+constexpr int SQN_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n4, float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -29,7 +32,16 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ void adamw_prep_kernel(const float* __restrict__ normsq, float max_norm, float beta1, float beta2,
@@ -91,11 +103,15 @@ __global__ void axpy_scalar_kernel(float* dst, const float* src, const float* sc
 
 extern "C" long spmm_adam_scalars_bytes(void) { return sizeof(AdamScalars); }
 
-extern "C" int spmm_grad_sqnorm(const float* g, long n, float* out_zeroed, hipStream_t stream) {
+extern "C" long spmm_grad_sqnorm_workspace_bytes(void) { return SQN_BLOCKS * sizeof(float); }
+
+extern "C" int spmm_grad_sqnorm(const float* g, long n, float* out_zeroed, float* workspace, hipStream_t stream) {
   SPMM_CHECK_SHAPE(n > 0 && n % 4 == 0, "spmm_grad_sqnorm: n=%ld must be a positive multiple of 4", n);
+  SPMM_CHECK_SHAPE(workspace != nullptr, "spmm_grad_sqnorm: needs a workspace of spmm_grad_sqnorm_workspace_bytes()");
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, g, n / 4, out_zeroed);
+  if (blocks > SQN_BLOCKS) blocks = SQN_BLOCKS;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, g, n / 4, workspace);
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, workspace, (int)blocks, out_zeroed);
   SPMM_LAUNCH_CHECK("spmm_grad_sqnorm");
   return SPMM_OK;
 }

@@ -222,8 +222,15 @@ def adam_scalars_bytes():
     return lib().cdll.spmm_adam_scalars_bytes()
 
 
+_sqn_ws = {}
+
+
 def grad_sqnorm(g, out):
-    _call("spmm_grad_sqnorm", _p(g), g.numel(), _p(out), _st())
+    ws = _sqn_ws.get(g.device)
+    if ws is None:
+        nbytes = 4096 if _DRY_RUN else lib().cdll.spmm_grad_sqnorm_workspace_bytes()
+        ws = _sqn_ws[g.device] = torch.zeros(nbytes // 4, dtype=torch.float32, device=g.device)
+    _call("spmm_grad_sqnorm", _p(g), g.numel(), _p(out), _p(ws), _st())
 
 
 def adamw_step(p, g, m, v, shadow, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.02, normsq, max_norm=5.0, step,
