@@ -519,7 +519,8 @@ __device__ __forceinline__ void dma_one(const bf16* __restrict__ src, long ld, i
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
 }
 
-template <int EPI, bool INTERLEAVE>
+// ABL (timing experiments only, results are garbage): 1 = no DMA, 2 = no LDS fragment reads, 3 = MFMA only
+template <int EPI, bool INTERLEAVE, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -552,11 +553,14 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     stage2_dma(p.W, p.ldw, n0, p.N, (kt_) * BK, b_ + T3_BYTES, tid, 4);                       \
   } while (0)
 
-  STAGE3(0);
+  if (ABL != 1 && ABL != 3) STAGE3(0);
+  bf16x8 cst;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cst[e] = (bf16)(0.001f * (lane + e));
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
     const bool more = kt + 1 < nk;
-    if (!INTERLEAVE && more) STAGE3(kt + 1);
+    if (!INTERLEAVE && more && ABL != 1 && ABL != 3) STAGE3(kt + 1);
     const char* As = smem3 + (kt & 1) * STAGE3_BYTES;
     const char* Ws = As + T3_BYTES;
     char* nxt = smem3 + ((kt + 1) & 1) * STAGE3_BYTES;
@@ -565,15 +569,22 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     for (int kk = 0; kk < 4; ++kk) {
       const int s = kk * 2 + (lane >> 5);
       bf16x8 af[4], wf[2];
+      if constexpr (ABL >= 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ar = wm * 128 + i * 32 + (lane & 31);
-        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-      }
+        for (int i = 0; i < 4; ++i) { af[i] = cst; asm volatile("" : "+v"(af[i])); }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wr = wn * 64 + i * 32 + (lane & 31);
-        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+        for (int i = 0; i < 2; ++i) { wf[i] = cst; asm volatile("" : "+v"(wf[i])); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ar = wm * 128 + i * 32 + (lane & 31);
+          af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int wr = wn * 64 + i * 32 + (lane & 31);
+          wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+        }
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -736,9 +747,20 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   return SPMM_OK;
 }
 static int g_tile_order = 0;
+static int g_v3_abl = 0;
 static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
+template <int ABL>
+int launch_v3_abl(const GemmP& p, hipStream_t st) {
+  hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI_BF16, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI_BF16, false, ABL>), grid, dim3(512), LDS3_BYTES, st, p);
+  return SPMM_OK;
+}
 template <int EPI>
 int launch_v3_one(const GemmP& p, hipStream_t st) {
+  if (EPI == EPI_BF16 && g_v3_abl == 1) return launch_v3_abl<1>(p, st);
+  if (EPI == EPI_BF16 && g_v3_abl == 2) return launch_v3_abl<2>(p, st);
+  if (EPI == EPI_BF16 && g_v3_abl == 3) return launch_v3_abl<3>(p, st);
   return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
 }
 static int g_use_v4 = 0;
@@ -819,6 +841,7 @@ extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_l
 extern "C" void spmm_gemm_set_variant(int v) {
   if (v >= 300 && v <= 302) { g_tile_order = v - 300; return; }
   if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
+  if (v >= 500 && v <= 503) { g_v3_abl = v - 500; return; }
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
   else g_v2_variant = v;
