@@ -635,3 +635,33 @@ def synthetic_batch(B: int, Lt: int, seed: int = 42, n_props: int = 53, vocab: i
         ids[b, n - 1] = 3
     mask = (ids != 0).long()
     return prop, ids, mask
+
+
+# ------------------------------------------------------------------ module-API view (for the decode parity tests)
+class OracleModule:
+    """The reference's module API over the functional oracle, CPU fp32: lets code written against
+    `model.property_embed / property_cls / property_encoder / text_encoder(..., return_logits=True)` (d_pv2smiles_*.py) run
+    on the oracle."""
+
+    def __init__(self, sd: SD, cfg: SPMMCfg):
+        self.sd, self.cfg = sd, cfg
+        self.property_cls = sd["property_cls"]
+
+    def property_embed(self, x):
+        return F.linear(x, self.sd["property_embed.weight"], self.sd["property_embed.bias"])
+
+    def property_encoder(self, inputs_embeds=None, return_dict=True, is_decoder=False):
+        from types import SimpleNamespace
+        with torch.no_grad():
+            return SimpleNamespace(last_hidden_state=bert_model(self.sd, "property_encoder.", self.cfg.prop, False,
+                                                                inputs_embeds=inputs_embeds, is_decoder=is_decoder))
+
+    def text_encoder(self, input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                     return_dict=True, is_decoder=False, return_logits=False):
+        with torch.no_grad():
+            n = input_ids.shape[0]
+            enc = encoder_hidden_states.expand(n, -1, -1)
+            em = None if encoder_attention_mask is None else encoder_attention_mask.expand(n, -1)
+            h = bert_model(self.sd, "text_encoder.bert.", self.cfg.text, True, input_ids=input_ids, attention_mask=attention_mask,
+                           enc=enc, enc_mask=em, is_decoder=is_decoder)
+            return mlm_head(self.sd, "text_encoder.", self.cfg.text, h)

@@ -56,6 +56,10 @@ class BertFacade:
         kv, Lkv, kvm = None, 0, None
         if encoder_hidden_states is not None:
             Lkv = encoder_hidden_states.shape[1]
+            if encoder_hidden_states.shape[0] == 1 and nseq > 1:      # one PV sequence shared by k beams: the reference relies on
+                encoder_hidden_states = encoder_hidden_states.expand(nseq, -1, -1)   # matmul broadcasting (d_pv2smiles_single.py:29-35)
+                if encoder_attention_mask is not None:
+                    encoder_attention_mask = encoder_attention_mask.expand(nseq, -1)
             kv = encoder_hidden_states.to(dev).to(BF).reshape(nseq * Lkv, H).contiguous()
             kvm = _i32(encoder_attention_mask, nseq, Lkv, dev)
         lo, hi = {"text": (0, c.fusion_layer), "fusion": (c.fusion_layer, c.num_hidden_layers),

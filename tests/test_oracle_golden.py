@@ -116,3 +116,20 @@ def test_state_spec_counts():
     n_train = sum(int(np.prod(s)) if s else 1 for n, s, k in O.state_spec(O.full_cfg())
                   if n in set(O.trainable_names(O.full_cfg())))
     assert n_train == 144_374_064
+
+
+def test_oracle_module_api_runs_beam_decode():
+    """The decode algorithm itself (host logic) on the CPU oracle: hypotheses are well formed and sorted."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from spmm_amd import decode
+    sd = O.closed_form_state_dict(O.tiny_cfg())
+    om = O.OracleModule(sd, O.tiny_cfg())
+    prop = torch.randn(53, generator=torch.Generator().manual_seed(9))
+    pe = decode.encode_properties(om, prop.reshape(1, -1))
+    assert pe.shape == (1, 54, 128)
+    v, i = decode.next_token_topk(om, pe, torch.full((1, 1), decode.CLS_ID, dtype=torch.long), 4)
+    assert v.shape == (1, 4) and (v[0, :-1] >= v[0, 1:]).all() and i.max() < 300
+    hyps = decode.beam_search(om, prop, k=3, max_steps=8)
+    assert all(s[0] == decode.CLS_ID and s[-1] == decode.SEP_ID for _, s in hyps)
+    assert [p for p, _ in hyps] == sorted([p for p, _ in hyps], reverse=True)
