@@ -76,16 +76,18 @@ __device__ __forceinline__ void stage_tile_write(char* lds_tile, int tid, const 
 }
 
 
-// Coalesced bf16 epilogue: the wave's 64x64 output tile goes through LDS (8 KiB per wave per output) so that global
+// Coalesced bf16 epilogue: a wave's 64x64 output tile goes through LDS (8 KiB per wave per output) so that global
 // stores are 16 B per lane along rows (8 lanes = one 128-B row segment) instead of 8-B fragments scattered over 32 rows.
 // acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5).   Tile rows are 128 B; the 16-B chunk index is
 // XOR-ed with (row & 7) so the row-parallel writes and the row-major reads both spread over the banks.
-template <int EPI>
-__device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane) {
+// Split in two halves so that a kernel can let DIFFERENT waves do the second half (wave-specialised stores, v6):
+//   epi_convert: accumulators -> scale / bias / GELU -> bf16 tile in LDS       (GMODE 1: pre-activation, 2: activation only)
+//   epi_store  : LDS tile -> (+R, * gelu'(G)) -> row-coalesced global stores (+ fused column sums)
+template <int EPI, int GMODE = 0>
+__device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2], char* t0, char* t1, int n_base, int lane,
+                                            const float* bias_lds = nullptr) {
   float scale = p.alpha;
   if (p.div_ptr) scale /= *p.div_ptr;
-  char* t0 = wtile;                 // main output
-  char* t1 = wtile + 8192;          // EPI_GELU: pre-activation
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -100,13 +102,17 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
         if (p.bias) {
           const int n = n_base + col;
           if (n < p.N) {
-            const f32x4 b = *(const f32x4*)(p.bias + n);
+            const f32x4 b = bias_lds ? *(const f32x4*)(bias_lds + n) : *(const f32x4*)(p.bias + n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += b[j];
           }
         }
         const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
-        if constexpr (EPI == EPI_GELU) {
+        if constexpr (EPI == EPI_GELU && GMODE == 1) {
+          *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (EPI == EPI_GELU && GMODE == 2) {
+          *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else if constexpr (EPI == EPI_GELU) {
           if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
           *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
         } else {
@@ -114,7 +120,31 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
         }
       }
     }
-  // same-wave LDS round trip: the waits the compiler inserts (lgkmcnt) are enough, no barrier needed
+}
+
+template <int EPI, bool NOSTORE = false, int GMODE = 0>
+__device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const char* t1, int m_base, int n_base, int lane) {
+  // all R / G operand loads first: a load placed behind a store to a possibly aliasing pointer would be serialised behind it
+  bf16x8 rr[8], gg[8];
+  if (p.R || EPI == EPI_GELU_GRAD) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+      const int m = m_base + row, n = n_base + c16 * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { rr[it][e] = (bf16)0.f; gg[it][e] = (bf16)0.f; }
+      if (m >= p.M || n >= p.N) continue;
+      const bool full = n + 8 <= p.N;
+      if (p.R) {
+        if (full) rr[it] = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
+        else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); rr[it][0] = h4[0]; rr[it][1] = h4[1]; rr[it][2] = h4[2]; rr[it][3] = h4[3]; }
+      }
+      if constexpr (EPI == EPI_GELU_GRAD) {
+        if (full) gg[it] = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
+        else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); gg[it][0] = h4[0]; gg[it][1] = h4[1]; gg[it][2] = h4[2]; gg[it][3] = h4[3]; }
+      }
+    }
+  }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -125,30 +155,26 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
     bf16x8 o = *(const bf16x8*)(t0 + off);
     const bool full = n + 8 <= p.N;
     if (p.R) {
-      bf16x8 r = {};
-      if (full) r = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
-      else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); r[0] = h4[0]; r[1] = h4[1]; r[2] = h4[2]; r[3] = h4[3]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)r[e]);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)rr[it][e]);
     }
     if constexpr (EPI == EPI_GELU_GRAD) {
-      bf16x8 x = {};
-      if (full) x = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
-      else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); x[0] = h4[0]; x[1] = h4[1]; x[2] = h4[2]; x[3] = h4[3]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)x[e]));
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)gg[it][e]));
     }
     if (p.colsum) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
     }
+    if constexpr (NOSTORE) { asm volatile("" :: "v"(o)); continue; }
+    bf16* dst = (EPI == EPI_GELU && GMODE == 1) ? p.C2 + (long)m * p.ldc2 + n : (bf16*)p.C + (long)m * p.ldc + n;
     if (full) {
-      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
-      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
+      *(bf16x8*)dst = o;
+      if constexpr (EPI == EPI_GELU && GMODE == 0) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
     } else {   // ragged last chunk (N % 8 == 4)
       bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
-      *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = lo4;
-      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
+      *(bf16x4*)dst = lo4;
+      if constexpr (EPI == EPI_GELU && GMODE == 0) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
     }
   }
   if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
@@ -167,6 +193,13 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
         if (n + e < p.N) atomicAdd(p.colsum + n + e, cs[e]);
     }
   }
+}
+
+// both halves by the same wave on its private region (same-wave LDS round trip: the compiler's lgkmcnt waits suffice)
+template <int EPI, bool NOSTORE = false, int GMODE = 0>
+__device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane) {
+  epi_convert<EPI, GMODE>(p, acc, wtile, wtile + 8192, n_base, lane);
+  epi_store<EPI, NOSTORE, GMODE>(p, wtile, wtile + 8192, m_base, n_base, lane);
 }
 
 template <int EPI, bool GLDS>
@@ -609,9 +642,376 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
 #undef STAGE3
   __syncthreads();                                     // all waves done with the staging buffers
   char* wt = smem3 + wave * 16384;                     // 16 KiB private epilogue region per wave
+  if constexpr (ABL == 5) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[h][i][j]));
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
-    epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+    epilogue_bf16<EPI, ABL == 4>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v5: PERSISTENT v3.  One 512-thread workgroup per CU walks its share of the 256x256 tiles; the k-steps of consecutive
+// tiles form one continuous double-buffered stream, so the next tile's first stage is already in flight while the current
+// tile's epilogue runs, no workgroup dispatch sits between tiles, and the epilogue's (fire-and-forget) global stores drain
+// under the next tile's MFMAs.  Motivation (ablation on 93184x3072x768): 790 TF as launched per tile, 1035 with the stores
+// skipped, 1268 with no epilogue.  Workgroup b keeps XCD b%8 and takes tiles start_x + (b>>3) + j*(blocks per XCD) of that
+// XCD's contiguous range, so the tiles an XCD runs concurrently stay neighbours (same A panels in its L2).
+// The epilogue uses only the 64-KiB stage that was just consumed (8 KiB per wave); GELU's two outputs go out in two passes.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem5[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  const int nk = p.K / BK;
+  // this workgroup's tiles
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q = nt >> 3, r = nt & 7;
+  const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int xn = xcd < r ? q + 1 : q;
+  const int my_tiles = lb < xn ? (xn - lb + bpx - 1) / bpx : 0;
+  if (my_tiles == 0) return;
+  const long S = (long)my_tiles * nk;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+
+  // staging cursor (one step ahead of the compute cursor)
+  int sj = 0, skt = 0, sm0, sn0;
+  {
+    int tm, tn;
+    tile_of(xs + lb, ntm, ntn, p.order, tm, tn);
+    sm0 = tm * BM3; sn0 = tn * BN3;
+  }
+  int cm0 = sm0, cn0 = sn0, ckt = 0;
+  auto stage = [&](long g) {
+    char* b_ = smem5 + (g & 1) * STAGE3_BYTES;
+    stage2_dma(p.A, p.lda, sm0, p.M, skt * BK, b_, tid, 4);
+    stage2_dma(p.W, p.ldw, sn0, p.N, skt * BK, b_ + T3_BYTES, tid, 4);
+    if (++skt == nk) {
+      skt = 0;
+      ++sj;
+      if (sj < my_tiles) {
+        int tm, tn;
+        tile_of(xs + lb + sj * bpx, ntm, ntn, p.order, tm, tn);
+        sm0 = tm * BM3; sn0 = tn * BN3;
+      }
+    }
+  };
+  stage(0);
+  int cj = 0;
+  for (long g = 0; g < S; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage g landed (issued a whole k-step ago); older epilogue stores done
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < S) stage(g + 1);
+    const char* As = smem5 + (g & 1) * STAGE3_BYTES;
+    const char* Ws = As + T3_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 128 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+    }
+    if (++ckt == nk) {      // tile finished: epilogue out of the stage that was just consumed; stage g+1 keeps landing meanwhile
+      ckt = 0;
+      __builtin_amdgcn_s_barrier();                      // every wave is done reading stage g
+      char* wt = smem5 + (g & 1) * STAGE3_BYTES + wave * 8192;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if constexpr (EPI == EPI_GELU) {
+          if (p.C2) epilogue_bf16<EPI_GELU, false, 1>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
+          epilogue_bf16<EPI_GELU, false, 2>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
+        } else {
+          epilogue_bf16<EPI>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+      }
+      ++cj;
+      if (cj < my_tiles) {
+        int tm, tn;
+        tile_of(xs + lb + cj * bpx, ntm, ntn, p.order, tm, tn);
+        cm0 = tm * BM3; cn0 = tn * BN3;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v6: v5 + WAVE SPECIALISATION.  vmcnt is an in-order per-wave counter that also counts stores, so in v5 every wave had to
+// see its own epilogue stores (a chip-wide 32-MiB burst ~ 8 us at HBM write speed) complete before it could consume the next
+// LDS-DMA stage: the stores never overlapped the next tile.  Here waves 4-7 ("loaders") issue ALL LDS-DMA and the R / G
+// fix-up loads and never store; every wave converts its accumulators into its 8-KiB LDS region; waves 0-3 ("storers") issue
+// ALL global stores (two regions each) and contain no VMEM load at all (the bias vector is staged into LDS once per kernel),
+// so nothing in a storer ever waits on vmcnt and the stores drain under the next tile's MFMAs.
+constexpr int BIAS6_BYTES = 16384;                  // bias staged in LDS: N <= 4096
+constexpr int LDS6_BYTES = LDS3_BYTES + BIAS6_BYTES;
+
+// loader waves: tile[row][*] (+)= R, *= gelu'(G), in place in LDS (16 B per lane, row-coalesced global loads)
+template <int EPI>
+__device__ __forceinline__ void epi_fixup(const GemmP& p, char* t0, int m_base, int n_base, int lane) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+    const int m = m_base + row, n = n_base + c16 * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const int off = row * 128 + ((c16 ^ (row & 7)) << 4);
+    const bool full = n + 8 <= p.N;
+    bf16x8 o = *(const bf16x8*)(t0 + off);
+    if (p.R) {
+      bf16x8 r = {};
+      if (full) r = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
+      else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); r[0] = h4[0]; r[1] = h4[1]; r[2] = h4[2]; r[3] = h4[3]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)r[e]);
+    }
+    if constexpr (EPI == EPI_GELU_GRAD) {
+      bf16x8 x = {};
+      if (full) x = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
+      else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); x[0] = h4[0]; x[1] = h4[1]; x[2] = h4[2]; x[3] = h4[3]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)x[e]));
+    }
+    *(bf16x8*)(t0 + off) = o;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_v6_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem6[];
+  float* bias_lds = (float*)(smem6 + LDS3_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool loader = wave >= 4;
+  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  const int nk = p.K / BK;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q = nt >> 3, r = nt & 7;
+  const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int xn = xcd < r ? q + 1 : q;
+  const int my_tiles = lb < xn ? (xn - lb + bpx - 1) / bpx : 0;
+  if (my_tiles == 0) return;
+  const long S = (long)my_tiles * nk;
+  if (p.bias) {
+    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias[i];
+  }
+  GemmP pe = p;                                   // epilogue view: R / G are applied by the loaders' fix-up, not by epi_store
+  pe.R = nullptr;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+
+  int sj = 0, skt = 0, sm0, sn0;
+  {
+    int tm, tn;
+    tile_of(xs + lb, ntm, ntn, p.order, tm, tn);
+    sm0 = tm * BM3; sn0 = tn * BN3;
+  }
+  int cm0 = sm0, cn0 = sn0, ckt = 0, cj = 0;
+  // loaders only: 2048 chunks per operand tile / 256 loader threads = 8 LDS-DMA instructions per operand per stage
+  auto stage = [&](long g) {
+    char* b_ = smem6 + (g & 1) * STAGE3_BYTES;
+    const int lt = tid - 256;
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const bf16* src = op ? p.W : p.A;
+      const long ld = op ? p.ldw : p.lda;
+      const int row0 = op ? sn0 : sm0, nrows = op ? p.N : p.M;
+      char* tile = b_ + op * T3_BYTES;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int id = c * 256 + lt;
+        const int row = id >> 3, ps = id & 7;
+        const int ls = ps ^ ((row >> 1) & 7);
+        int grow = row0 + row;
+        grow = grow < nrows ? grow : nrows - 1;
+        const bf16* gp = src + (long)grow * ld + skt * BK + ls * 8;
+        const int wave_base = __builtin_amdgcn_readfirstlane((c * 256 + (lt & ~63)) * 16);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gp, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
+      }
+    }
+  };
+  auto advance_stage = [&]() {
+    if (++skt == nk) {
+      skt = 0;
+      ++sj;
+      if (sj < my_tiles) {
+        int tm, tn;
+        tile_of(xs + lb + sj * bpx, ntm, ntn, p.order, tm, tn);
+        sm0 = tm * BM3; sn0 = tn * BN3;
+      }
+    }
+  };
+  if (loader) stage(0);
+  advance_stage();
+  for (long g = 0; g < S; ++g) {
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loaders' DMA of stage g (and fix-up loads) landed
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < S) {
+      if (loader) stage(g + 1);
+      advance_stage();
+    }
+    const char* As = smem6 + (g & 1) * STAGE3_BYTES;
+    const char* Ws = As + T3_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 128 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+    }
+    if (++ckt == nk) {
+      ckt = 0;
+      char* base = smem6 + (g & 1) * STAGE3_BYTES;         // the stage just consumed: 8 regions of 8 KiB
+      char* mine = base + wave * 8192;
+      constexpr bool FIX = (EPI == EPI_GELU_GRAD);
+      const bool fix = FIX || p.R != nullptr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        constexpr int NPASS = (EPI == EPI_GELU) ? 2 : 1;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          if (EPI == EPI_GELU && pass == 0 && !p.C2) continue;
+          __builtin_amdgcn_s_barrier();                    // regions free: main-loop reads / previous stores' LDS reads done
+          if constexpr (EPI == EPI_GELU) {
+            if (pass == 0) epi_convert<EPI_GELU, 1>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
+            else epi_convert<EPI_GELU, 2>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
+          } else {
+            epi_convert<EPI, 0>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
+          }
+          __builtin_amdgcn_s_barrier();
+          if (fix) {                                        // loaders patch R / gelu'(G) into two regions each
+            if (loader) {
+#pragma unroll
+              for (int rr = 0; rr < 2; ++rr) {
+                const int w2 = (wave - 4) + rr * 4;
+                epi_fixup<EPI>(p, base + w2 * 8192, cm0 + (w2 >> 2) * 128 + h * 64, cn0 + (w2 & 3) * 64, lane);
+              }
+            }
+            __builtin_amdgcn_s_barrier();
+          }
+          if (!loader) {                                    // storers: two regions each, no VMEM loads in this path
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              const int w2 = wave + rr * 4;
+              const char* reg = base + w2 * 8192;
+              const int mb = cm0 + (w2 >> 2) * 128 + h * 64, nb = cn0 + (w2 & 3) * 64;
+              if constexpr (EPI == EPI_GELU) {
+                if (pass == 0) epi_store<EPI_GELU, false, 1>(pe, reg, reg, mb, nb, lane);
+                else epi_store<EPI_GELU, false, 2>(pe, reg, reg, mb, nb, lane);
+              } else if constexpr (EPI == EPI_GELU_GRAD) {
+                epi_store<EPI_BF16, false, 0>(pe, reg, reg, mb, nb, lane);      // gelu' already applied by the fix-up
+              } else {
+                epi_store<EPI, false, 0>(pe, reg, reg, mb, nb, lane);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+      }
+      ++cj;
+      if (cj < my_tiles) {
+        int tm, tn;
+        tile_of(xs + lb + cj * bpx, ntm, ntn, p.order, tm, tn);
+        cm0 = tm * BM3; cn0 = tn * BN3;
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_v6_one(const GemmP& p, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS6_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const long nt = (long)((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
+  int nb = nt >= 256 ? 256 : (int)((nt + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_nt_v6_kernel<EPI>), dim3(nb), dim3(512), LDS6_BYTES, st, p);
+  return SPMM_OK;
+}
+
+template <int EPI>
+int launch_v5_one(const GemmP& p, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const long nt = (long)((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
+  int nb = nt >= 256 ? 256 : (int)((nt + 7) / 8) * 8;     // one workgroup per CU, a multiple of the 8 XCDs
+  hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI>), dim3(nb), dim3(512), LDS3_BYTES, st, p);
+  return SPMM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -747,11 +1147,11 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   return SPMM_OK;
 }
 static int g_tile_order = 0;
-static int g_v3_abl = 0;
+static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
 static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
 template <int ABL>
 int launch_v3_abl(const GemmP& p, hipStream_t st) {
-  hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI_BF16, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI_BF16, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
   dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
   hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI_BF16, false, ABL>), grid, dim3(512), LDS3_BYTES, st, p);
   return SPMM_OK;
@@ -761,10 +1161,29 @@ int launch_v3_one(const GemmP& p, hipStream_t st) {
   if (EPI == EPI_BF16 && g_v3_abl == 1) return launch_v3_abl<1>(p, st);
   if (EPI == EPI_BF16 && g_v3_abl == 2) return launch_v3_abl<2>(p, st);
   if (EPI == EPI_BF16 && g_v3_abl == 3) return launch_v3_abl<3>(p, st);
+  if (EPI == EPI_BF16 && g_v3_abl == 4) return launch_v3_abl<4>(p, st);
+  if (EPI == EPI_BF16 && g_v3_abl == 5) return launch_v3_abl<5>(p, st);
   return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
 }
 static int g_use_v4 = 0;
+static int g_use_v5 = 0;           // 0 (default): per-tile v3; 1: persistent v5; 2: persistent + wave-specialised v6 -- all three measure the same
 int launch_v3(int epi, const GemmP& p, hipStream_t st) {
+  if (g_use_v5 == 2 && !g_use_v4 && g_v3_abl == 0 && p.N <= 4096) {
+    switch (epi) {
+      case EPI_BF16: return launch_v6_one<EPI_BF16>(p, st);
+      case EPI_GELU: return launch_v6_one<EPI_GELU>(p, st);
+      case EPI_GELU_GRAD: return launch_v6_one<EPI_GELU_GRAD>(p, st);
+      default: return -1;
+    }
+  }
+  if (g_use_v5 && !g_use_v4 && g_v3_abl == 0) {
+    switch (epi) {
+      case EPI_BF16: return launch_v5_one<EPI_BF16>(p, st);
+      case EPI_GELU: return launch_v5_one<EPI_GELU>(p, st);
+      case EPI_GELU_GRAD: return launch_v5_one<EPI_GELU_GRAD>(p, st);
+      default: return -1;
+    }
+  }
   if (g_use_v4) {
     switch (epi) {
       case EPI_BF16: return launch_v4_one<EPI_BF16>(p, st);
@@ -841,7 +1260,8 @@ extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_l
 extern "C" void spmm_gemm_set_variant(int v) {
   if (v >= 300 && v <= 302) { g_tile_order = v - 300; return; }
   if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
-  if (v >= 500 && v <= 503) { g_v3_abl = v - 500; return; }
+  if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
+  if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
   else g_v2_variant = v;
