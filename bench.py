@@ -183,8 +183,17 @@ def main():
                 return r
             return w
 
+        gemm_bytes = [0.0]
+
         def gemm_flops(A, W, C, **k):
-            return 2.0 * A.shape[0] * W.shape[0] * (k.get("K") or A.shape[1])
+            M, N, K = A.shape[0], W.shape[0], (k.get("K") or A.shape[1])
+            # algorithmic bytes of the launch: each operand read once, each output written once
+            b = 2.0 * (M * K + N * K) + M * N * C.element_size()
+            for name in ("R", "G", "C2"):
+                if k.get(name) is not None:
+                    b += M * N * k[name].element_size()
+            gemm_bytes[0] += b
+            return 2.0 * M * N * K
 
         ops.gemm_nt = timed("gemm", orig_gemm, gemm_flops)
         nsteps = min(3, args.steps)
@@ -228,7 +237,17 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "launches_per_step": n_launch // nsteps, "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
                 "flops_per_step": tot_fl / nsteps, "gemm_ms_per_step": round(tot_ms / nsteps, 3),
+                "algorithmic_bytes_per_launch": round(gemm_bytes[0] / n_launch),
                 "measured": f"HIP events around every launch, {nsteps} instrumented steps after the timed region"}
+        # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
+        # process); the committed summary is quoted only when it was taken on this exact workload.
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_nt_gemm.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc["workload"] == {"batch": B, "seq_len": Lt, "layers": nt, "queue": args.queue}:
+                roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
+                roof["traffic_note"] = ("bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_nt_gemm.json "
+                                        "(L2<->fabric requests, Infinity-Cache hits included)")
 
     flops = step_flops(B, Lt, n_text=nt, fusion=f, n_pv=npv, Q=args.queue)
     value = world * B / (dt / args.steps)

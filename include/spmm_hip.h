@@ -88,6 +88,19 @@ int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mea
                 void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H, float dropout_p,
                 const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, spmm_stream_t stream);
 
+/* One decode step of BertEmbeddings.forward (xbert.py:193-220) at inference: y[r] = LN(word[ids[r]] + pos[pos_index] +
+ * type[0]) for `rows` single-token rows (every beam is at the same position). */
+int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const float* word, const float* pos, const float* type0,
+                           const float* gamma, const float* beta, void* y, long rows, int H, float eps, spmm_stream_t stream);
+
+/* Single-query attention over a key/value cache (xbert.py:305-354 for the newest position only; the cache slots the
+ * reference sketches at xbert.py:291-295,480,1344-1348).  Row r, head h: softmax_j(q_r,h . K[s(r,j), j, h] * scale) V[...],
+ * j < Lkv <= 256, head_dim 64.  Key/value (s, j) lives at element offset s*seq_stride + j*tok_stride (+ h*64) from K / V.
+ * s(r,j) = anc[r*anc_ld + j] (self-attention: beam ancestry table, cache rows are never moved) or r / kv_div when anc is
+ * null (cross-attention: the k beams of a molecule share its PV keys/values).  No mask: beams carry no padding. */
+int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, const int* anc,
+                     int anc_ld, int kv_div, void* out, long ldo, int R, int nH, int Lkv, float scale, spmm_stream_t stream);
+
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings
  * (inputs_embeds branch).  Sequence s reads PV source row s % src_mod.  mode 2: generic inputs_embeds branch of

@@ -526,6 +526,19 @@ __device__ __forceinline__ void tile_of(int t, int ntm, int ntn, int order, int&
     tn = nb * gn + rr / rows;
     return;
   }
+  if (order >= 3 && ntn >= 8) {
+    // ng column groups, each walked row-major: an XCD's chunk of consecutive t stays inside one group, so the W panel it
+    // keeps re-reading is <= ~2.4 MB (L2-resident) instead of the whole W (4.7 MB at N=3072, K=768 > the 4-MiB L2).
+    const int ng = order == 3 ? 2 : 4, base = ntn / ng, rem = ntn - base * ng;
+    int c0 = 0, u = t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g >= ng) break;
+      const int cg = base + (g < rem ? 1 : 0), sz = ntm * cg;
+      if (u < sz || g == ng - 1) { tm = u / cg; tn = c0 + (u - tm * cg); return; }
+      u -= sz; c0 += cg;
+    }
+  }
   tm = t / ntn; tn = t - tm * ntn;
 }
 
@@ -1146,7 +1159,7 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, IL>), grid, dim3(512), LDS3_BYTES, st, p);
   return SPMM_OK;
 }
-static int g_tile_order = 0;
+static int g_tile_order = 3;          // row-major, split into 2 column groups when N >= 2048 and K <= 1024: lowest measured L2-miss traffic (profiles/r01_pmc_nt_gemm.txt); launch time is order-insensitive
 static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
 static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
 template <int ABL>
@@ -1258,7 +1271,7 @@ int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
 static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v1 only), 2: force the v1 kernel with LDS-DMA
 extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
 extern "C" void spmm_gemm_set_variant(int v) {
-  if (v >= 300 && v <= 302) { g_tile_order = v - 300; return; }
+  if (v >= 300 && v <= 304) { g_tile_order = v - 300; return; }
   if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
   if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
   if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
@@ -1288,7 +1301,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = g_tile_order; p.colsum = colsum;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum;
   SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
     const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);

@@ -62,3 +62,210 @@ def beam_search(model, prop: torch.Tensor, k: int = 5, max_steps: int = 100) -> 
         product_input = product_input_k2[rows, cols]
     final = sorted(final, key=lambda x: x[0], reverse=True)[:k]
     return [(p, s.tolist()) for p, s in final]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Batched decoding: N molecules x k beams per launch, key/value cache, no host round trips inside the loop.
+# ------------------------------------------------------------------------------------------------------------------
+class BeamBook:
+    """The beam bookkeeping of `beam_search` above for N independent molecules at once, as tensor ops (no `.item()`):
+    per molecule it makes exactly the decisions d_pv2smiles_batched.py:29-57 makes -- candidates ending in [SEP] are moved to
+    `final` in row-major order and struck out with -1e5, the molecule stops once it holds >= k finals, the k best of the
+    k*k candidates survive."""
+
+    def __init__(self, N: int, k: int, max_steps: int, device):
+        self.N, self.k, self.Lmax = N, k, max_steps + 3
+        self.F = 2 * k                                    # < k finals before the last appending step, <= k appended by it
+        self.tokens = torch.zeros(N, k, self.Lmax, dtype=torch.long, device=device)
+        self.tokens[:, :, 0] = CLS_ID
+        self.t = 1                                        # tokens held by every live beam
+        self.cur_p = torch.zeros(N, k, device=device)
+        self.fin_p = torch.full((N, self.F + 1), -float("inf"), device=device)           # slot F is a write-only dump
+        self.fin_len = torch.zeros(N, self.F + 1, dtype=torch.long, device=device)
+        self.fin_tok = torch.zeros(N, self.F + 1, self.Lmax, dtype=torch.long, device=device)
+        self.fin_n = torch.zeros(N, dtype=torch.long, device=device)
+        self.done = torch.zeros(N, dtype=torch.bool, device=device)
+
+    def first(self, values: torch.Tensor, indices: torch.Tensor):
+        """values/indices [N,k]: log-probs and ids of the k best successors of [CLS]."""
+        self.tokens[:, :, 1] = indices
+        self.cur_p = values.clone()
+        self.t = 2
+
+    def update(self, values: torch.Tensor, indices: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """values/indices [N,k,k]: per live beam the k best next tokens.  Returns (parent [N,k], token [N,k]) of the new beams."""
+        N, k, t, F = self.N, self.k, self.t, self.F
+        k2_p = (self.cur_p[:, :, None] + values).reshape(N, k * k)
+        idx = indices.reshape(N, k * k)
+        ends = (idx == SEP_ID) & ~self.done[:, None]
+        e = ends.long()
+        slot = torch.where(ends, self.fin_n[:, None] + torch.cumsum(e, 1) - e, torch.full_like(e, F))
+        self.fin_p.scatter_(1, slot, k2_p)
+        self.fin_len.scatter_(1, slot, torch.full_like(e, t + 1))
+        cand = self.tokens[:, :, None, :].expand(N, k, k, self.Lmax).reshape(N, k * k, self.Lmax).clone()
+        cand[:, :, t] = SEP_ID
+        self.fin_tok.scatter_(1, slot[:, :, None].expand(N, k * k, self.Lmax), cand)
+        self.fin_n = self.fin_n + e.sum(1)
+        k2_p = torch.where(ends, torch.full_like(k2_p, -1e5), k2_p)
+        new_p, flat = torch.topk(k2_p, k, dim=1)
+        parent = flat // k
+        tok = idx.gather(1, flat)
+        live = ~(self.done | (self.fin_n >= k))           # a molecule that just reached k finals breaks before this update
+        new_tokens = self.tokens.gather(1, parent[:, :, None].expand(N, k, self.Lmax)).clone()
+        new_tokens[:, :, t] = tok
+        self.tokens = torch.where(live[:, None, None], new_tokens, self.tokens)
+        self.cur_p = torch.where(live[:, None], new_p, self.cur_p)
+        self.done = self.done | (self.fin_n >= k)
+        self.t = t + 1
+        return parent, tok
+
+    def results(self) -> List[List[Tuple[float, List[int]]]]:
+        k, F = self.k, self.F
+        p = self.fin_p[:, :F]
+        order = torch.sort(p, dim=1, descending=True, stable=True).indices[:, :k].cpu()
+        p, ln, tk, n = p.cpu(), self.fin_len[:, :F].cpu(), self.fin_tok[:, :F].cpu(), self.fin_n.cpu()
+        out = []
+        for m in range(self.N):
+            hyp = []
+            for j in order[m].tolist():
+                if j < int(n[m]):
+                    hyp.append((float(p[m, j]), tk[m, j, : int(ln[m, j])].tolist()))
+            out.append(hyp)
+        return out
+
+
+class RecomputeDecoder:
+    """Step function with the reference's cost model: re-runs the whole prefix of every beam through the module API
+    (`model.text_encoder(..., is_decoder=True, return_logits=True)`), so it works with the CPU oracle as well."""
+
+    def __init__(self, model, prop_embeds: torch.Tensor, k: int, Lmax: int):
+        self.m, self.k = model, k
+        self.kv = prop_embeds.repeat_interleave(k, dim=0)
+        self.tok = torch.zeros(self.kv.shape[0], Lmax, dtype=torch.long, device=prop_embeds.device)
+
+    def step(self, ids: torch.Tensor, t: int) -> torch.Tensor:
+        self.tok[:, t] = ids
+        text = self.tok[:, : t + 1]
+        return self.m.text_encoder(text, attention_mask=torch.ones_like(text), encoder_hidden_states=self.kv,
+                                   encoder_attention_mask=torch.ones(self.kv.shape[:-1], dtype=torch.long, device=self.kv.device),
+                                   return_dict=True, is_decoder=True, return_logits=True)[:, -1, :]
+
+    def reorder(self, parent: torch.Tensor, t: int):
+        N, k = parent.shape
+        L = self.tok.shape[1]
+        self.tok = self.tok.view(N, k, L).gather(1, parent[:, :, None].expand(N, k, L)).reshape(N * k, L)
+
+
+class CachedDecoder:
+    """One new token per beam per step on the HIP engine: per-layer self-attention K/V cache [R, Lmax, H] that is never
+    moved (the ancestry table `anc[r, j]` names the cache row holding position j of row r's hypothesis), cross-attention
+    K/V projected once per molecule and shared by its k beams (cache slots sketched at
+    xbert.py:291-295,480,1344-1348)."""
+
+    def __init__(self, model, prop_embeds: torch.Tensor, k: int, Lmax: int):
+        from . import ops
+        from .engine import BF
+        self.ops, self.BF = ops, BF
+        eng = model.engine
+        self.eng, self.P, self.c, self.k = eng, eng.P, model.cfg.text, k
+        self.pfx = "text_encoder."
+        c, dev = self.c, model.device_
+        N, Lkv, H = prop_embeds.shape
+        assert Lmax <= 256 and H == c.hidden_size and c.hidden_size // c.num_attention_heads == 64
+        self.N, self.R, self.Lmax, self.Lp, self.H = N, N * k, Lmax, Lkv, H
+        nl = c.num_hidden_layers
+        self.kc = [torch.empty(self.R, Lmax, H, dtype=BF, device=dev) for _ in range(nl)]
+        self.vc = [torch.empty(self.R, Lmax, H, dtype=BF, device=dev) for _ in range(nl)]
+        self.anc = torch.arange(self.R, dtype=torch.int32, device=dev)[:, None].repeat(1, Lmax).contiguous()
+        self.rows = torch.arange(self.R, dtype=torch.int32, device=dev)
+        kv_src = prop_embeds.to(dev).to(BF).reshape(N * Lkv, H).contiguous()
+        self.xkv = {}
+        for l in range(c.fusion_layer, nl):
+            pf = f"{self.pfx}bert.encoder.layer.{l}.crossattention.self."
+            KV = torch.empty(N * Lkv, 2 * H, dtype=BF, device=dev)
+            ops.gemm_nt(kv_src, self.P.fused(pf, ("key", "value"), "weight"), KV, bias=self.P.fused(pf, ("key", "value"), "bias", what="w"))
+            self.xkv[l] = KV
+
+    def _new(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.BF, device=self.anc.device)
+
+    def _attn_out(self, pf, ctx, resid):
+        ops, P, c = self.ops, self.P, self.c
+        x = self._new(self.R, self.H)
+        ops.gemm_nt(ctx, P.wb(pf + "output.dense.weight"), x, bias=P.w(pf + "output.dense.bias"))
+        y = self._new(self.R, self.H)
+        ops.ln_fwd(x, resid, P.w(pf + "output.LayerNorm.weight"), P.w(pf + "output.LayerNorm.bias"), y, eps=c.layer_norm_eps)
+        return y
+
+    @torch.no_grad()
+    def step(self, ids: torch.Tensor, t: int) -> torch.Tensor:
+        """ids [R]: the token at position t of every beam -> fp32 logits [R, V] for position t + 1."""
+        ops, P, c, R, H, nH = self.ops, self.P, self.c, self.R, self.H, self.c.num_attention_heads
+        bp = self.pfx + "bert."
+        x = self._new(R, H)
+        ops.embed_step_ln_fwd(ids.to(torch.int32).contiguous(), t, x, word=P.w(bp + "embeddings.word_embeddings.weight"),
+                              pos=P.w(bp + "embeddings.position_embeddings.weight"), type0=P.w(bp + "embeddings.token_type_embeddings.weight"),
+                              gamma=P.w(bp + "embeddings.LayerNorm.weight"), beta=P.w(bp + "embeddings.LayerNorm.bias"), eps=c.layer_norm_eps)
+        for l in range(c.num_hidden_layers):
+            lp = f"{bp}encoder.layer.{l}."
+            pf = lp + "attention."
+            QKV = self._new(R, 3 * H)
+            ops.gemm_nt(x, P.fused(pf + "self.", ("query", "key", "value"), "weight"), QKV,
+                        bias=P.fused(pf + "self.", ("query", "key", "value"), "bias", what="w"))
+            self.kc[l][:, t].copy_(QKV[:, H:2 * H])
+            self.vc[l][:, t].copy_(QKV[:, 2 * H:])
+            ctx = self._new(R, H)
+            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=t + 1, seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc)
+            a = self._attn_out(pf, ctx, x)
+            if l >= c.fusion_layer:
+                pf = lp + "crossattention."
+                q = self._new(R, H)
+                ops.gemm_nt(a, P.wb(pf + "self.query.weight"), q, bias=P.w(pf + "self.query.bias"))
+                KV = self.xkv[l]
+                ops.decode_attn(q, KV[:, :H], KV[:, H:], ctx, nH=nH, Lkv=self.Lp, seq_stride=self.Lp * 2 * H, tok_stride=2 * H, kv_div=self.k)
+                a = self._attn_out(pf, ctx, a)
+            h = self._new(R, c.intermediate_size)
+            ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"), epi=ops.EPI_GELU)
+            x2 = self._new(R, H)
+            ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x2, bias=P.w(lp + "output.dense.bias"))
+            x = self._new(R, H)
+            ops.ln_fwd(x2, a, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), x, eps=c.layer_norm_eps)
+        logits, _ = self.eng.lm_head_fwd(self.pfx, c, x, False)
+        return logits
+
+    @torch.no_grad()
+    def reorder(self, parent: torch.Tensor, t: int):
+        """New beam b of molecule n continues old beam parent[n, b]; positions < t are inherited, position t is its own."""
+        N, k, L = self.N, self.k, self.Lmax
+        self.anc = self.anc.view(N, k, L).gather(1, parent[:, :, None].expand(N, k, L)).reshape(N * k, L).contiguous()
+        self.anc[:, t:] = self.rows[:, None]
+
+
+@torch.no_grad()
+def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
+                        sync_every: int = 4) -> List[List[Tuple[float, List[int]]]]:
+    """`beam_search` for N molecules at once (props [N,53]); result[n] is what beam_search(model, props[n]) returns.
+    cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
+    through the module API (any model exposing it, e.g. the CPU oracle)."""
+    if cached is None:
+        cached = hasattr(model, "engine")
+    prop_embeds = encode_properties(model, props)
+    N, dev = prop_embeds.shape[0], prop_embeds.device
+    if cached:
+        model.engine.train_mode = False
+    dec = (CachedDecoder if cached else RecomputeDecoder)(model, prop_embeds, k, max_steps + 3)
+    book = BeamBook(N, k, max_steps, dev)
+    ids = torch.full((N * k,), CLS_ID, dtype=torch.long, device=dev)
+    logits = dec.step(ids, 0).view(N, k, -1)[:, 0]                       # all k rows hold the same [CLS] prefix
+    top = torch.topk(torch.softmax(logits.float(), dim=-1), k=k, dim=-1)
+    book.first(torch.log(top.values), top.indices)
+    ids = top.indices.reshape(N * k)
+    for s in range(max_steps):
+        logits = dec.step(ids, s + 1).view(N, k, -1)
+        top = torch.topk(torch.softmax(logits.float(), dim=-1), k=k, dim=-1)
+        parent, tok = book.update(torch.log(top.values), top.indices)
+        dec.reorder(parent, s + 2)
+        ids = tok.reshape(N * k)
+        if s % sync_every == sync_every - 1 and bool(book.done.all()):
+            break
+    return book.results()

@@ -662,3 +662,51 @@ def test_adamw_clip_ema_match_torch(ops):
     ops.ema_update(pm, p, shadow, 0.995)
     close(pm, ref, 1e-6, 1e-6, "ema")
     assert torch.equal(shadow, pm.to(BF))
+
+
+@pytest.mark.parametrize("R,nH,Lkv,Lmax,kv_div", [(10, 2, 1, 16, 0), (15, 12, 37, 64, 0), (20, 12, 54, 54, 5), (64, 4, 130, 160, 0), (6, 2, 256, 256, 3)])
+def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div):
+    """Single-query attention against a cache addressed through the beam ancestry table (kv_div == 0) or shared per molecule
+    (kv_div > 0), vs fp32 torch on the same bf16 inputs (xbert.py:305-354 for the last position)."""
+    H = nH * 64
+    g = torch.Generator().manual_seed(R + Lkv)
+    q = (torch.randn(R, 3 * H, generator=g)).to(BF).cuda()                     # strided view like the fused QKV output
+    nseq = R if kv_div == 0 else (R + kv_div - 1) // kv_div
+    wide = 2 * H if kv_div else H                                               # cross K/V live side by side in one buffer
+    cache = torch.randn(nseq, Lmax, wide, generator=g).to(BF).cuda()
+    Kc = cache[:, :, :H]
+    Vc = cache[:, :, H:] if kv_div else torch.randn(nseq, Lmax, H, generator=g).to(BF).cuda()
+    anc = None if kv_div else torch.randint(0, R, (R, Lmax), generator=g).to(torch.int32).cuda()
+    out = torch.zeros(R, H, dtype=BF, device="cuda")
+    ops.decode_attn(q[:, :H], Kc, Vc, out, nH=nH, Lkv=Lkv, seq_stride=Lmax * wide, tok_stride=wide, anc=anc, kv_div=max(kv_div, 1))
+    j = torch.arange(Lkv, device="cuda")
+    seq = anc[:, :Lkv].long() if kv_div == 0 else (torch.arange(R, device="cuda") // kv_div)[:, None].expand(R, Lkv)
+    K = Kc.float()[seq, j[None, :]].view(R, Lkv, nH, 64)
+    V = Vc.float()[seq, j[None, :]].view(R, Lkv, nH, 64)
+    s = torch.einsum("rhd,rjhd->rhj", q[:, :H].float().view(R, nH, 64), K) * 0.125
+    ref = torch.einsum("rhj,rjhd->rhd", torch.softmax(s, -1), V).reshape(R, H)
+    close(out.float(), ref, 2e-2, 2e-2, "decode_attn")
+
+
+def test_decode_attention_rejects_bad_arguments(ops):
+    q = torch.zeros(4, 128, dtype=BF, device="cuda")
+    kv = torch.zeros(4, 300, 128, dtype=BF, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.decode_attn(q, kv, kv, q.clone(), nH=2, Lkv=300, seq_stride=300 * 128, tok_stride=128, kv_div=1)
+    with pytest.raises(RuntimeError):
+        ops.decode_attn(q, kv, kv, q.clone(), nH=2, Lkv=8, seq_stride=300 * 128 + 4, tok_stride=128, kv_div=1)
+
+
+def test_embed_step_matches_full_embedding(ops):
+    """Embedding one token at position t equals row t of the whole-sequence embedding kernel (same arithmetic, bit-exact)."""
+    H, V, L, n = 256, 50, 12, 9
+    g = torch.Generator().manual_seed(3)
+    word, pos, typ = (torch.randn(s, H, generator=g).cuda() for s in (V, 32, 2))
+    gamma, beta = torch.rand(H, generator=g).cuda() + 0.5, torch.randn(H, generator=g).cuda()
+    ids = torch.randint(1, V, (n, L), generator=g).to(torch.int32).cuda()
+    full = torch.empty(n * L, H, dtype=BF, device="cuda")
+    ops.embed_ln_fwd(0, full, nseq=n, L=L, H=H, pos=pos, type0=typ, gamma=gamma, beta=beta, ids=ids, word=word)
+    for t in (0, 5, 11):
+        y = torch.empty(n, H, dtype=BF, device="cuda")
+        ops.embed_step_ln_fwd(ids[:, t].contiguous(), t, y, word=word, pos=pos, type0=typ, gamma=gamma, beta=beta)
+        assert torch.equal(y, full.view(n, L, H)[:, t])

@@ -352,3 +352,76 @@ def test_beam_decode_matches_oracle_teacher_forced(env):
     hyps = decode.beam_search(m, prop, k=k, max_steps=12)
     for p, seq in hyps:
         assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and p <= 0.0
+
+
+def _peaky_lm(sd, seed=5, sep_gap=1.5):
+    """Make next-token distributions well separated and [SEP] a frequent runner-up, so beams diverge and finish."""
+    g = torch.Generator().manual_seed(seed)
+    b = torch.randn(sd["text_encoder.cls.predictions.bias"].shape, generator=g) * 1.5
+    b[3] = b.max() - sep_gap
+    sd = dict(sd)
+    sd["text_encoder.cls.predictions.bias"] = b
+    sd["text_encoder.cls.predictions.decoder.bias"] = b          # tied alias (xbert.py:695-701): both keys are in the state_dict
+    return sd
+
+
+def test_cached_decoder_step_matches_full_prefix_forward(env):
+    """One-token-per-step decoding against the K/V cache gives the logits the whole-prefix forward (the reference's cost
+    model, d_pv2smiles_single.py:26-44) gives for the last position -- through beam reorders that only touch the ancestry
+    table.  Tolerance 3e-2 on log-probabilities (bf16 activations; the two paths use different attention kernels)."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd import decode
+    sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()))
+    m = _mk(SPMM, tiny_config(), sd).eval()
+    N, k, T = 3, 4, 9
+    g = torch.Generator().manual_seed(2)
+    props = torch.randn(N, 53, generator=g)
+    pe = decode.encode_properties(m, props)
+    cached = decode.CachedDecoder(m, pe, k, T + 3)
+    full = decode.RecomputeDecoder(m, pe, k, T + 3)
+    ids = torch.full((N * k,), decode.CLS_ID, dtype=torch.long, device="cuda")
+    for t in range(T):
+        lc = torch.log_softmax(cached.step(ids, t).float(), -1)
+        lf = torch.log_softmax(full.step(ids, t).float(), -1)
+        assert (lc - lf).abs().max().item() < 3e-2, t
+        parent = torch.randint(0, k, (N, k), generator=g).cuda()
+        cached.reorder(parent, t + 1)
+        full.reorder(parent, t + 1)
+        ids = torch.randint(4, 300, (N * k,), generator=g).cuda()
+
+
+def test_batched_cached_beam_search(env):
+    """beam_search_batched on the K/V-cache path: hypotheses are well formed, sorted, and their scores are the sums of the
+    teacher-forced log-probabilities of the uncached forward (3e-2 per token); against the uncached search of the same
+    model the best score of every molecule agrees within 0.1 (a bf16 near-tie may legitimately pick another beam)."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd import decode
+    for sep_gap in (0.4, 0.7):          # 0.4: every molecule collects k finals within a few steps; 0.7: runs to max_steps
+        _check_cached_beam_search(O, SPMM, tiny_config, decode, sep_gap)
+
+
+def _check_cached_beam_search(O, SPMM, tiny_config, decode, sep_gap):
+    sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), sep_gap=sep_gap)
+    m = _mk(SPMM, tiny_config(), sd).eval()
+    N, k = 6, 5
+    props = torch.randn(N, 53, generator=torch.Generator().manual_seed(4)) * 2
+    got = decode.beam_search_batched(m, props, k=k, max_steps=14)
+    ref = decode.beam_search_batched(m, props, k=k, max_steps=14, cached=False)
+    pe = decode.encode_properties(m, props)
+    n_hyp = 0
+    for n in range(N):
+        ps = [p for p, _ in got[n]]
+        assert ps == sorted(ps, reverse=True) and len(got[n]) <= k
+        for p, seq in got[n]:
+            n_hyp += 1
+            assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and decode.SEP_ID not in seq[1:-1]
+            text = torch.tensor([seq], device="cuda")
+            logits = m.text_encoder(text, attention_mask=torch.ones_like(text), encoder_hidden_states=pe[n:n + 1],
+                                    encoder_attention_mask=torch.ones(1, pe.shape[1], dtype=torch.long, device="cuda"),
+                                    return_dict=True, is_decoder=True, return_logits=True)
+            lp = torch.log_softmax(logits.float(), -1)[0, :-1].gather(1, text[0, 1:, None]).sum().item()
+            assert abs(lp - p) < 3e-2 * (len(seq) - 1), (n, seq, lp, p)
+        if got[n] and ref[n]:
+            assert abs(got[n][0][0] - ref[n][0][0]) < 0.1, (n, got[n][0], ref[n][0])
+        assert bool(got[n]) == bool(ref[n])
+    assert n_hyp >= N
