@@ -97,9 +97,12 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const float* word, con
  * reference sketches at xbert.py:291-295,480,1344-1348).  Row r, head h: softmax_j(q_r,h . K[s(r,j), j, h] * scale) V[...],
  * j < Lkv <= 256, head_dim 64.  Key/value (s, j) lives at element offset s*seq_stride + j*tok_stride (+ h*64) from K / V.
  * s(r,j) = anc[r*anc_ld + j] (self-attention: beam ancestry table, cache rows are never moved) or r / kv_div when anc is
- * null (cross-attention: the k beams of a molecule share its PV keys/values).  No mask: beams carry no padding. */
+ * null (cross-attention: the k beams of a molecule share its PV keys/values).  `group` (R % group == 0) only steers
+ * placement: rows n*group .. n*group+group-1 are scheduled next to each other because they read mostly the same lines.
+ * No mask: beams carry no padding. */
 int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, const int* anc,
-                     int anc_ld, int kv_div, void* out, long ldo, int R, int nH, int Lkv, float scale, spmm_stream_t stream);
+                     int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv, float scale,
+                     spmm_stream_t stream);
 
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings

@@ -4,9 +4,9 @@
 // reads the PV keys/values computed once per molecule and shared by its k beams.
 //
 // Shape of the work: R rows (molecules x beams) x nH heads, one query each, Lkv <= 256 keys, d = 64.  It is an HBM-bound
-// gather (2 x Lkv x 128 B per row-head), so there is no MFMA here: one wave64 per (row, head); lane j scores key j with a
-// 64-term fp32 dot product (16-B loads), wave-shuffle softmax, then lane d accumulates output dim d over the keys
-// (128-B coalesced V rows).  Beams are never physically reordered: `anc[r, j]` names the cache row that holds position j of
+// gather (2 x Lkv x 128 B per row-head), so there is no MFMA here: one wave64 per (row, head); 8 lanes share a key (each
+// reads 16 B of its 128-B row: whole cache lines per wave instruction), fp32 dot products and softmax with wave shuffles,
+// scores parked in LDS between the two passes over the keys.  Beams are never physically reordered: `anc[r, j]` names the cache row that holds position j of
 // row r's hypothesis (updated by the host-side beam bookkeeping with one small gather per step).
 #include "common.h"
 #include "../../include/spmm_hip.h"
@@ -16,75 +16,101 @@ namespace {
 struct DecAttnP {
   const bf16* q; long ldq;
   const bf16* K; const bf16* V; long seq_stride, tok_stride;
-  const int* anc; int anc_ld; int kv_div;
+  const int* anc; int anc_ld; int kv_div; int group; int nblocks;
   bf16* out; long ldo;
   int R, nH, Lkv; float scale;
 };
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
-  __shared__ float sq[4][64];
+  __shared__ float ssc[4][256];                      // scores of the wave's (row, head), one wave per LDS row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long gw = (long)blockIdx.x * 4 + wave;
-  if (gw >= (long)p.R * p.nH) return;
-  const int r = (int)(gw / p.nH), h = (int)(gw - (long)r * p.nH);
-  sq[wave][lane] = (float)p.q[(long)r * p.ldq + h * 64 + lane] ;
-  __builtin_amdgcn_wave_barrier();
-  // scores: lane owns keys lane, lane+64, lane+128, lane+192
-  float s[4]; long long base[4];
+  // Beams of one molecule share most of their keys/values (all of them in cross-attention), so their waves are placed
+  // together: consecutive logical waves are the `group` beams of one (molecule, head), and consecutive logical blocks go to
+  // the same XCD (blockIdx round-robins over the 8 XCDs), so the shared lines hit in that XCD's L2 / the CU's L1.
+  const int per_xcd = (p.nblocks + 7) >> 3;
+  const long lb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const long gw = lb * 4 + wave;
+  if (lb >= p.nblocks || gw >= (long)p.R * p.nH) return;
+  const int per_mol = p.nH * p.group;
+  const int n = (int)(gw / per_mol), rem = (int)(gw - (long)n * per_mol);
+  const int h = rem / p.group, r = n * p.group + (rem - h * p.group);
+  // 8 lanes share one key: lane (g, c) reads the 16-B chunk c of the head's 128-B K/V row of key 8*i + g, so one wave
+  // instruction covers 8 whole cache lines (a lane-per-key layout touches 64 lines for the same bytes).
+  const int g = lane >> 3, c = lane & 7;
+  float qf[8];
+  {
+    const bf16x8 qv = *(const bf16x8*)(p.q + (long)r * p.ldq + h * 64 + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * p.scale;
+  }
+  const int* anc_row = p.anc ? p.anc + (long)r * p.anc_ld : nullptr;
+  const long own = (long)(r / max(p.kv_div, 1)) * p.seq_stride + h * 64 + c * 8;
+  const int niter = (p.Lkv + 7) >> 3;
   float mx = -INFINITY;
+  for (int i = 0; i < niter; ++i) {
+    const int j = i * 8 + g;
+    float part = 0.f;
+    if (j < p.Lkv) {
+      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * 64 + c * 8 : own) + (long)j * p.tok_stride;
+      const bf16x8 kv = *(const bf16x8*)(p.K + off);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int j = lane + 64 * c;
-    s[c] = -INFINITY; base[c] = 0;
-    if (c * 64 < p.Lkv && j < p.Lkv) {
-      const long seq = p.anc ? (long)p.anc[(long)r * p.anc_ld + j] : (long)(r / p.kv_div);
-      base[c] = seq * p.seq_stride + (long)j * p.tok_stride + h * 64;
-      const bf16* kp = p.K + base[c];
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < 64; d += 8) {
-        const bf16x8 kv = *(const bf16x8*)(kp + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += (float)kv[e] * sq[wave][d + e];
-      }
-      s[c] = acc * p.scale;
-      mx = fmaxf(mx, s[c]);
+      for (int e = 0; e < 8; ++e) part += (float)kv[e] * qf[e];
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (j < p.Lkv) {
+      if (c == 0) ssc[wave][j] = part;
+      mx = fmaxf(mx, part);
     }
   }
   mx = wave_max(mx);
-  float e[4], sum = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sum = 0.f;
+  for (int i = 0; i < niter; ++i) {
+    const int j = i * 8 + g;
+    if (j < p.Lkv) {
+      const float e = __expf(ssc[wave][j] - mx);
+      sum += e;
+      const float pe = (float)(bf16)e;               // the tiled training kernel feeds bf16 probabilities to the PV MFMA
+      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * 64 + c * 8 : own) + (long)j * p.tok_stride;
+      const bf16x8 vv = *(const bf16x8*)(p.V + off);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    e[c] = (s[c] == -INFINITY) ? 0.f : __expf(s[c] - mx);
-    sum += e[c];
-    e[c] = (float)(bf16)e[c];          // the tiled training kernel feeds bf16 probabilities to the PV MFMA; keep the same rounding
-  }
-  sum = wave_sum(sum);
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int n = min(64, p.Lkv - 64 * c);
-    for (int jj = 0; jj < n; ++jj) {
-      const float pj = __shfl(e[c], jj, 64);
-      const long long b = __shfl(base[c], jj, 64);
-      acc += pj * (float)p.V[b + lane];
+      for (int d = 0; d < 8; ++d) acc[d] += pe * (float)vv[d];
     }
   }
-  p.out[(long)r * p.ldo + h * 64 + lane] = (bf16)(acc / sum);
+  // combine the 8 key slots (lanes with equal c): xor 8, 16, 32
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] += __shfl_xor(acc[d], o, 64);
+  }
+  if (g == 0) {
+    const float inv = 1.f / sum;
+    bf16x8 o;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = (bf16)(acc[d] * inv);
+    *(bf16x8*)(p.out + (long)r * p.ldo + h * 64 + c * 8) = o;
+  }
 }
 
 }  // namespace
 
 extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride,
-                                const int* anc, int anc_ld, int kv_div, void* out, long ldo, int R, int nH, int Lkv, float scale,
-                                hipStream_t stream) {
+                                const int* anc, int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv,
+                                float scale, hipStream_t stream) {
   SPMM_CHECK_SHAPE(R > 0 && nH > 0 && Lkv > 0 && Lkv <= 256, "spmm_decode_attn: R=%d nH=%d Lkv=%d (Lkv <= 256)", R, nH, Lkv);
   SPMM_CHECK_SHAPE((anc != nullptr && anc_ld >= Lkv) || (anc == nullptr && kv_div > 0), "spmm_decode_attn: anc_ld=%d kv_div=%d", anc_ld, kv_div);
-  SPMM_CHECK_SHAPE(seq_stride % 8 == 0 && tok_stride % 8 == 0 && ldq >= (long)nH * 64 && ldo >= (long)nH * 64,
+  SPMM_CHECK_SHAPE(seq_stride % 8 == 0 && tok_stride % 8 == 0 && ldq >= (long)nH * 64 && ldo >= (long)nH * 64 && ldq % 8 == 0 && ldo % 8 == 0,
                    "spmm_decode_attn: strides must keep 16-B alignment (seq %ld tok %ld)", seq_stride, tok_stride);
-  DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, anc, anc_ld, kv_div, (bf16*)out, ldo, R, nH, Lkv, scale};
+  SPMM_CHECK_SHAPE(group > 0 && R % group == 0, "spmm_decode_attn: R=%d must be a multiple of group=%d", R, group);
   const long waves = (long)R * nH;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+  const int nblocks = (int)((waves + 3) / 4);
+  DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, anc, anc_ld, kv_div, group, nblocks,
+                (bf16*)out, ldo, R, nH, Lkv, scale};
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
   SPMM_LAUNCH_CHECK("spmm_decode_attn");
   return SPMM_OK;
 }

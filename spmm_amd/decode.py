@@ -215,14 +215,14 @@ class CachedDecoder:
             self.kc[l][:, t].copy_(QKV[:, H:2 * H])
             self.vc[l][:, t].copy_(QKV[:, 2 * H:])
             ctx = self._new(R, H)
-            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=t + 1, seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc)
+            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=t + 1, seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k)
             a = self._attn_out(pf, ctx, x)
             if l >= c.fusion_layer:
                 pf = lp + "crossattention."
                 q = self._new(R, H)
                 ops.gemm_nt(a, P.wb(pf + "self.query.weight"), q, bias=P.w(pf + "self.query.bias"))
                 KV = self.xkv[l]
-                ops.decode_attn(q, KV[:, :H], KV[:, H:], ctx, nH=nH, Lkv=self.Lp, seq_stride=self.Lp * 2 * H, tok_stride=2 * H, kv_div=self.k)
+                ops.decode_attn(q, KV[:, :H], KV[:, H:], ctx, nH=nH, Lkv=self.Lp, seq_stride=self.Lp * 2 * H, tok_stride=2 * H, kv_div=self.k, group=self.k)
                 a = self._attn_out(pf, ctx, a)
             h = self._new(R, c.intermediate_size)
             ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"), epi=ops.EPI_GELU)

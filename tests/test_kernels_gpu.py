@@ -664,8 +664,9 @@ def test_adamw_clip_ema_match_torch(ops):
     assert torch.equal(shadow, pm.to(BF))
 
 
-@pytest.mark.parametrize("R,nH,Lkv,Lmax,kv_div", [(10, 2, 1, 16, 0), (15, 12, 37, 64, 0), (20, 12, 54, 54, 5), (64, 4, 130, 160, 0), (6, 2, 256, 256, 3)])
-def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div):
+@pytest.mark.parametrize("R,nH,Lkv,Lmax,kv_div,group", [(10, 2, 1, 16, 0, 1), (15, 12, 37, 64, 0, 5), (20, 12, 54, 54, 5, 5), (64, 4, 130, 160, 0, 4),
+                                                    (6, 2, 256, 256, 3, 3), (35, 12, 9, 16, 0, 7)])
+def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group):
     """Single-query attention against a cache addressed through the beam ancestry table (kv_div == 0) or shared per molecule
     (kv_div > 0), vs fp32 torch on the same bf16 inputs (xbert.py:305-354 for the last position)."""
     H = nH * 64
@@ -678,7 +679,7 @@ def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div):
     Vc = cache[:, :, H:] if kv_div else torch.randn(nseq, Lmax, H, generator=g).to(BF).cuda()
     anc = None if kv_div else torch.randint(0, R, (R, Lmax), generator=g).to(torch.int32).cuda()
     out = torch.zeros(R, H, dtype=BF, device="cuda")
-    ops.decode_attn(q[:, :H], Kc, Vc, out, nH=nH, Lkv=Lkv, seq_stride=Lmax * wide, tok_stride=wide, anc=anc, kv_div=max(kv_div, 1))
+    ops.decode_attn(q[:, :H], Kc, Vc, out, nH=nH, Lkv=Lkv, seq_stride=Lmax * wide, tok_stride=wide, anc=anc, kv_div=max(kv_div, 1), group=group)
     j = torch.arange(Lkv, device="cuda")
     seq = anc[:, :Lkv].long() if kv_div == 0 else (torch.arange(R, device="cuda") // kv_div)[:, None].expand(R, Lkv)
     K = Kc.float()[seq, j[None, :]].view(R, Lkv, nH, 64)
