@@ -139,7 +139,7 @@ def main():
     model.train(not args.eval_mode)
     B, Lt = args.batch, args.seq_len
     batches = [synthetic_batch(B, Lt, 42 + 1000 * rank + i, dev) for i in range(4)]
-    sync = grad_sync_fn()
+    sync = grad_sync_fn(model.store)
 
     def one_step(i):
         prop, ids, mask = batches[i % len(batches)]

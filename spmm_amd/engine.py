@@ -64,6 +64,7 @@ class Engine:
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)
         self.train_mode = True
+        self.layer_done_cb = None
         self._salt = 0
         self.tape = None
         E, Q = cfg.embed_dim, cfg.queue_size
@@ -241,6 +242,8 @@ class Engine:
     def stack_bwd(self, pfx, c, layers, tape, dY, groups, dkv_acc=None):
         for i, sv in zip(reversed(list(layers)), reversed(tape)):
             dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
+            if self.layer_done_cb is not None:           # this layer's gradients are final: data-parallel reduce may start
+                self.layer_done_cb(f"{pfx}encoder.layer.{i}.")
         return dY
 
     # --------------------------------------------------------------------------------------------- embeddings

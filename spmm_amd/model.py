@@ -103,6 +103,7 @@ class SPMM(nn.Module):
         self.device_ = torch.device(device)
         self.cfg = spmm_config if spmm_config is not None else SPMMConfig.from_reference_dict(config)
         self.no_train = no_train
+        self._grad_sync = None
         self.store = ParamStore(self.cfg, self.device_, train=not no_train)
         self.engine = PretrainStep(self.cfg, self.store, self.device_)
         self._param_names = []
@@ -264,9 +265,18 @@ class SPMM(nn.Module):
         self.store.grad.zero_()
         dev = self.device_
         losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn())
-        eng.backward()
-        if grad_sync is not None:
-            grad_sync(self.store.grad)
+        if hasattr(grad_sync, "layer_done"):             # overlapped: slices are reduced as their layers finish backward
+            grad_sync.begin(self.store.grad)
+            eng.layer_done_cb = grad_sync.layer_done
+            try:
+                eng.backward()
+            finally:
+                eng.layer_done_cb = None
+            grad_sync.finish()
+        else:
+            eng.backward()
+            if grad_sync is not None:
+                grad_sync(self.store.grad)
         opt.step()
         return losses
 
@@ -281,7 +291,9 @@ class SPMM(nn.Module):
         alpha = self.config["alpha"] if self.current_epoch > 0 else self.config["alpha"] * min(1., batch_idx / self.loader_len)
         opt, sch = self.optimizers(), self.lr_schedulers()
         from .parallel import grad_sync_fn
-        losses = self.fused_step(prop, ids, mask, alpha, grad_sync=grad_sync_fn())
+        if self._grad_sync is None:
+            self._grad_sync = grad_sync_fn(self.store) or False
+        losses = self.fused_step(prop, ids, mask, alpha, grad_sync=self._grad_sync or None)
         if self.global_rank == 0:
             self.logged = {"lr": opt.param_groups[0]["lr"], "losses": losses}
         step_size, warm = 100, self.warmup_steps

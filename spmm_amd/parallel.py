@@ -10,6 +10,8 @@ Buffers are NOT broadcast every step (DDP's broadcast_buffers, C3 in SURVEY.md):
 every rank enqueues the same gathered features; `assert_replicas_identical` checks that."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -47,8 +49,67 @@ def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = BUCKET_ELEMS) -> tor
     return flat
 
 
-def grad_sync_fn():
-    return allreduce_mean_ if world() > 1 else None
+class OverlappedGradSync:
+    """C2 overlapped with backward (what DDP's bucketed hooks do for the reference, SPMM_pretrain.py:36).
+
+    Every encoder layer's gradients are final the moment its backward returns -- each parameter range is written by exactly
+    one backward stage (text layers f..n-1 by S6, 0..f-1 by S2, the PV encoder by S1; spmm_amd/step.py) -- and a layer's
+    tensors are contiguous in the flat arena, so `layer_done(prefix)` launches one asynchronous all-reduce over that slice
+    (28-38 MB fp32: long messages for the point-to-point xGMI links).  RCCL runs it on its own stream behind an event on the
+    compute stream while the next layers' backward kernels keep the CUs busy.  `finish()` reduces what no layer covered
+    (embeddings, heads, projections: ~2 % of the bytes) and joins the streams before the optimiser."""
+
+    def __init__(self, order, offset, total):
+        self.total = int(total)
+        names = list(order)
+        ends = [offset[n] for n in names[1:]] + [self.total]
+        self._ranges = {}
+        import re
+        for n, e in zip(names, ends):
+            m = re.match(r"(.*encoder\.layer\.\d+\.)", n)
+            if not m:
+                continue
+            lo, hi = self._ranges.get(m.group(1), (offset[n], offset[n]))
+            if offset[n] != hi:
+                raise ValueError(f"parameters of {m.group(1)} are not contiguous in the flat arena")
+            self._ranges[m.group(1)] = (lo, e)
+        self._grad, self._work, self._done = None, [], []
+
+    def begin(self, grad: torch.Tensor):
+        assert grad.numel() == self.total
+        self._grad, self._work, self._done = grad, [], []
+        self._avg = dist.get_backend() == "nccl"
+
+    def _reduce(self, lo, hi):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._work.append(dist.all_reduce(self._grad[lo:hi], op=op, async_op=True))
+        self._done.append((lo, hi))
+
+    def layer_done(self, prefix: str):
+        if self._grad is None or prefix not in self._ranges:
+            return
+        self._reduce(*self._ranges[prefix])
+
+    def finish(self):
+        pos = 0
+        for lo, hi in sorted(self._done) + [(self.total, self.total)]:
+            for a in range(pos, lo, BUCKET_ELEMS):
+                self._reduce(a, min(lo, a + BUCKET_ELEMS))
+            pos = max(pos, hi)
+        for w in self._work:
+            w.wait()
+        if not self._avg:
+            self._grad.div_(world())
+        self._grad, self._work = None, []
+
+
+def grad_sync_fn(store=None):
+    """None on a single rank; otherwise the overlapped reducer when the parameter layout is given, else the plain bucketed one."""
+    if world() == 1:
+        return None
+    if store is not None and os.environ.get("SPMM_GRAD_OVERLAP", "1") != "0":
+        return OverlappedGradSync(store.order, store.offset, store.total)
+    return allreduce_mean_
 
 
 def broadcast_state_(tensors, src: int = 0):

@@ -72,3 +72,57 @@ def test_two_rank_gather_and_grad_average():
     cfg = O.tiny_cfg()
     init = O.closed_form_state_dict(cfg)["prop_queue"]
     assert not torch.allclose(queue[:, :8], init[:, :8]) and torch.equal(queue[:, 8:], init[:, 8:])
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPMM_DRY_RUN="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spmm_amd import parallel
+    from spmm_amd.config import tiny_config, state_spec
+    from spmm_amd.params import _layout_order, ALIGN
+    import math
+    cfg = tiny_config()
+    spec = state_spec(cfg)
+    order = _layout_order(spec)
+    shape = {n: s for n, s, _ in spec}
+    offset, off = {}, 0
+    for n in order:                                    # the arithmetic of ParamStore.__init__ (needs no device)
+        offset[n] = off
+        off += ((int(math.prod(shape[n])) if shape[n] else 1) + ALIGN - 1) // ALIGN * ALIGN
+    sync = parallel.OverlappedGradSync(order, offset, off)
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(off, generator=g)
+    local = grad.clone()
+    sync.begin(grad)
+    nt, npv, f = cfg.text.num_hidden_layers, cfg.prop.num_hidden_layers, cfg.text.fusion_layer
+    called = []
+    for pfx, layers in (("text_encoder.bert.", range(nt - 1, f - 1, -1)), ("text_encoder.bert.", range(f - 1, -1, -1)),
+                        ("property_encoder.", range(npv - 1, -1, -1))):      # the order backward finishes layers in
+        for i in layers:
+            sync.layer_done(f"{pfx}encoder.layer.{i}.")
+            called.append(f"{pfx}encoder.layer.{i}.")
+    covered = sum(hi - lo for lo, hi in sync._done)
+    sync.layer_done("text_encoder_m.bert.encoder.layer.0.")                   # unknown prefixes are ignored
+    sync.finish()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    if rank == 0:
+        q.put((grad.numpy(), torch.stack(gathered).mean(0).numpy(), covered, off, len(called)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_grad_sync_two_ranks():
+    """Per-layer asynchronous all-reduces + the final sweep over what no layer covered average the whole arena exactly once."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, want, covered, total, nl = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.allclose(torch.from_numpy(got), torch.from_numpy(want), atol=1e-7)
+    assert 0.5 * total < covered < total and nl >= 3          # layers carry most of the bytes, the sweep the rest
