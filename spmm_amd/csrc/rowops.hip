@@ -123,116 +123,142 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // dz = rstd * (dy*g - mean_H(dy*g) - xhat * mean_H(dy*g*xhat));  dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
 // dx (optional) = dropout-mask(dz).  Per-column partial sums are kept in registers over the block's rows,
 // combined through LDS and flushed with one atomicAdd per column per block.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2,
+// NC = 8-byte chunks per lane (3 covers H <= 768, 4 covers H <= 1024).  The raw bf16 rows of the NEXT iteration are
+// requested before the current row is reduced, so the wave always has loads in flight (the kernel is pure HBM streaming:
+// 2-3 rows in, 1-2 rows out per row).
+template <int NC>
+struct RawRow { bf16x4 v[NC]; };
+
+template <int NC>
+__device__ __forceinline__ void load_raw(const bf16* __restrict__ p, int H, int lane, RawRow<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) r.v[i] = *(const bf16x4*)(p + c);
+    else r.v[i] = to_bf16x4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2,
                                                      const bf16* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
                                                      bf16* __restrict__ dz_o, bf16* __restrict__ dx_o,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H,
                                                      uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt,
                                                      int drop_on_dy, float* __restrict__ dxsum) {
-  __shared__ float red[3][4][MAXC * 256];
+  __shared__ float red[4][NC * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  RowVec gsum, bsum, xsum;       // xsum: column sums of dx = bias gradient of the dense layer that produced x
+  float gsum[NC][4], bsum[NC][4], xsum[NC][4];   // xsum: column sums of dx = bias gradient of the dense layer that produced x
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gsum.v[i][j] = bsum.v[i][j] = xsum.v[i][j] = 0.f;
-  RowVec gm;
-  load_row_f32(gamma, H, lane, gm);
+    for (int j = 0; j < 4; ++j) gsum[i][j] = bsum[i][j] = xsum[i][j] = 0.f;
   const uint64_t seed = thresh16 ? (*seed_ptr ^ salt) : 0;
-  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-    RowVec g, zz, o;
-    load_row_bf16(dy + row * H, H, lane, g);
-    if (dy2) {
-      load_row_bf16(dy2 + row * H, H, lane, o);
-#pragma unroll
-      for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g.v[i][j] += o.v[i][j];
+  const long stride = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  RawRow<NC> ng, ng2, nz;
+  float nmean = 0.f, nrstd = 0.f;
+  if (row < rows) {
+    load_raw<NC>(dy + row * H, H, lane, ng);
+    if (dy2) load_raw<NC>(dy2 + row * H, H, lane, ng2);
+    load_raw<NC>(z + row * H, H, lane, nz);
+    nmean = mean_i[row]; nrstd = rstd_i[row];
+  }
+  for (; row < rows; row += stride) {
+    RawRow<NC> cg = ng, cg2 = ng2, cz = nz;
+    const float mean = nmean, rstd = nrstd;
+    const long nrow = row + stride;
+    if (nrow < rows) {
+      load_raw<NC>(dy + nrow * H, H, lane, ng);
+      if (dy2) load_raw<NC>(dy2 + nrow * H, H, lane, ng2);
+      load_raw<NC>(z + nrow * H, H, lane, nz);
+      nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
     }
+    float g[NC][4], xh[NC][4];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[i][j] = (float)cg.v[i][j] + (dy2 ? (float)cg2.v[i][j] : 0.f);
     if (thresh16 && drop_on_dy) {   // y_out = dropout(LN(z)) (BertEmbeddings): mask the incoming gradient
 #pragma unroll
-      for (int i = 0; i < MAXC; ++i) {
+      for (int i = 0; i < NC; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < H) {
           bool k[4];
           drop_keep4(seed, (uint64_t)row * H + c, thresh16, k);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g.v[i][j] = k[j] ? g.v[i][j] * dscale : 0.f;
+          for (int j = 0; j < 4; ++j) g[i][j] = k[j] ? g[i][j] * dscale : 0.f;
         }
       }
     }
-    load_row_bf16(z + row * H, H, lane, zz);
-    const float mean = mean_i[row], rstd = rstd_i[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
+        const f32x4 gm = *(const f32x4*)(gamma + c);      // L1-resident; keeping it in registers costs occupancy
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float xh = (zz.v[i][j] - mean) * rstd;
-          const float dg = g.v[i][j] * gm.v[i][j];
-          gsum.v[i][j] += g.v[i][j] * xh;
-          bsum.v[i][j] += g.v[i][j];
-          zz.v[i][j] = xh;
-          g.v[i][j] = dg;
+          const float x = ((float)cz.v[i][j] - mean) * rstd;
+          const float dg = g[i][j] * gm[j];
+          gsum[i][j] += g[i][j] * x;
+          bsum[i][j] += g[i][j];
+          xh[i][j] = x;
+          g[i][j] = dg;
           s1 += dg;
-          s2 += dg * xh;
+          s2 += dg * x;
         }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
       }
     }
     s1 = wave_sum(s1) / H;
     s2 = wave_sum(s2) / H;
+    const bool mask_dx = dx_o && thresh16 && !drop_on_dy;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o.v[i][j] = rstd * (g.v[i][j] - s1 - zz.v[i][j] * s2);
-    store_row_bf16(dz_o + row * H, H, lane, o);
-    if (dxsum && !(dx_o && thresh16 && !drop_on_dy)) {
-#pragma unroll
-      for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xsum.v[i][j] += (float)(bf16)o.v[i][j];
-    }
-    if (dx_o) {
-      if (thresh16 && !drop_on_dy) {
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-          const int c = (lane + 64 * i) * 4;
-          if (c < H) {
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        const bf16x4 ob = to_bf16x4(o[0], o[1], o[2], o[3]);
+        *(bf16x4*)(dz_o + row * H + c) = ob;
+        if (dx_o) {
+          bf16x4 xb = ob;
+          if (mask_dx) {
             bool k[4];
             drop_keep4(seed, (uint64_t)row * H + c, thresh16, k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o.v[i][j] = k[j] ? o.v[i][j] * dscale : 0.f;
+            xb = to_bf16x4(k[0] ? o[0] * dscale : 0.f, k[1] ? o[1] * dscale : 0.f, k[2] ? o[2] * dscale : 0.f, k[3] ? o[3] * dscale : 0.f);
           }
+          *(bf16x4*)(dx_o + row * H + c) = xb;
+          if (dxsum) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xsum[i][j] += (float)xb[j];
+          }
+        } else if (dxsum) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xsum[i][j] += (float)ob[j];
         }
-      }
-      store_row_bf16(dx_o + row * H, H, lane, o);
-      if (dxsum && thresh16 && !drop_on_dy) {
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xsum.v[i][j] += (float)(bf16)o.v[i][j];
       }
     }
   }
   if (dgamma == nullptr && dxsum == nullptr) return;
+  // three block reductions through one LDS buffer: dgamma, dbeta, dxsum
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int which = 0; which < 3; ++which) {
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dxsum;
+    if (dst == nullptr) continue;
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[0][wave][(lane + 64 * i) * 4 + j] = gsum.v[i][j];
-      red[1][wave][(lane + 64 * i) * 4 + j] = bsum.v[i][j];
-      red[2][wave][(lane + 64 * i) * 4 + j] = xsum.v[i][j];
-    }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    if (dgamma) {
-      atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-      atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-    }
-    if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        red[wave][(lane + 64 * i) * 4 + j] = which == 0 ? gsum[i][j] : which == 1 ? bsum[i][j] : xsum[i][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
   }
 }
 
@@ -510,10 +536,15 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_bwd: rows=%ld H=%d", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
-                     gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, (uint32_t)(dropout_p * 65536.f + 0.5f),
-                     1.f / (1.f - dropout_p), seed_ptr, salt, drop_on_dy, dxsum);
+  if (g > 2048) g = 2048;
+  const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
+  const float ds = 1.f / (1.f - dropout_p);
+  if (H <= 768)
+    hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
+                       gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
+                       gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum);
   SPMM_LAUNCH_CHECK("spmm_ln_bwd");
   return SPMM_OK;
 }
