@@ -67,14 +67,21 @@ void spmm_gemm_set_variant(int v);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.
  * Replaces BertSelfAttention.forward xbert.py:305-354 incl. the additive masks of :889-948 (self: 0/-10000, causal
- * for sequences >= causal_from) and invert_attention_mask :1038-1043 (cross: 0/finfo.min, is_cross=1). */
-int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask, void* O,
-                  long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross, float dropout_p,
-                  const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+ * for sequences >= causal_from) and invert_attention_mask :1038-1043 (cross: 0/finfo.min, is_cross=1).
+ * kv_seq (optional, [nseq]): query sequence s reads the keys/values of sequence kv_seq[s] -- the passes of SPMM.forward
+ * that cross-attend to the same encoder_hidden_states (SPMM_models.py:139-150,181-199,224-231,245-250) share one K/V
+ * projection instead of four.  kmask stays per query sequence; dK/dV are written per query sequence. */
+int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
+                  const int* kv_seq, void* O, long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from,
+                  int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
 int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
-                  const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ, long lddq, void* dK,
-                  long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross,
-                  float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+                  const int* kv_seq, const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ,
+                  long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from,
+                  int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+/* out[u] = sum over k in [start[u], start[u+1]) of src[list[k]]  (rows of W bf16 elements, fp32 accumulation, fixed order).
+ * Folds the per-query-sequence dK/dV of a cross-attention whose sequences share key/value sources (kv_seq) back onto the
+ * unique sources before the K/V weight- and data-gradient GEMMs. */
+int spmm_segment_sum_bf16(const void* src, const int* start, const int* list, void* out, int U, long W, spmm_stream_t stream);
 
 /* y = LayerNorm(dropout(x) + res): BertSelfOutput xbert.py:369-373, BertOutput :447-451, transform LN :675,
  * property_mtr_head LN SPMM_models.py:41.  zout (may alias x) keeps the pre-norm sum for backward. */

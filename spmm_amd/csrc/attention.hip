@@ -31,6 +31,7 @@ struct AttnP {
   const bf16* K; long ldk;
   const bf16* V; long ldv;
   const int* kmask;               // [nseq, Lkv] 1 = attend, or null (all ones)
+  const int* kv_seq;              // [nseq] key/value sequence read by query sequence s (null: s itself); dK/dV stay per query sequence
   bf16* O; long ldo;              // fwd output (unused by backward)
   float* LSE;                     // [nseq, nH, Lq]
   const bf16* dO; long lddo;
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
   const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
-  const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
-  const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
+  const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
+  const bf16* Kg = p.K + kvs * p.Lkv * p.ldk + h * HD;
+  const bf16* Vg = p.V + kvs * p.Lkv * p.ldv + h * HD;
   stage_head(Kg, p.ldk, p.Lkv, Ks, tid, nthreads);
   stage_head(Vg, p.ldv, p.Lkv, Vs, tid, nthreads);
   for (int j = tid; j < 128; j += nthreads)
@@ -221,8 +223,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
   const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
-  const bf16* Kg = p.K + (long)seq * p.Lkv * p.ldk + h * HD;
-  const bf16* Vg = p.V + (long)seq * p.Lkv * p.ldv + h * HD;
+  const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
+  const bf16* Kg = p.K + kvs * p.Lkv * p.ldk + h * HD;
+  const bf16* Vg = p.V + kvs * p.Lkv * p.ldv + h * HD;
   const bf16* dOg = p.dO + (long)seq * p.Lq * p.lddo + h * HD;
   stage_head(Kg, p.ldk, p.Lkv, Ks, tid, 256);
   stage_head(Vg, p.ldv, p.Lkv, Vs, tid, 256);
@@ -387,15 +390,15 @@ int check_common(const char* name, int nseq, int nH, int Lq, int Lkv, long ldq, 
 // head_dim is fixed at 64 (config_bert.json: 768 / 12).  Tensors are token-major: row = seq*L + pos, head h at
 // columns [h*64, h*64+64) of the given base pointer.
 extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
-                             const int* kmask, void* O, long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv,
-                             int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
+                             const int* kmask, const int* kv_seq, void* O, long ldo, float* LSE, int nseq, int nH, int Lq,
+                             int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
                              uint64_t seed_salt, hipStream_t stream) {
   int rc = check_common("spmm_attn_fwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
   if (rc) return rc;
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_fwd: dropout needs a device seed");
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
-  p.kmask = kmask; p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
+  p.kmask = kmask; p.kv_seq = kv_seq; p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
   p.causal_from = is_cross ? nseq : causal_from;
   p.mask_neg = is_cross ? -3.4028234663852886e38f : -10000.f;
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
@@ -415,8 +418,8 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
 }
 
 extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
-                             const int* kmask, const void* O, long ldo, const float* LSE, const void* dO, long lddo,
-                             void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq,
+                             const int* kmask, const int* kv_seq, const void* O, long ldo, const float* LSE, const void* dO,
+                             long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq,
                              int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
                              uint64_t seed_salt, hipStream_t stream) {
   int rc = check_common("spmm_attn_bwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
@@ -437,7 +440,7 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   }
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
-  p.kmask = kmask; p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
+  p.kmask = kmask; p.kv_seq = kv_seq; p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
   p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
   p.causal_from = is_cross ? nseq : causal_from;

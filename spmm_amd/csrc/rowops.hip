@@ -591,6 +591,34 @@ extern "C" int spmm_embed_bwd(int mode, const void* dz, const int* ids, const fl
   return SPMM_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void segment_sum_kernel(const bf16* __restrict__ src, const int* __restrict__ start,
+                                                          const int* __restrict__ list, bf16* __restrict__ out, long W) {
+  const int u = blockIdx.y;
+  const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= W) return;
+  const int k0 = start[u], k1 = start[u + 1];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = k0; k < k1; ++k) {
+    const bf16x8 v = *(const bf16x8*)(src + (long)list[k] * W + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+  *(bf16x8*)(out + (long)u * W + c) = o;
+}
+}  // namespace
+
+extern "C" int spmm_segment_sum_bf16(const void* src, const int* start, const int* list, void* out, int U, long W, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(U > 0 && U <= 65535 && W > 0 && W % 8 == 0, "spmm_segment_sum_bf16: U=%d W=%ld (W %% 8 == 0)", U, W);
+  hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((W / 8 + 255) / 256), U), dim3(256), 0, stream, (const bf16*)src, start, list,
+                     (bf16*)out, W);
+  SPMM_LAUNCH_CHECK("spmm_segment_sum_bf16");
+  return SPMM_OK;
+}
+
 extern "C" int spmm_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, int Rpad, float* colsum,
                                    hipStream_t stream) {
   SPMM_CHECK_SHAPE(R > 0 && C > 0 && Rpad >= R && ldo >= Rpad, "spmm_transpose_bf16: R=%d C=%d Rpad=%d ldo=%ld", R, C, Rpad, ldo);

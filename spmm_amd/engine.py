@@ -44,10 +44,23 @@ class Group:
     kv: Optional[torch.Tensor] = None      # cross-attention source, bf16 [nseq*Lkv, H]
     Lkv: int = 0
     kv_mask: Optional[torch.Tensor] = None
+    kv_idx: Optional[torch.Tensor] = None  # int32 [nseq]: query sequence s attends kv sequence kv_idx[s] (kv holds the unique ones)
+    kv_start: Optional[torch.Tensor] = None   # CSR inverse of kv_idx: query sequences of unique source u are
+    kv_list: Optional[torch.Tensor] = None    # kv_list[kv_start[u] : kv_start[u+1]]
+    kv_unique: int = 0
 
     @property
     def rows(self):
         return slice(self.row0, self.row0 + self.nseq * self.L)
+
+    def share_kv(self, idx: torch.Tensor, n_unique: int) -> "Group":
+        """kv holds n_unique sequences; idx[s] (int64 [nseq], device) names the one query sequence s cross-attends to."""
+        order = torch.sort(idx, stable=True).indices
+        counts = torch.bincount(idx, minlength=n_unique)
+        start = torch.zeros(n_unique + 1, dtype=torch.int32, device=idx.device)
+        start[1:] = torch.cumsum(counts, 0)
+        self.kv_idx, self.kv_start, self.kv_list, self.kv_unique = idx.to(torch.int32), start, order.to(torch.int32), n_unique
+        return self
 
 
 class Engine:
@@ -124,13 +137,13 @@ class Engine:
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
             for g in groups:
-                KV = self._new(g.nseq * g.Lkv, 2 * H)
+                KV = self._new(g.kv.shape[0], 2 * H)             # one row per key/value token of the (unique) sources
                 ops.gemm_nt(g.kv, Wkv, KV, bias=bkv)
                 lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
                 salt = self._next_salt()
                 r = g.rows
                 ops.attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
-                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt)
+                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt, kv_seq=g.kv_idx)
                 sv["KV"].append(KV)
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
@@ -184,7 +197,10 @@ class Engine:
                 dKV = self._new(g.nseq * g.Lkv, 2 * H)
                 ops.attn_bwd(Qc[r], KV[:, :H], KV[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQc[r], dKV[:, :H], dKV[:, H:],
                              nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask, is_cross=True, dropout_p=pa, seed=self.seed,
-                             salt=sv["salt_a"][i])
+                             salt=sv["salt_a"][i], kv_seq=g.kv_idx)
+                if g.kv_idx is not None:                         # fold the per-query-sequence dK/dV onto the unique sources
+                    W = g.Lkv * 2 * H
+                    dKV = ops.segment_sum_bf16(dKV.view(g.nseq, W), g.kv_start, g.kv_list, self._new(g.kv_unique, W)).view(-1, 2 * H)
                 self._wgrad(dKV, g.kv, gWkv, gbkv)
                 ops.gemm_nt(dKV, WkvT, dkv_acc[i], epi=ops.EPI_F32_ACC)
             self._wgrad(dQc, X, P.g(pfx + ".self.query.weight"), P.g(pfx + ".self.query.bias"))

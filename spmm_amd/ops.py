@@ -80,18 +80,18 @@ def colsum_bf16(x, out):
 
 
 def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
-             seed=None, salt=0):
+             seed=None, salt=0, kv_seq=None):
     """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]."""
     cf = nseq if causal_from is None else causal_from
-    _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
+    _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(O),
                _row_stride(O), _p(lse), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
     return O
 
 
 def attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False,
-             dropout_p=0.0, seed=None, salt=0):
+             dropout_p=0.0, seed=None, salt=0, kv_seq=None):
     cf = nseq if causal_from is None else causal_from
-    _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(O),
+    _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(O),
                _row_stride(O), _p(lse), _p(dO), _row_stride(dO), _p(dQ), _row_stride(dQ), _p(dK), _row_stride(dK), _p(dV),
                _row_stride(dV), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
 
@@ -264,4 +264,13 @@ def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_d
     assert anc is None or (anc.dtype == torch.int32 and anc.shape[0] == R)
     _call("spmm_decode_attn", _p(q), _row_stride(q), _p(K), _p(V), int(seq_stride), int(tok_stride), _p(anc),
           0 if anc is None else _row_stride(anc), int(kv_div), int(group), _p(out), _row_stride(out), R, nH, Lkv, float(scale), _st())
+    return out
+
+
+def segment_sum_bf16(src, start, lst, out):
+    """out[u] = sum_{k in [start[u], start[u+1])} src[list[k]] over rows of W bf16 elements (fp32 accumulation)."""
+    U, W = out.shape
+    assert src.dtype == BF16 and out.dtype == BF16 and src.shape[1] == W and src.is_contiguous() and out.is_contiguous()
+    assert start.dtype == torch.int32 and lst.dtype == torch.int32 and start.numel() == U + 1
+    _call("spmm_segment_sum_bf16", _p(src), _p(start), _p(lst), _p(out), U, W, _st())
     return out

@@ -99,12 +99,16 @@ class PretrainStep(Engine):
         mask_neg = mask32.index_select(0, neg[B:])
         qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
         qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
-        kv_qpv = torch.cat([te, te, te_neg, te]).view(4 * B * Lt, H)
+        # Cross-attention sources: the four PV-query passes read [te, te, te[neg], te], the four text-query passes
+        # [pe, pe[neg], pe, pe] -- B unique sequences each.  The K/V projections (and their weight/data gradients) run once
+        # on the unique rows; the attention kernels follow `kv_idx` (same numbers as projecting every copy, a quarter of the work).
+        ar = torch.arange(B, dtype=torch.int64, device=self.dev)
+        idx_qpv = torch.cat([ar, ar, neg[B:], ar])
+        idx_qtext = torch.cat([ar, neg[:B], ar, ar])
         kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
-        kv_qtext = torch.cat([pe, pe_neg, pe, pe]).view(4 * B * Lp, H)
         X6 = torch.cat([qpv, qtext])
-        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv=kv_qpv, Lkv=Lt, kv_mask=kvmask_qpv),
-              Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B, kv=kv_qtext, Lkv=Lp, kv_mask=None)]
+        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv=text_embeds.view(B * Lt, H), Lkv=Lt, kv_mask=kvmask_qpv).share_kv(idx_qpv, B),
+              Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B, kv=prop_embeds.view(B * Lp, H), Lkv=Lp, kv_mask=None).share_kv(idx_qtext, B)]
         y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save)
         ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
 
@@ -193,24 +197,19 @@ class PretrainStep(Engine):
                      slot=LOSS_ITM, dxa=dYpv, dxb=dYtext, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
 
         # ---- S6 backward
-        dkv_text = self._zeros(4 * B * Lt, H, dtype=torch.float32)
-        dkv_prop = self._zeros(4 * B * Lp, H, dtype=torch.float32)
-        dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"], dkv_acc=[dkv_text, dkv_prop])
+        d_pe = self._zeros(B, Lp * H, dtype=torch.float32)          # hub gradients of prop_embeds / text_embeds (fp32)
+        d_te = self._zeros(B, Lt * H, dtype=torch.float32)
+        # the cross-attention K/V data gradients land directly on the unique sources (Group.share_kv)
+        dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"],
+                             dkv_acc=[d_te.view(B * Lt, H), d_pe.view(B * Lp, H)])
         dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:].view(4 * B, Lt * H)
         neg_p, neg_t = T["neg"][:B], T["neg"][B:]
-        d_pe = self._zeros(B, Lp * H, dtype=torch.float32)
-        d_te = self._zeros(B, Lt * H, dtype=torch.float32)
         ops.acc_rows(d_pe, dXpv[0:B])
         ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
         ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
         ops.acc_rows(d_te, dXt[0:B])
         ops.acc_rows(d_te, dXt[B:2 * B])
         ops.acc_rows(d_te, dXt[2 * B:3 * B], idx=neg_t, atomic=True)
-        kt, kp = dkv_text.view(4 * B, Lt * H), dkv_prop.view(4 * B, Lp * H)
-        d_te.add_(kt[0:B]).add_(kt[B:2 * B]).add_(kt[3 * B:])
-        d_te.index_add_(0, neg_t, kt[2 * B:3 * B])
-        d_pe.add_(kp[0:B]).add_(kp[2 * B:3 * B]).add_(kp[3 * B:])
-        d_pe.index_add_(0, neg_p, kp[B:2 * B])
 
         # ---- ITA: stored d loss / d features -> projections -> CLS rows
         for k, (proj, d_hub, L) in enumerate((("property_proj", d_pe, Lp), ("text_proj", d_te, Lt))):

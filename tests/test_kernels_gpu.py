@@ -247,6 +247,42 @@ def test_attention_backward(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
         close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
 
 
+@pytest.mark.parametrize("nseq,U,nH,Lq,Lkv", [(8, 3, 2, 54, 128), (8, 2, 12, 128, 54), (5, 5, 2, 40, 40)])
+def test_cross_attention_with_shared_kv_sources(ops, nseq, U, nH, Lq, Lkv):
+    """kv_seq: query sequence s reads K/V of source kv_seq[s].  Outputs and dQ equal the kernel run on physically gathered
+    K/V copies bit for bit; segment_sum of the per-query dK/dV equals (fp32 sum, one bf16 rounding) the sum over sharers."""
+    H = nH * 64
+    g = torch.Generator().manual_seed(nseq + U)
+    Q = rnd(nseq * Lq, H, seed=40)
+    kvu = rnd(U * Lkv, 2 * H, seed=41)
+    idx = torch.randint(0, U, (nseq,), generator=g)
+    idx[:U] = torch.arange(U)                                     # every source used at least once
+    idx = idx.cuda()
+    mask = (torch.rand(nseq, Lkv, generator=g) > 0.2).int().cuda()
+    mask[:, 0] = 1
+    dO = rnd(nseq * Lq, H, seed=42)
+    kvg = kvu.view(U, Lkv, 2 * H)[idx].reshape(nseq * Lkv, 2 * H).contiguous()   # the gathered copies the reference path builds
+    outs = []
+    for K, V, ks in ((kvu[:, :H], kvu[:, H:], idx.to(torch.int32)), (kvg[:, :H], kvg[:, H:], None)):
+        O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+        lse = torch.zeros(nseq, nH, Lq, device="cuda")
+        ops.attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, is_cross=True, kv_seq=ks)
+        dQ = torch.zeros_like(Q)
+        dKV = torch.zeros(nseq * Lkv, 2 * H, dtype=BF, device="cuda")
+        ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dKV[:, :H], dKV[:, H:], nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, is_cross=True, kv_seq=ks)
+        outs.append((O, lse, dQ, dKV))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    order = torch.sort(idx, stable=True).indices.to(torch.int32)
+    start = torch.zeros(U + 1, dtype=torch.int32, device="cuda")
+    start[1:] = torch.cumsum(torch.bincount(idx, minlength=U), 0)
+    W = Lkv * 2 * H
+    dKV = outs[0][3].view(nseq, W)
+    folded = ops.segment_sum_bf16(dKV, start, order, torch.zeros(U, W, dtype=BF, device="cuda"))
+    ref = torch.zeros(U, W, device="cuda").index_add_(0, idx, dKV.float())
+    assert torch.equal(folded, ref.to(BF))
+
+
 def test_attention_backward_near_constant_values(ops):
     """Regression: in a real model V rows (hence dP) are nearly constant across keys, so ds = P (dP - D) is a small
     difference of large numbers.  D must be the fp32 sum_kv P dP; taking it from rowsum(dO * bf16(O)) gave 50-300 %
