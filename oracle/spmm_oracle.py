@@ -656,12 +656,39 @@ class OracleModule:
             return SimpleNamespace(last_hidden_state=bert_model(self.sd, "property_encoder.", self.cfg.prop, False,
                                                                 inputs_embeds=inputs_embeds, is_decoder=is_decoder))
 
-    def text_encoder(self, input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
-                     return_dict=True, is_decoder=False, return_logits=False):
+    @property
+    def text_encoder(self):
+        return _OracleMaskedLM(self.sd, self.cfg)
+
+    def property_mtr_head(self, x):
+        """SPMM_models.py:39-42: Linear -> GELU -> LayerNorm -> Linear(H, 1)."""
+        h = F.gelu(_lin(self.sd, "property_mtr_head.0", x))
+        h = _ln(self.sd, "property_mtr_head.2", h, self.cfg.text.layer_norm_eps)
+        return _lin(self.sd, "property_mtr_head.3", h)
+
+
+class _OracleMaskedLM:
+    """`model.text_encoder(...)` (BertForMaskedLM with return_logits, xbert.py:1377-1428) and `model.text_encoder.bert(...)`."""
+
+    def __init__(self, sd: SD, cfg: SPMMCfg):
+        self.sd, self.cfg = sd, cfg
+
+    def bert(self, input_ids=None, attention_mask=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+             return_dict=True, is_decoder=False, mode="multi_modal"):
+        from types import SimpleNamespace
         with torch.no_grad():
-            n = input_ids.shape[0]
-            enc = encoder_hidden_states.expand(n, -1, -1)
-            em = None if encoder_attention_mask is None else encoder_attention_mask.expand(n, -1)
-            h = bert_model(self.sd, "text_encoder.bert.", self.cfg.text, True, input_ids=input_ids, attention_mask=attention_mask,
-                           enc=enc, enc_mask=em, is_decoder=is_decoder)
+            enc, em = encoder_hidden_states, encoder_attention_mask
+            n = (input_ids if input_ids is not None else encoder_embeds).shape[0]
+            if enc is not None:
+                enc = enc.expand(n, -1, -1)
+                em = None if em is None else em.expand(n, -1)
+            h = bert_model(self.sd, "text_encoder.bert.", self.cfg.text, True, input_ids=input_ids, encoder_embeds=encoder_embeds,
+                           attention_mask=attention_mask, enc=enc, enc_mask=em, is_decoder=is_decoder, mode=mode)
+            return SimpleNamespace(last_hidden_state=h)
+
+    def __call__(self, input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                 return_dict=True, is_decoder=False, return_logits=False):
+        h = self.bert(input_ids, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
+                      encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder).last_hidden_state
+        with torch.no_grad():
             return mlm_head(self.sd, "text_encoder.", self.cfg.text, h)

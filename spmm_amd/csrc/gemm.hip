@@ -39,6 +39,7 @@ struct GemmP {
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range: 0 n-fastest, 1 m-fastest, 2 blocked (8 m-panels x GN n-tiles)
+  int krot;                  // v3: tiles start their k loop at different slices (de-synchronises the CUs' walks over shared W lines)
 };
 
 // LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
@@ -592,11 +593,14 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
+  const int rot = p.krot ? (tile_m * 5 + tile_n * 3) % nk : 0;
+#define KOF3(kt_) ((((kt_) + rot) >= nk ? (kt_) + rot - nk : (kt_) + rot) * BK)
 #define STAGE3(kt_)                                                                           \
   do {                                                                                        \
     char* b_ = smem3 + ((kt_) & 1) * STAGE3_BYTES;                                            \
-    stage2_dma(p.A, p.lda, m0, p.M, (kt_) * BK, b_, tid, 4);                                  \
-    stage2_dma(p.W, p.ldw, n0, p.N, (kt_) * BK, b_ + T3_BYTES, tid, 4);                       \
+    const int k0_ = KOF3(kt_);                                                                \
+    stage2_dma(p.A, p.lda, m0, p.M, k0_, b_, tid, 4);                                         \
+    stage2_dma(p.W, p.ldw, n0, p.N, k0_, b_ + T3_BYTES, tid, 4);                              \
   } while (0)
 
   if (ABL != 1 && ABL != 3) STAGE3(0);
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
     const char* As = smem3 + (kt & 1) * STAGE3_BYTES;
     const char* Ws = As + T3_BYTES;
     char* nxt = smem3 + ((kt + 1) & 1) * STAGE3_BYTES;
-    const int knext = (kt + 1) * BK;
+    const int knext = KOF3(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int s = kk * 2 + (lane >> 5);
@@ -1159,6 +1163,7 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, IL>), grid, dim3(512), LDS3_BYTES, st, p);
   return SPMM_OK;
 }
+static int g_krot = 0;
 static int g_tile_order = 3;          // row-major, split into 2 column groups when N >= 2048 and K <= 1024: lowest measured L2-miss traffic (profiles/r01_pmc_nt_gemm.txt); launch time is order-insensitive
 static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
 static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
@@ -1274,6 +1279,7 @@ extern "C" void spmm_gemm_set_variant(int v) {
   if (v >= 300 && v <= 304) { g_tile_order = v - 300; return; }
   if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
   if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
+  if (v == 700 || v == 701) { g_krot = v - 700; return; }
   if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
@@ -1301,7 +1307,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum; p.krot = g_krot;
   SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
     const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);

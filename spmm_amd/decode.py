@@ -269,3 +269,32 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
         if s % sync_every == sync_every - 1 and bool(book.done.all()):
             break
     return book.results()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SMILES -> PV: 53 autoregressive regression steps
+# ------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def smiles_to_pv(model, text_ids: torch.Tensor, text_mask: torch.Tensor, n_props: int = 53) -> torch.Tensor:
+    """Predict the (normalised) property vector of every SMILES in the batch, one property per step, as
+    d_smiles2pv.py:14-52 does: the text is encoded once by the unimodal text layers; at step i the PV prefix
+    [CLS, p_0..p_{i-1}] goes through the (bidirectional) PV encoder, then causally through the fusion layers with
+    cross-attention to the text, and `property_mtr_head` reads property i off the last position.  The whole batch advances
+    together; the prefix is re-encoded every step because the PV encoder is bidirectional (nothing to cache).
+    text_ids / text_mask: [B, Lt] without the tokenizer's own [CLS] (the caller drops column 0, SPMM_models.py:357).
+    Returns [B, n_props] in the normalised space (de-normalise with the dataset's mean/std as d_smiles2pv.py:49 does)."""
+    text_embeds = model.text_encoder.bert(text_ids, attention_mask=text_mask, return_dict=True, mode="text").last_hidden_state
+    B, dev = text_embeds.shape[0], text_embeds.device
+    cls = model.property_cls
+    prefix = cls.detach().to(dev).to(text_embeds.dtype).expand(B, -1, -1)
+    out = []
+    for _ in range(n_props):
+        pv = model.property_encoder(inputs_embeds=prefix, return_dict=True).last_hidden_state
+        ones = torch.ones(pv.shape[:-1], dtype=torch.long, device=dev)
+        fused = model.text_encoder.bert(encoder_embeds=pv, attention_mask=ones, encoder_hidden_states=text_embeds,
+                                        encoder_attention_mask=text_mask.to(dev), return_dict=True, is_decoder=True,
+                                        mode="fusion").last_hidden_state
+        nxt = model.property_mtr_head(fused[:, -1:, :]).reshape(B)            # only the last position is read (:25)
+        out.append(nxt)
+        prefix = torch.cat([prefix, model.property_embed(nxt.reshape(B, 1, 1)).to(prefix.dtype)], dim=1)
+    return torch.stack(out, dim=-1)

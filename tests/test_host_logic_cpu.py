@@ -185,3 +185,25 @@ def test_batched_beam_bookkeeping_matches_sequential_search():
                 assert sw == sg and abs(pw - pg) < 1e-5, (k, n, sw, sg)
             n_nonempty += bool(want)
         assert n_nonempty >= (6 if steps > 1 else 0), (k, n_nonempty)
+
+
+def test_wordpiece_tokenizer_matches_reference_golden(golden_dir):
+    """SmilesWordPiece vs ids produced by the WordpieceTokenizer the reference wires into its BertTokenizer, on the
+    reference's 300-piece vocabulary (fixture written by oracle/make_tokenizer_golden.py): drug-like SMILES, charged and
+    stereo atoms, truncation at max_length=100, an out-of-vocabulary character, the empty string, whitespace."""
+    import os
+    import numpy as np
+    import torch
+    from spmm_amd.tokenizer import SmilesWordPiece
+    g = np.load(os.path.join(golden_dir, "tokenizer_vocab300.npz"))
+    tok = SmilesWordPiece([str(t) for t in g["vocab"]])
+    texts = ["[CLS]" + str(s) for s in g["smiles"]]
+    out = tok(texts, padding="longest", truncation=True, max_length=100, return_tensors="pt")
+    assert torch.equal(out.input_ids, torch.from_numpy(g["input_ids"]))
+    assert torch.equal(out.attention_mask, torch.from_numpy(g["attention_mask"]))
+    assert out.input_ids.shape[1] == 100 and (out.input_ids[:, 0] == 2).all()          # the long row was truncated to 100
+    # what the model consumes (SPMM_models.py:357) and the way back to text
+    ids = out.input_ids[:, 1:]
+    assert ids[0, 0].item() == tok.cls_token_id
+    assert tok.decode(ids[0].tolist()) == str(g["smiles"][0])
+    assert tok.decode(ids[4].tolist()) == "CCO"
