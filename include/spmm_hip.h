@@ -70,12 +70,18 @@ void spmm_gemm_set_variant(int v);
  * for sequences >= causal_from) and invert_attention_mask :1038-1043 (cross: 0/finfo.min, is_cross=1).
  * kv_seq (optional, [nseq]): query sequence s reads the keys/values of sequence kv_seq[s] -- the passes of SPMM.forward
  * that cross-attend to the same encoder_hidden_states (SPMM_models.py:139-150,181-199,224-231,245-250) share one K/V
- * projection instead of four.  kmask stays per query sequence; dK/dV are written per query sequence. */
+ * projection instead of four.  kmask stays per query sequence; dK/dV are written per query sequence.
+ * q_row0/q_len ([nseq]) and kv_row0/kv_len ([number of key/value sources]), optional pairs: packed variable-length
+ * layouts -- sequence s owns q_len[s] <= Lq rows from row q_row0[s] of Q/O/dO/dQ, source u owns kv_len[u] <= Lkv rows from
+ * row kv_row0[u] of K/V (and of dK/dV unless kv_seq is given).  Rows of padding tokens whose outputs never reach a loss
+ * (SPMM_models.py:139-206 read only position 0 of those passes) are then simply not computed. */
 int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
-                  const int* kv_seq, void* O, long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from,
-                  int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+                  const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len, void* O,
+                  long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross, float dropout_p,
+                  const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
 int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
-                  const int* kv_seq, const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ,
+                  const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len,
+                  const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ,
                   long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from,
                   int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
 /* out[u] = sum over k in [start[u], start[u+1]) of src[list[k]]  (rows of W bf16 elements, fp32 accumulation, fixed order).

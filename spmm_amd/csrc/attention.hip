@@ -32,6 +32,10 @@ struct AttnP {
   const bf16* V; long ldv;
   const int* kmask;               // [nseq, Lkv] 1 = attend, or null (all ones)
   const int* kv_seq;              // [nseq] key/value sequence read by query sequence s (null: s itself); dK/dV stay per query sequence
+  // Packed (variable-length) layouts: sequence s owns q_len[s] <= Lq query rows starting at row q_row0[s]; key/value
+  // source u owns kv_len[u] <= Lkv rows starting at kv_row0[u].  Null = dense layout (row = seq*L + pos).  LSE, kmask and
+  // the dropout counter keep the dense [.., Lq, Lkv] indexing, so packed and padded runs draw the same masks.
+  const int* q_row0; const int* q_len; const int* kv_row0; const int* kv_len;
   bf16* O; long ldo;              // fwd output (unused by backward)
   float* LSE;                     // [nseq, nH, Lq]
   const bf16* dO; long lddo;
@@ -123,17 +127,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   float* mb = (float*)(smem + 2 * TILE);   // mask value per kv (1/0), -1 = padding
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
-  const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
-  const bf16* Kg = p.K + kvs * p.Lkv * p.ldk + h * HD;
-  const bf16* Vg = p.V + kvs * p.Lkv * p.ldv + h * HD;
-  stage_head(Kg, p.ldk, p.Lkv, Ks, tid, nthreads);
-  stage_head(Vg, p.ldv, p.Lkv, Vs, tid, nthreads);
+  const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
+  const long qrow = p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq;
+  const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
+  const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
+  const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
+  const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, nthreads);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, nthreads);
   for (int j = tid; j < 128; j += nthreads)
-    mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
+    mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
   const int q = wave * 32 + (lane & 31);
-  const int qc = q < p.Lq ? q : p.Lq - 1;
+  const int qc = q < Lq ? q : Lq - 1;
   bf16x8 qf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Qg + (long)qc * p.ldq + (kk * 2 + g) * 8);
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
-  if (p.LSE && q < p.Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
+  if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
   if (p.drop_thresh16) {
     const uint64_t seed = *p.seed_ptr ^ p.seed_salt;
     const uint64_t rowbase = (((uint64_t)seq * p.nH + h) * p.Lq + q) * (uint64_t)p.Lkv;
@@ -194,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       ot[0] = MFMA32(vf[0], pf, ot[0]);
       ot[1] = MFMA32(vf[1], pf, ot[1]);
     }
-  if (q < p.Lq) {
-    bf16* Og = p.O + ((long)seq * p.Lq + q) * p.ldo + h * HD;
+  if (q < Lq) {
+    bf16* Og = p.O + (qrow + q) * p.ldo + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -222,19 +229,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   float* Dq = lse + 128;
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-  const bf16* Qg = p.Q + (long)seq * p.Lq * p.ldq + h * HD;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
-  const bf16* Kg = p.K + kvs * p.Lkv * p.ldk + h * HD;
-  const bf16* Vg = p.V + kvs * p.Lkv * p.ldv + h * HD;
-  const bf16* dOg = p.dO + (long)seq * p.Lq * p.lddo + h * HD;
-  stage_head(Kg, p.ldk, p.Lkv, Ks, tid, 256);
-  stage_head(Vg, p.ldv, p.Lkv, Vs, tid, 256);
-  stage_head(Qg, p.ldq, p.Lq, Qs, tid, 256);
-  stage_head(dOg, p.lddo, p.Lq, dOs, tid, 256);
+  const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
+  const long qrow = p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq;
+  const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
+  const long dkvrow = p.kv_seq ? (long)seq * p.Lkv : kvrow;     // shared sources: dK/dV per query sequence, dense
+  const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
+  const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
+  const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
+  const bf16* dOg = p.dO + qrow * p.lddo + h * HD;
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, 256);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, 256);
+  stage_head(Qg, p.ldq, Lq, Qs, tid, 256);
+  stage_head(dOg, p.lddo, Lq, dOs, tid, 256);
   if (tid < 128) {
     const int j = tid;
-    mb[j] = j < p.Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
-    lse[j] = j < p.Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] : 0.f;
+    mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
+    lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] : 0.f;
     Dq[j] = 0.f;
   }
   __syncthreads();
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   const bool drop = p.drop_thresh16 != 0;
   const uint64_t seed = drop ? (*p.seed_ptr ^ p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
-  const int NTq = (p.Lq + 31) >> 5;
+  const int NTq = (Lq + 31) >> 5;
 
   // ---- phase A: wave owns query tile `wave` -> D[q] = sum_kv P dP (fp32, exactly consistent with ds) and dQ.
   // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float mv = mb[kv];
         float pr = 0.f, dpr = 0.f;
-        if (mv >= 0.f && q < p.Lq) {
+        if (mv >= 0.f && q < Lq) {
           const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
           pr = __expf(s - lq);
           dpr = dp[t][r];
@@ -300,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         dq[1] = MFMA32(kf[1], dsf, dq[1]);
       }
     }
-    if (q < p.Lq) {
-      bf16* dQg = p.dQ + ((long)seq * p.Lq + q) * p.lddq + h * HD;
+    if (q < Lq) {
+      bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         float pd = 0.f, ds = 0.f;
-        if (mv >= 0.f && q < p.Lq) {
+        if (mv >= 0.f && q < Lq) {
           const float sc = s[r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
           const float pr = __expf(sc - lse[q]);
           float dpr = dp[r];
@@ -362,9 +373,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         dk[1] = MFMA32(qf[1], dsf, dk[1]);
       }
     }
-    if (kv < p.Lkv) {
-      bf16* dKg = p.dK + ((long)seq * p.Lkv + kv) * p.lddk + h * HD;
-      bf16* dVg = p.dV + ((long)seq * p.Lkv + kv) * p.lddv + h * HD;
+    if (kv < Lkv) {
+      bf16* dKg = p.dK + (dkvrow + kv) * p.lddk + h * HD;
+      bf16* dVg = p.dV + (dkvrow + kv) * p.lddv + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -390,15 +401,19 @@ int check_common(const char* name, int nseq, int nH, int Lq, int Lkv, long ldq, 
 // head_dim is fixed at 64 (config_bert.json: 768 / 12).  Tensors are token-major: row = seq*L + pos, head h at
 // columns [h*64, h*64+64) of the given base pointer.
 extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
-                             const int* kmask, const int* kv_seq, void* O, long ldo, float* LSE, int nseq, int nH, int Lq,
+                             const int* kmask, const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0,
+                             const int* kv_len, void* O, long ldo, float* LSE, int nseq, int nH, int Lq,
                              int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
                              uint64_t seed_salt, hipStream_t stream) {
   int rc = check_common("spmm_attn_fwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
   if (rc) return rc;
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_fwd: dropout needs a device seed");
+  SPMM_CHECK_SHAPE((q_row0 == nullptr) == (q_len == nullptr) && (kv_row0 == nullptr) == (kv_len == nullptr),
+                   "spmm_attn_fwd: row0 and len arrays come in pairs");
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
-  p.kmask = kmask; p.kv_seq = kv_seq; p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
+  p.kmask = kmask; p.kv_seq = kv_seq; p.q_row0 = q_row0; p.q_len = q_len; p.kv_row0 = kv_row0; p.kv_len = kv_len;
+  p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
   p.causal_from = is_cross ? nseq : causal_from;
   p.mask_neg = is_cross ? -3.4028234663852886e38f : -10000.f;
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
@@ -418,13 +433,16 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
 }
 
 extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
-                             const int* kmask, const int* kv_seq, const void* O, long ldo, const float* LSE, const void* dO,
+                             const int* kmask, const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0,
+                             const int* kv_len, const void* O, long ldo, const float* LSE, const void* dO,
                              long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq,
                              int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
                              uint64_t seed_salt, hipStream_t stream) {
   int rc = check_common("spmm_attn_bwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
   if (rc) return rc;
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_bwd: dropout needs a device seed");
+  SPMM_CHECK_SHAPE((q_row0 == nullptr) == (q_len == nullptr) && (kv_row0 == nullptr) == (kv_len == nullptr),
+                   "spmm_attn_bwd: row0 and len arrays come in pairs");
   static bool attr_set = false;
   if (!attr_set) {
     const void* fns[4] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
@@ -440,7 +458,8 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   }
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
-  p.kmask = kmask; p.kv_seq = kv_seq; p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
+  p.kmask = kmask; p.kv_seq = kv_seq; p.q_row0 = q_row0; p.q_len = q_len; p.kv_row0 = kv_row0; p.kv_len = kv_len;
+  p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
   p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
   p.causal_from = is_cross ? nseq : causal_from;

@@ -80,18 +80,20 @@ def colsum_bf16(x, out):
 
 
 def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
-             seed=None, salt=0, kv_seq=None):
-    """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]."""
+             seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None):
+    """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]; packed layouts via the row0/len arrays."""
     cf = nseq if causal_from is None else causal_from
-    _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(O),
+    _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(q_row0),
+               _p(q_len), _p(kv_row0), _p(kv_len), _p(O),
                _row_stride(O), _p(lse), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
     return O
 
 
 def attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False,
-             dropout_p=0.0, seed=None, salt=0, kv_seq=None):
+             dropout_p=0.0, seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None):
     cf = nseq if causal_from is None else causal_from
-    _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(O),
+    _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(q_row0),
+               _p(q_len), _p(kv_row0), _p(kv_len), _p(O),
                _row_stride(O), _p(lse), _p(dO), _row_stride(dO), _p(dQ), _row_stride(dQ), _p(dK), _row_stride(dK), _p(dV),
                _row_stride(dV), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
 

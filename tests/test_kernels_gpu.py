@@ -283,6 +283,53 @@ def test_cross_attention_with_shared_kv_sources(ops, nseq, U, nH, Lq, Lkv):
     assert torch.equal(folded, ref.to(BF))
 
 
+@pytest.mark.parametrize("is_cross,shared", [(False, False), (True, False), (True, True)])
+def test_attention_packed_variable_length_layout(ops, is_cross, shared):
+    """Packed rows (q_row0/q_len, kv_row0/kv_len) give bit-identical O, LSE, dQ, dK, dV on the valid rows to the dense
+    padded layout with a key mask: the padded positions are simply never computed."""
+    nseq, nH, Lq, Lkv = 6, 2, 100, 54 if is_cross else 100
+    H = nH * 64
+    g = torch.Generator().manual_seed(77)
+    qlen = torch.randint(5, Lq + 1, (nseq,), generator=g); qlen[0] = Lq
+    U = 3 if shared else nseq
+    kvlen = qlen.clone() if not is_cross else torch.randint(3, Lkv + 1, (U,), generator=g)
+    idx = torch.randint(0, U, (nseq,), generator=g) if shared else torch.arange(nseq)
+    Qd = rnd(nseq * Lq, H, seed=50); dOd = rnd(nseq * Lq, H, seed=51)
+    # padded query rows exist in the dense layout; in the model their upstream gradient is exactly zero (no loss reads them)
+    dOd = dOd * (torch.arange(Lq)[None, :] < qlen[:, None]).reshape(-1, 1).to(BF).cuda()
+    KVd = rnd(U * Lkv, 2 * H, seed=52) if is_cross else None
+    if not is_cross:
+        KVd = torch.cat([rnd(nseq * Lq, H, seed=53), rnd(nseq * Lq, H, seed=54)], dim=1)
+    kmask_u = (torch.arange(Lkv)[None, :] < kvlen[:, None]).int()
+    kmask = kmask_u[idx].contiguous().cuda()                             # dense path: per query sequence
+    i32 = lambda t: t.to(torch.int32).cuda()
+    # dense run
+    Od = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda"); lsed = torch.zeros(nseq, nH, Lq, device="cuda")
+    kw = dict(nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, is_cross=is_cross, kv_seq=i32(idx) if shared else None)
+    ops.attn_fwd(Qd, KVd[:, :H], KVd[:, H:], Od, lsed, kmask=kmask, **kw)
+    dQd = torch.zeros_like(Qd); dKVd = torch.zeros(nseq * Lkv, 2 * H, dtype=BF, device="cuda")
+    ops.attn_bwd(Qd, KVd[:, :H], KVd[:, H:], Od, lsed, dOd, dQd, dKVd[:, :H], dKVd[:, H:], kmask=kmask, **kw)
+    # packed run
+    qsel = torch.cat([torch.arange(int(qlen[s])) + s * Lq for s in range(nseq)]).cuda()
+    ksel = torch.cat([torch.arange(int(kvlen[u])) + u * Lkv for u in range(U)]).cuda()
+    q0 = torch.cumsum(qlen, 0) - qlen; k0 = torch.cumsum(kvlen, 0) - kvlen
+    Qp, dOp, KVp = Qd[qsel].contiguous(), dOd[qsel].contiguous(), KVd[ksel].contiguous()
+    Op = torch.zeros_like(Qp); lsep = torch.zeros(nseq, nH, Lq, device="cuda")
+    pk = dict(q_row0=i32(q0), q_len=i32(qlen), kv_row0=i32(k0), kv_len=i32(kvlen))
+    ops.attn_fwd(Qp, KVp[:, :H], KVp[:, H:], Op, lsep, **kw, **pk)
+    dQp = torch.zeros_like(Qp)
+    dKVp = torch.zeros(nseq * Lkv if shared else KVp.shape[0], 2 * H, dtype=BF, device="cuda")
+    ops.attn_bwd(Qp, KVp[:, :H], KVp[:, H:], Op, lsep, dOp, dQp, dKVp[:, :H], dKVp[:, H:], **kw, **pk)
+    assert torch.equal(Op, Od[qsel]) and torch.equal(dQp, dQd[qsel])
+    valid_q = (torch.arange(Lq)[None, :] < qlen[:, None]).cuda()
+    assert torch.equal(lsep[valid_q[:, None, :].expand(nseq, nH, Lq)], lsed[valid_q[:, None, :].expand(nseq, nH, Lq)])
+    if shared:      # dK/dV stay dense per query sequence; rows past the source's length are not written
+        vk = kmask.bool().reshape(-1)
+        assert torch.equal(dKVp[vk], dKVd[vk])
+    else:
+        assert torch.equal(dKVp, dKVd[ksel])
+
+
 def test_attention_backward_near_constant_values(ops):
     """Regression: in a real model V rows (hence dP) are nearly constant across keys, so ds = P (dP - D) is a small
     difference of large numbers.  D must be the fp32 sum_kv P dP; taking it from rowsum(dO * bf16(O)) gave 50-300 %
