@@ -66,6 +66,15 @@ def shared_kv_saving(B, Lt, Lp=54, H=768, n_text=12, fusion=6):
     return 3 * (n_text - fusion) * 3 * B * (Lt + Lp) * 4 * H * H
 
 
+def padding_saving(B, Lt, n_valid, Lp=54, H=768, I=3072, n_text=12, fusion=6):
+    """FLOPs not executed because the passes that only read position 0 (P2, P4, P6, first half of P8) run on the n_valid
+    real tokens of the batch instead of B*Lt (spmm_amd/step.py::_pack_plan); per-token costs as in step_flops."""
+    pad = B * Lt - n_valid
+    self_tok = 8 * H * H + 4 * Lt * H + 4 * H * I
+    fus_tok = 12 * H * H + 4 * Lt * H + 4 * Lp * H + 4 * H * I
+    return pad * (3 * fusion * self_tok + fusion * self_tok + 3 * 2 * (n_text - fusion) * fus_tok)
+
+
 def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):
     """Fused cross-attention unit (Q/K/V projections + core + out-proj), BASELINE.md section 3."""
     return nseq * (4 * H * H * Lq + 4 * H * H * Lkv + 4 * Lq * Lkv * H)
@@ -148,6 +157,7 @@ def main():
     B, Lt = args.batch, args.seq_len
     batches = [synthetic_batch(B, Lt, 42 + 1000 * rank + i, dev) for i in range(4)]
     sync = grad_sync_fn(model.store)
+    n_valid = sum(int(b[2].sum()) for b in batches) / len(batches)     # real (non-padding) text tokens per batch
 
     def one_step(i):
         prop, ids, mask = batches[i % len(batches)]
@@ -265,7 +275,10 @@ def main():
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}"},
-           "step_tflop": round(flops / 1e12, 2), "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)) / 1e12, 2),
+           "step_tflop": round(flops / 1e12, 2),
+           "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
+                                         - padding_saving(B, Lt, n_valid, n_text=nt, fusion=f)) / 1e12, 2),
+           "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses}
     if rank == 0:

@@ -33,33 +33,62 @@ def _ceil(x, m):
     return (x + m - 1) // m * m
 
 
+class KVSource:
+    """Key/value source of a cross-attention shared by several query sequences (possibly of several groups): `kv` holds U
+    unique sequences of up to Lkv tokens -- dense ([U*Lkv, H]) or packed (row0/len int32 [U], `pack_idx` = dense row of every
+    packed row).  Each consumer group registers its sequence -> source map; K/V are projected once per layer, and in backward
+    the consumers' dK/dV are folded onto the unique rows (CSR inverse map) before the weight- and data-gradient GEMMs."""
+
+    def __init__(self, kv: torch.Tensor, U: int, Lkv: int, row0=None, length=None, pack_idx=None):
+        self.kv, self.U, self.Lkv, self.row0, self.len, self.pack_idx = kv, U, Lkv, row0, length, pack_idx
+        self._idx: List[torch.Tensor] = []
+        self.nseq = 0
+        self.start = self.list = None
+
+    def add(self, idx: torch.Tensor) -> int:
+        """Registers consumer sequences (idx int64 [n]: source of each); returns their offset in the consumer numbering."""
+        off = self.nseq
+        self._idx.append(idx)
+        self.nseq += idx.numel()
+        return off
+
+    def finalize(self):
+        idx = torch.cat(self._idx)
+        order = torch.sort(idx, stable=True).indices
+        start = torch.zeros(self.U + 1, dtype=torch.int32, device=idx.device)
+        start[1:] = torch.cumsum(torch.bincount(idx, minlength=self.U), 0)
+        self.start, self.list = start, order.to(torch.int32)
+        return self
+
+
 @dataclass
 class Group:
-    """A run of `nseq` equal-length sequences inside a token-major batch, attended independently."""
+    """A run of `nseq` sequences inside a token-major batch, attended independently: dense (`L` rows each) or packed
+    (`q_len[s]` rows from row `q_row0[s]`, relative to row0; `nrows` rows in total)."""
     row0: int
     nseq: int
     L: int
     kmask: Optional[torch.Tensor]          # int32 [nseq, L] (1 = attend) or None
     causal_from: int                       # sequences >= causal_from (within the group) are causal
-    kv: Optional[torch.Tensor] = None      # cross-attention source, bf16 [nseq*Lkv, H]
+    kv: Optional[torch.Tensor] = None      # private cross-attention source, bf16 [nseq*Lkv, H] (facades, momentum pass)
     Lkv: int = 0
     kv_mask: Optional[torch.Tensor] = None
-    kv_idx: Optional[torch.Tensor] = None  # int32 [nseq]: query sequence s attends kv sequence kv_idx[s] (kv holds the unique ones)
-    kv_start: Optional[torch.Tensor] = None   # CSR inverse of kv_idx: query sequences of unique source u are
-    kv_list: Optional[torch.Tensor] = None    # kv_list[kv_start[u] : kv_start[u+1]]
-    kv_unique: int = 0
+    q_row0: Optional[torch.Tensor] = None  # int32 [nseq]
+    q_len: Optional[torch.Tensor] = None   # int32 [nseq]
+    nrows: int = -1
+    src: Optional[KVSource] = None         # shared cross-attention source ...
+    kv_idx: Optional[torch.Tensor] = None  # ... int32 [nseq]: the source sequence each query sequence attends
+    kv_off: int = 0                        # ... offset of this group's sequences in the source's consumer numbering
 
     @property
     def rows(self):
-        return slice(self.row0, self.row0 + self.nseq * self.L)
+        n = self.nrows if self.nrows >= 0 else self.nseq * self.L
+        return slice(self.row0, self.row0 + n)
 
-    def share_kv(self, idx: torch.Tensor, n_unique: int) -> "Group":
-        """kv holds n_unique sequences; idx[s] (int64 [nseq], device) names the one query sequence s cross-attends to."""
-        order = torch.sort(idx, stable=True).indices
-        counts = torch.bincount(idx, minlength=n_unique)
-        start = torch.zeros(n_unique + 1, dtype=torch.int32, device=idx.device)
-        start[1:] = torch.cumsum(counts, 0)
-        self.kv_idx, self.kv_start, self.kv_list, self.kv_unique = idx.to(torch.int32), start, order.to(torch.int32), n_unique
+    def attend(self, src: KVSource, idx: torch.Tensor) -> "Group":
+        self.src, self.Lkv = src, src.Lkv
+        self.kv_off = src.add(idx)
+        self.kv_idx = idx.to(torch.int32)
         return self
 
 
@@ -77,6 +106,7 @@ class Engine:
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)
         self.train_mode = True
+        self.pack_text = True       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
         self._salt = 0
         self.tape = None
@@ -127,7 +157,8 @@ class Engine:
                 salt = self._next_salt()
                 r = g.rows
                 ops.attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
-                             kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt)
+                             kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt,
+                             q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
         else:
@@ -136,14 +167,22 @@ class Engine:
             Wkv = P.fused(pfx + ".self.", ("key", "value"), "weight")
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
+            shared = {}                                          # K/V of a shared source: projected once per layer
             for g in groups:
-                KV = self._new(g.kv.shape[0], 2 * H)             # one row per key/value token of the (unique) sources
-                ops.gemm_nt(g.kv, Wkv, KV, bias=bkv)
+                if g.src is not None:
+                    if id(g.src) not in shared:
+                        shared[id(g.src)] = ops.gemm_nt(g.src.kv, Wkv, self._new(g.src.kv.shape[0], 2 * H), bias=bkv)
+                    KV = shared[id(g.src)]
+                else:
+                    KV = self._new(g.nseq * g.Lkv, 2 * H)
+                    ops.gemm_nt(g.kv, Wkv, KV, bias=bkv)
                 lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
                 salt = self._next_salt()
                 r = g.rows
+                src = g.src
                 ops.attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
-                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt, kv_seq=g.kv_idx)
+                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt, kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
+                             kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)
                 sv["KV"].append(KV)
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
@@ -180,7 +219,8 @@ class Engine:
                 r = g.rows
                 ops.attn_bwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H],
                              dQKV[r, H:2 * H], dQKV[r, 2 * H:], nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L, kmask=g.kmask,
-                             causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=sv["salt_a"][i])
+                             causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=sv["salt_a"][i],
+                             q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
             self._wgrad(dQKV, X, P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="g"),
                         P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="g"))
             WT = self._wT(pfx + ".self.qkv", P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="w"))
@@ -191,18 +231,31 @@ class Engine:
             gWkv = P.fused(pfx + ".self.", ("key", "value"), "weight", what="g")
             gbkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="g")
             WkvT = self._wT(pfx + ".self.kv", P.fused(pfx + ".self.", ("key", "value"), "weight", what="w"))
+            pool = {}                                            # per shared source: the consumers' dK/dV, dense per query sequence
             for i, g in enumerate(groups):
                 r = g.rows
                 KV = sv["KV"][i]
-                dKV = self._new(g.nseq * g.Lkv, 2 * H)
+                src = g.src
+                if src is not None:
+                    if id(src) not in pool:
+                        pool[id(src)] = (src, self._new(src.nseq * src.Lkv, 2 * H))
+                    dKV = pool[id(src)][1][g.kv_off * g.Lkv:(g.kv_off + g.nseq) * g.Lkv]
+                else:
+                    dKV = self._new(g.nseq * g.Lkv, 2 * H)
                 ops.attn_bwd(Qc[r], KV[:, :H], KV[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQc[r], dKV[:, :H], dKV[:, H:],
                              nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask, is_cross=True, dropout_p=pa, seed=self.seed,
-                             salt=sv["salt_a"][i], kv_seq=g.kv_idx)
-                if g.kv_idx is not None:                         # fold the per-query-sequence dK/dV onto the unique sources
-                    W = g.Lkv * 2 * H
-                    dKV = ops.segment_sum_bf16(dKV.view(g.nseq, W), g.kv_start, g.kv_list, self._new(g.kv_unique, W)).view(-1, 2 * H)
-                self._wgrad(dKV, g.kv, gWkv, gbkv)
-                ops.gemm_nt(dKV, WkvT, dkv_acc[i], epi=ops.EPI_F32_ACC)
+                             salt=sv["salt_a"][i], kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
+                             kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)
+                if src is None:
+                    self._wgrad(dKV, g.kv, gWkv, gbkv)
+                    ops.gemm_nt(dKV, WkvT, dkv_acc[i], epi=ops.EPI_F32_ACC)
+            for src, dKV in pool.values():                       # fold onto the unique source rows, then one wgrad + dgrad
+                W = src.Lkv * 2 * H
+                dKVu = ops.segment_sum_bf16(dKV.view(src.nseq, W), src.start, src.list, self._new(src.U, W)).view(-1, 2 * H)
+                if src.pack_idx is not None:
+                    dKVu = dKVu.index_select(0, src.pack_idx)
+                self._wgrad(dKVu, src.kv, gWkv, gbkv)
+                ops.gemm_nt(dKVu, WkvT, dkv_acc[id(src)], epi=ops.EPI_F32_ACC)
             self._wgrad(dQc, X, P.g(pfx + ".self.query.weight"), P.g(pfx + ".self.query.bias"))
             ops.gemm_nt(dQc, self._wT(pfx + ".self.query", P.w(pfx + ".self.query.weight")), dX, R=dz)
         return dX
@@ -361,10 +414,14 @@ class Engine:
         return (dz.float() * (cdf + x * pdf)).to(BF)
 
     # ---------------------------------------------------------------------------------------------- features
-    def _feat_fwd(self, proj, X, L, B, save):
-        """normalize(proj(X[:, 0, :])) SPMM_models.py:92,95,101,105 -> (feat f32 [B,E], tape)."""
+    def _feat_fwd(self, proj, X, L, B, save, cls_rows=None):
+        """normalize(proj(X[:, 0, :])) SPMM_models.py:92,95,101,105 -> (feat f32 [B,E], tape).  cls_rows (int64 [B]): rows of
+        the first token of every sequence when X is packed."""
         P, E, H = self.P, self.cfg.embed_dim, self.cfg.text.hidden_size
-        cls = X.view(-1, L * H)[:B, :H]                     # strided CLS rows, row stride L*H
+        if cls_rows is not None:
+            cls = X.index_select(0, cls_rows)
+        else:
+            cls = X.view(-1, L * H)[:B, :H]                 # strided CLS rows, row stride L*H
         raw = self._new(B, E, dtype=torch.float32)
         ops.gemm_nt(cls, P.wb(proj + ".weight"), raw, bias=P.w(proj + ".bias"), epi=ops.EPI_F32)
         feat = self._new(B, E, dtype=torch.float32)

@@ -6,10 +6,24 @@ from typing import Callable, Optional, Tuple
 import torch
 
 from . import ops
-from .engine import BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, _ceil
+from .engine import BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, KVSource, _ceil
 
 
 class PretrainStep(Engine):
+    def _pack_plan(self, mask32: torch.Tensor, B: int, Lt: int):
+        """Row bookkeeping for the packed text passes: valid rows of the dense [B*Lt] layout in order, per-sequence start
+        and length.  One host read per step (the packed row count sizes the GEMMs); returns None -- dense fallback -- when
+        a sequence does not start with a valid token (position 0 is what the losses read) or nothing would be saved."""
+        lens = mask32.sum(1)
+        prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
+        stats = torch.stack([lens.sum(), (lens > 0).sum(), prefix.all().to(lens.dtype)]).cpu()
+        M, nonempty, is_prefix = int(stats[0]), int(stats[1]), int(stats[2])
+        if nonempty != B or not is_prefix or M >= B * Lt:       # holes in the mask: the packed index would not be the position
+            return None
+        rows = torch.argsort((mask32.view(-1) == 0), stable=True)[:M]          # valid rows first, original order kept
+        row0 = torch.cumsum(lens, 0) - lens
+        return dict(M=M, rows=rows, row0=row0.to(torch.int32), row0_64=row0.to(torch.int64), len=lens.to(torch.int32))
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, prop: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, *, mpm_mask: Optional[torch.Tensor] = None,
                 neg_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, gather: Optional[Callable] = None,
@@ -41,11 +55,20 @@ class PretrainStep(Engine):
         g1 = [Group(0, 2 * B, Lp, None, B)]
         y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save)
         prop_embeds, prop_embeds_causal = y1[:B * Lp], y1[B * Lp:]
-        ids2, mask2 = torch.cat([ids32, ids32]), torch.cat([mask32, mask32])
+        ids2 = torch.cat([ids32, ids32])
         x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
-        g2 = [Group(0, 2 * B, Lt, mask2, B)]
+        # P2 (and P4, P6, P8) feed only position 0 of their outputs to a loss (:95, :105, :201), and a padding token is
+        # never attended as a key, so its rows influence nothing: those passes run on the packed valid rows.  The LM passes
+        # (P9, P10) keep every row -- their loss counts the padding targets (:233).
+        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None) else None
+        M = pk["M"] if pk else B * Lt
+        if pk:
+            x2 = torch.cat([x2[:B * Lt].index_select(0, pk["rows"]), x2[B * Lt:]])
+            g2 = [Group(0, B, Lt, None, B, q_row0=pk["row0"], q_len=pk["len"], nrows=M), Group(M, B, Lt, mask32, 0)]
+        else:
+            g2 = [Group(0, 2 * B, Lt, torch.cat([mask32, mask32]), B)]
         y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
-        text_embeds, hidden10 = y2[:B * Lt], y2[B * Lt:]
+        text_embeds, hidden10 = y2[:M], y2[M:]
 
         # ---- momentum branch (:98-106, :215-222), no tape
         ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)                     # :99 / :266-269
@@ -53,8 +76,10 @@ class PretrainStep(Engine):
         prop_embeds_m, _ = self.stack_fwd("property_encoder_m.", cp, range(cp.num_hidden_layers), False, x3,
                                           [Group(0, B, Lp, None, B)], False)
         x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
+        if pk:
+            x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:]])
         y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g2, False)
-        text_embeds_m, hidden9 = y4[:B * Lt], y4[B * Lt:]
+        text_embeds_m, hidden9 = y4[:M], y4[M:]
         g5 = [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
         y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
         logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
@@ -68,7 +93,7 @@ class PretrainStep(Engine):
                                                   ("text_proj", text_embeds, Lt, None, None),
                                                   ("property_proj_m", prop_embeds_m, Lp, *bank["prop"]),
                                                   ("text_proj_m", text_embeds_m, Lt, *bank["text"]))):
-            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save)
+            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save, cls_rows=pk["row0_64"] if (pk and proj.startswith("text_proj")) else None)
             ops.l2norm_fwd(raw, feat, nrm, a3=A3[k * B:(k + 1) * B], w3=None if w3 is None else w3[:B], yT=qT)
             feats[proj] = (feat, nrm, cls)
         S_text = self._new(4 * B, J, dtype=torch.float32)     # rows: i2t | t2t | i2t_m | t2t_m
@@ -93,28 +118,48 @@ class PretrainStep(Engine):
         ops.sample_neg(S_text[:B], B, neg[B:], forced=ft, seed=self.seed, salt=self._next_salt())
 
         # ---- S6: the fusion layers over all seven student fusion passes at once (:137-198, :224-231, :243-250)
-        pe, te = prop_embeds.view(B, Lp * H), text_embeds.view(B, Lt * H)
+        # Cross-attention sources: the four PV-query passes read [te, te, te[neg], te], the four text-query passes
+        # [pe, pe[neg], pe, pe] -- B unique sequences each (KVSource): K/V are projected once on the unique rows and the
+        # attention kernels follow the sequence -> source map.
+        pe = prop_embeds.view(B, Lp * H)
         pe_neg = ops.gather_rows(self._new(B, Lp * H), pe, neg[:B])
-        te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
+        ar = torch.arange(B, dtype=torch.int64, device=self.dev)
         mask_neg = mask32.index_select(0, neg[B:])
         qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
-        qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
-        # Cross-attention sources: the four PV-query passes read [te, te, te[neg], te], the four text-query passes
-        # [pe, pe[neg], pe, pe] -- B unique sequences each.  The K/V projections (and their weight/data gradients) run once
-        # on the unique rows; the attention kernels follow `kv_idx` (same numbers as projecting every copy, a quarter of the work).
-        ar = torch.arange(B, dtype=torch.int64, device=self.dev)
-        idx_qpv = torch.cat([ar, ar, neg[B:], ar])
-        idx_qtext = torch.cat([ar, neg[:B], ar, ar])
-        kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
+        src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp)
+        if pk:
+            src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"])
+            # text negatives as queries (second half of P8): their lengths are device data, so they stay dense [B, Lt];
+            # rows past the negative's length are zero-filled and masked as keys
+            neg_rows = pk["row0_64"].index_select(0, neg[B:])[:, None] + torch.arange(Lt, device=self.dev)[None, :]
+            neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)
+            te_neg = torch.cat([text_embeds, self._zeros(1, H)]).index_select(0, neg_rows)
+            qtext = torch.cat([text_embeds, text_embeds, te_neg, hidden10])
+            r0 = 4 * B * Lp
+            gt = [Group(r0, 2 * B, Lt, None, 2 * B, q_row0=torch.cat([pk["row0"], pk["row0"] + M]), q_len=torch.cat([pk["len"], pk["len"]]),
+                        nrows=2 * M).attend(src_pv, torch.cat([ar, neg[:B]])),
+                  Group(r0 + 2 * M, 2 * B, Lt, torch.cat([mask_neg, mask32]), B).attend(src_pv, torch.cat([ar, ar]))]
+            kvmask_qpv = None                                   # key padding is implied by the source lengths
+            cls_text = torch.cat([pk["row0_64"], pk["row0_64"] + M, 2 * M + ar * Lt])
+        else:
+            src_text = KVSource(text_embeds, B, Lt)
+            te = text_embeds.view(B, Lt * H)
+            te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
+            qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
+            kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
+            gt = [Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B).attend(src_pv, torch.cat([ar, neg[:B], ar, ar]))]
+            neg_rows, cls_text = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt
         X6 = torch.cat([qpv, qtext])
-        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv=text_embeds.view(B * Lt, H), Lkv=Lt, kv_mask=kvmask_qpv).share_kv(idx_qpv, B),
-              Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B, kv=prop_embeds.view(B * Lp, H), Lkv=Lp, kv_mask=None).share_kv(idx_qtext, B)]
+        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv_mask=kvmask_qpv).attend(src_text, torch.cat([ar, ar, neg[B:], ar]))] + gt
+        src_text.finalize()
+        src_pv.finalize()
         y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save)
         ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
 
-        # ---- ITM head (:199-206)
+        # ---- ITM head (:199-206) on the position-0 rows of the first 3B sequences of both halves
         vl_logits = self._new(3 * B, 2, dtype=torch.float32) if aux is not None else None
-        ops.itm_head(ypv, Lp * H, ytext, Lt * H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
+        itm_text = ytext.index_select(0, cls_text)
+        ops.itm_head(ypv, Lp * H, itm_text, H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
                      slot=LOSS_ITM, logits=vl_logits)
 
         # ---- queue (:208, :272-286)
@@ -126,7 +171,7 @@ class PretrainStep(Engine):
         ops.enqueue(feat_tm, P.buffers["text_queue"], *bank["text"], ptr, Bloc=B, advance=True)
 
         # ---- LM loss (:211-238)
-        hid10 = ytext[3 * B * Lt:]
+        hid10 = ytext[ytext.shape[0] - B * Lt:]
         logits, lmsv = self.lm_head_fwd("text_encoder.", ct, hid10, save)
         ops.lm_loss(logits, logits_m, ids32, nseq=B, L=Lt, V=ct.vocab_size, alpha=self.alpha, ws=self.icount[0:1], losses=self.losses,
                     slot=LOSS_MLM)
@@ -151,7 +196,8 @@ class PretrainStep(Engine):
                        pred=pred, prop_neg_idx=neg[:B], text_neg_idx=neg[B:], mpm_mask=mpm_mask,
                        prop_embeds_causal=prop_embeds_causal)
         if save:
-            self.tape = dict(B=B, Lt=Lt, prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
+            self.tape = dict(B=B, Lt=Lt, pk=pk, M=M, src_text=src_text, src_pv=src_pv, neg_rows=neg_rows, cls_text=cls_text, itm_text=itm_text,
+                             prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
                              esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv,
                              ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln,
                              mmean=mmean, mrstd=mrstd)
@@ -169,8 +215,9 @@ class PretrainStep(Engine):
         B, Lt = T["B"], T["Lt"]
         gs = self.gscale
         scratch = self.loss_scratch
-        M6 = 4 * B * (Lp + Lt)
-        dY6 = self._zeros(M6, H)
+        pk, M = T["pk"], T["M"]
+        nt6 = T["ytext"].shape[0]                                  # text-query rows of S6: 2M + 2B*Lt packed, 4B*Lt dense
+        dY6 = self._zeros(4 * B * Lp + nt6, H)
         dYpv, dYtext = dY6[:4 * B * Lp], dY6[4 * B * Lp:]
 
         # ---- MPM head
@@ -190,43 +237,62 @@ class PretrainStep(Engine):
         dlogits = self._new(B * Lt, _ceil(V, 64))
         ops.lm_loss(T["logits"], T["logits_m"], T["ids32"], nseq=B, L=Lt, V=V, alpha=self.alpha, ws=self.icount[0:1], losses=scratch,
                     slot=LOSS_MLM, dlogits=dlogits, gscale=gs[0:1])
-        dYtext[3 * B * Lt:].copy_(self.lm_head_bwd("text_encoder.", ct, T["lmsv"], dlogits))
+        dYtext[nt6 - B * Lt:].copy_(self.lm_head_bwd("text_encoder.", ct, T["lmsv"], dlogits))
 
-        # ---- ITM head: writes the CLS rows of the first 3B sequences of both halves
-        ops.itm_head(T["ypv"], Lp * H, T["ytext"], Lt * H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
-                     slot=LOSS_ITM, dxa=dYpv, dxb=dYtext, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
+        # ---- ITM head: gradients of the position-0 rows of the first 3B sequences of both halves
+        ditm = self._new(3 * B, H)
+        ops.itm_head(T["ypv"], Lp * H, T["itm_text"], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
+                     slot=LOSS_ITM, dxa=dYpv, dxb=ditm, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
+        dYtext.index_copy_(0, T["cls_text"], ditm)
 
         # ---- S6 backward
-        d_pe = self._zeros(B, Lp * H, dtype=torch.float32)          # hub gradients of prop_embeds / text_embeds (fp32)
-        d_te = self._zeros(B, Lt * H, dtype=torch.float32)
-        # the cross-attention K/V data gradients land directly on the unique sources (Group.share_kv)
+        d_pe = self._zeros(B, Lp * H, dtype=torch.float32)          # hub gradients of prop_embeds / text_embeds (fp32);
+        d_te = self._zeros(M + 1, H, dtype=torch.float32)           # text rows packed like text_embeds, + one dump row
+        # the cross-attention K/V data gradients land directly on the unique sources (KVSource)
         dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"],
-                             dkv_acc=[d_te.view(B * Lt, H), d_pe.view(B * Lp, H)])
-        dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:].view(4 * B, Lt * H)
+                             dkv_acc={id(T["src_text"]): d_te[:M], id(T["src_pv"]): d_pe.view(B * Lp, H)})
+        dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:]
         neg_p, neg_t = T["neg"][:B], T["neg"][B:]
         ops.acc_rows(d_pe, dXpv[0:B])
         ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
         ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
-        ops.acc_rows(d_te, dXt[0:B])
-        ops.acc_rows(d_te, dXt[B:2 * B])
-        ops.acc_rows(d_te, dXt[2 * B:3 * B], idx=neg_t, atomic=True)
+        if pk:
+            ops.acc_rows(d_te[:M], dXt[:M])
+            ops.acc_rows(d_te[:M], dXt[M:2 * M])
+            d_te.index_add_(0, T["neg_rows"], dXt[2 * M:2 * M + B * Lt].float())     # rows past a negative's length -> dump row
+        else:
+            dte, dxt = d_te[:M].view(B, Lt * H), dXt.view(4 * B, Lt * H)
+            ops.acc_rows(dte, dxt[0:B])
+            ops.acc_rows(dte, dxt[B:2 * B])
+            ops.acc_rows(dte, dxt[2 * B:3 * B], idx=neg_t, atomic=True)
+        dXt_lm = dXt[nt6 - B * Lt:]
 
         # ---- ITA: stored d loss / d features -> projections -> CLS rows
-        for k, (proj, d_hub, L) in enumerate((("property_proj", d_pe, Lp), ("text_proj", d_te, Lt))):
+        for k, proj in enumerate(("property_proj", "text_proj")):
             feat, nrm, cls = T["feats"][proj]
             dproj = self._new(B, E)
             ops.l2norm_bwd(T["dfeat"][k * B:(k + 1) * B], feat, nrm, dproj, gscale=gs[2:3])
             self._wgrad(dproj, cls, P.g(proj + ".weight"), P.g(proj + ".bias"))
             dcls = self._new(B, H)
             ops.gemm_nt(dproj, self._wT(proj, P.w(proj + ".weight")), dcls)
-            ops.acc_rows(d_hub[:, :H], dcls)
+            if k == 0:
+                ops.acc_rows(d_pe[:, :H], dcls)
+            elif pk:
+                d_te.index_add_(0, pk["row0_64"], dcls.float())
+            else:
+                ops.acc_rows(d_te[:M].view(B, Lt * H)[:, :H], dcls)
         ops.axpy_scalar(P.g("temp").view(1), self.dtemp_ita, scale_ptr=gs[2:3])
 
         # ---- S2 backward (text layers 0..f-1 on P2 | P10a) and the text embeddings
-        dY2 = self._new(2 * B * Lt, H)
-        ops.cast_f32_bf16(d_te.view(-1), dY2[:B * Lt].view(-1))
-        dY2[B * Lt:].copy_(dXt[3 * B:].reshape(B * Lt, H))
+        dY2 = self._new(M + B * Lt, H)
+        ops.cast_f32_bf16(d_te[:M].view(-1), dY2[:M].view(-1))
+        dY2[M:].copy_(dXt_lm)
         dX2 = self.stack_bwd("text_encoder.bert.", ct, range(0, f), T["tape2"], dY2, T["g2"])
+        if pk:                                                  # back to the dense layout of the embedding kernels
+            dense = self._zeros(2 * B * Lt, H)
+            dense[:B * Lt].index_copy_(0, pk["rows"], dX2[:M])
+            dense[B * Lt:].copy_(dX2[M:])
+            dX2 = dense
         dz2 = self._embed_ln_bwd("text_encoder.bert.", ct, T["esv2"], dX2)
         tp = "text_encoder.bert.embeddings."
         ops.embed_bwd(0, dz2, nseq=2 * B, L=Lt, H=H, dpos=P.g(tp + "position_embeddings.weight"),

@@ -81,8 +81,10 @@ def test_step_schedule_dry_run(dry):
                    "spmm_ita_rows", "spmm_sample_neg", "spmm_lm_loss", "spmm_itm_head", "spmm_mpm_head", "spmm_enqueue",
                    "spmm_ema_update", "spmm_grad_sqnorm", "spmm_adamw_step", "spmm_clamp_scalar", "spmm_l2norm_fwd", "spmm_l2norm_bwd"):
         assert needed in log, needed
-    # 2 text layers (1 fusion) + 1 PV layer: self-attention launches in forward = S1(1) + S2(1) + S3(1) + S4(1) + S5(1) + S6(2 groups)
-    assert log.count("spmm_attn_bwd") == 1 + 1 + 2 + 2          # S1, S2 self; S6: 2 groups x (self + cross)
+    # 2 text layers (1 fusion) + 1 PV layer, packed text passes: S1 one group; S2 two (packed P2 | dense causal P10a);
+    # S6 three (PV queries | packed text queries | dense text queries), each with a self- and a cross-attention launch
+    assert log.count("spmm_attn_bwd") == 1 + 2 + 3 * 2
+    assert log.count("spmm_segment_sum_bf16") == 2              # one fold per shared key/value source (text, PV) per fusion layer
     # autograd-boundary path
     dry._dry_log.clear()
     out = m(prop, ids, mask, alpha=0.1)

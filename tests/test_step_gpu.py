@@ -442,3 +442,40 @@ def test_smiles_to_pv_matches_oracle(env):
     assert got.shape == want.shape == (5, 12)
     assert (got - want).abs().max().item() < 5e-2, (got - want).abs().max().item()
     assert want.std().item() > 1e-2                       # not a constant predictor: the comparison is meaningful
+
+
+def test_packed_text_passes_equal_dense_layout(env):
+    """Dropping the padding-token rows from the passes that only read position 0 (P2, P4, P6, P8; spmm_amd/step.py) changes
+    nothing: same four losses and the same gradient as the dense layout on a batch with ragged lengths, dropout off.
+    (Not bit-exact: the weight-gradient GEMMs sum over a different number of rows, i.e. in a different split order.)"""
+    O, SPMM, tiny_config, *_ = env
+    cfg = tiny_config()
+    for c in (cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.closed_form_state_dict(O.tiny_cfg())
+    B, Lt = 8, 24
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=21)
+    assert int(mask.sum()) < B * Lt and int(mask.sum(1).min()) < Lt           # ragged: there is something to drop
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(3))
+    neg = (torch.arange(B).roll(2), torch.arange(B).roll(3))
+    out = {}
+    for pack in (True, False):
+        m = _mk(SPMM, cfg, sd).train()
+        m.engine.pack_text = pack
+        losses = m(prop, ids, mask, alpha=0.3, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+        sum(losses).backward()
+        out[pack] = (torch.stack([l.detach() for l in losses]).cpu(), m.store.grad.detach().clone().cpu(),
+                     m.store.buffers["text_queue"].clone().cpu())
+    lp, gp, qp = out[True]
+    ld, gd, qd = out[False]
+    assert torch.allclose(lp, ld, rtol=0, atol=2e-6), (lp, ld)
+    assert torch.equal(qp, qd)
+    rel = ((gp - gd).norm() / gd.norm()).item()
+    print("packed vs dense: losses", lp.tolist(), "gradient rel L2", rel)
+    assert rel < 2e-4
+    # a mask that is not a prefix falls back to the dense layout (the packed index would not be the position)
+    holes = mask.clone()
+    holes[0, 2] = 0
+    m = _mk(SPMM, cfg, sd).train()
+    assert m.engine._pack_plan(holes.to(torch.int32).cuda(), B, Lt) is None
+    assert m.engine._pack_plan(mask.to(torch.int32).cuda(), B, Lt)["M"] == int(mask.sum())
