@@ -72,7 +72,8 @@ def padding_saving(B, Lt, n_valid, Lp=54, H=768, I=3072, n_text=12, fusion=6):
     pad = B * Lt - n_valid
     self_tok = 8 * H * H + 4 * Lt * H + 4 * H * I
     fus_tok = 12 * H * H + 4 * Lt * H + 4 * Lp * H + 4 * H * I
-    return pad * (3 * fusion * self_tok + fusion * self_tok + 3 * 2 * (n_text - fusion) * fus_tok)
+    # P2 (x3: forward + backward), P4 and P9a (teacher, forward only), P6 + P8a (x3), P9b (teacher fusion layers)
+    return pad * (3 * fusion * self_tok + 2 * fusion * self_tok + 3 * 2 * (n_text - fusion) * fus_tok + (n_text - fusion) * fus_tok)
 
 
 def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):

@@ -16,6 +16,7 @@ Everything that changes between steps (alpha, lr, dropout seed, loss-gradient sc
 device memory, so the same launch sequence can be captured once into a hipGraph and replayed."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -106,7 +107,7 @@ class Engine:
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)
         self.train_mode = True
-        self.pack_text = True       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
+        self.pack_text = os.environ.get("SPMM_PACK_TEXT", "1") != "0"       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
         self._salt = 0
         self.tape = None

@@ -77,12 +77,19 @@ class PretrainStep(Engine):
                                           [Group(0, B, Lp, None, B)], False)
         x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
         if pk:
-            x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:]])
-        y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g2, False)
+            # The teacher's LM logits are read only where the label is a real token (:236-237), and a causal position sees
+            # nothing to its right: P9 (unlike the student's P10, whose loss counts padding targets) is packed too.
+            x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:].index_select(0, pk["rows"])])
+            g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
+            g5 = [Group(0, B, Lt, None, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
+        else:
+            g4, g5 = g2, [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
+        y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False)
         text_embeds_m, hidden9 = y4[:M], y4[M:]
-        g5 = [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
         y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
         logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
+        if pk:                                                   # the loss kernel indexes [B, Lt, V]
+            logits_m = torch.zeros(B * Lt, logits_m.shape[1], dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
 
         # ---- features, similarity banks, ITA loss and its gradient w.r.t. the student features (:92-131)
         bank = self._banks(B)
@@ -129,18 +136,20 @@ class PretrainStep(Engine):
         src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp)
         if pk:
             src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"])
-            # text negatives as queries (second half of P8): their lengths are device data, so they stay dense [B, Lt];
-            # rows past the negative's length are zero-filled and masked as keys
             neg_rows = pk["row0_64"].index_select(0, neg[B:])[:, None] + torch.arange(Lt, device=self.dev)[None, :]
-            neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)
+            neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)   # dense (i, l) -> row of te
+            r0 = 4 * B * Lp
+            # Text negatives as queries (second half of P8) stay dense [B, Lt]: which sequences were drawn is device data, and
+            # packing them behind a second host read measured no gain.  Rows past the negative's length are zero-filled and
+            # masked as keys.
+            Mn = B * Lt
             te_neg = torch.cat([text_embeds, self._zeros(1, H)]).index_select(0, neg_rows)
             qtext = torch.cat([text_embeds, text_embeds, te_neg, hidden10])
-            r0 = 4 * B * Lp
             gt = [Group(r0, 2 * B, Lt, None, 2 * B, q_row0=torch.cat([pk["row0"], pk["row0"] + M]), q_len=torch.cat([pk["len"], pk["len"]]),
                         nrows=2 * M).attend(src_pv, torch.cat([ar, neg[:B]])),
                   Group(r0 + 2 * M, 2 * B, Lt, torch.cat([mask_neg, mask32]), B).attend(src_pv, torch.cat([ar, ar]))]
-            kvmask_qpv = None                                   # key padding is implied by the source lengths
             cls_text = torch.cat([pk["row0_64"], pk["row0_64"] + M, 2 * M + ar * Lt])
+            kvmask_qpv = None                                   # key padding is implied by the source lengths
         else:
             src_text = KVSource(text_embeds, B, Lt)
             te = text_embeds.view(B, Lt * H)
@@ -148,7 +157,7 @@ class PretrainStep(Engine):
             qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
             kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
             gt = [Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B).attend(src_pv, torch.cat([ar, neg[:B], ar, ar]))]
-            neg_rows, cls_text = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt
+            neg_rows, cls_text, Mn = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt, B * Lt
         X6 = torch.cat([qpv, qtext])
         g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv_mask=kvmask_qpv).attend(src_text, torch.cat([ar, ar, neg[B:], ar]))] + gt
         src_text.finalize()
@@ -196,7 +205,7 @@ class PretrainStep(Engine):
                        pred=pred, prop_neg_idx=neg[:B], text_neg_idx=neg[B:], mpm_mask=mpm_mask,
                        prop_embeds_causal=prop_embeds_causal)
         if save:
-            self.tape = dict(B=B, Lt=Lt, pk=pk, M=M, src_text=src_text, src_pv=src_pv, neg_rows=neg_rows, cls_text=cls_text, itm_text=itm_text,
+            self.tape = dict(B=B, Lt=Lt, pk=pk, M=M, Mn=Mn, src_text=src_text, src_pv=src_pv, neg_rows=neg_rows, cls_text=cls_text, itm_text=itm_text,
                              prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
                              esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv,
                              ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln,
@@ -259,7 +268,7 @@ class PretrainStep(Engine):
         if pk:
             ops.acc_rows(d_te[:M], dXt[:M])
             ops.acc_rows(d_te[:M], dXt[M:2 * M])
-            d_te.index_add_(0, T["neg_rows"], dXt[2 * M:2 * M + B * Lt].float())     # rows past a negative's length -> dump row
+            d_te.index_add_(0, T["neg_rows"], dXt[2 * M:2 * M + T["Mn"]].float())    # dense variant: rows past a negative's length -> dump row
         else:
             dte, dxt = d_te[:M].view(B, Lt * H), dXt.view(4 * B, Lt * H)
             ops.acc_rows(dte, dxt[0:B])
