@@ -66,8 +66,10 @@ __device__ __forceinline__ float score_bias(int mask_kv, bool causal, int q, int
 
 // LDS-DMA staging of the [L][64] head slice: global_load_lds_dwordx4 writes lane-linear, so the swizzle is applied on
 // the SOURCE chunk.  Rows >= L re-read row L-1 (finite data; such rows are masked / never stored).
-__device__ __forceinline__ void stage_head(const bf16* __restrict__ src, long ld, int L, char* tile, int tid, int nthreads) {
-  for (int id = tid; id < 128 * 8; id += nthreads) {
+__device__ __forceinline__ void stage_head(const bf16* __restrict__ src, long ld, int L, char* tile, int tid, int nthreads,
+                                           int rows = 128) {
+  // only the 32-row tiles the MFMAs will touch are staged (`rows` = tiles * 32): a 54-token sequence moves 64 rows, not 128
+  for (int id = tid; id < rows * 8; id += nthreads) {
     const int row = id >> 3, pc = id & 7;
     const int lc = pc ^ frot(row);
     const int grow = row < L ? row : L - 1;
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
   const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
-  stage_head(Kg, p.ldk, Lkv, Ks, tid, nthreads);
-  stage_head(Vg, p.ldv, Lkv, Vs, tid, nthreads);
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, nthreads, NT * 32);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, nthreads, NT * 32);
   for (int j = tid; j < 128; j += nthreads)
     mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
@@ -238,10 +240,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
   const bf16* dOg = p.dO + qrow * p.lddo + h * HD;
-  stage_head(Kg, p.ldk, Lkv, Ks, tid, 256);
-  stage_head(Vg, p.ldv, Lkv, Vs, tid, 256);
-  stage_head(Qg, p.ldq, Lq, Qs, tid, 256);
-  stage_head(dOg, p.lddo, Lq, dOs, tid, 256);
+  const int qrows = ((Lq + 31) >> 5) * 32;
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, 256, NT * 32);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, 256, NT * 32);
+  stage_head(Qg, p.ldq, Lq, Qs, tid, 256, qrows);
+  stage_head(dOg, p.lddo, Lq, dOs, tid, 256, qrows);
   if (tid < 128) {
     const int j = tid;
     mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
