@@ -214,6 +214,7 @@ def main():
             gemm_bytes[0] += b
             return 2.0 * M * N * K
 
+        model.engine.multi_stream = False     # per-launch events need one stream; concurrency would also smear the durations
         ops.gemm_nt = timed("gemm", orig_gemm, gemm_flops)
         nsteps = min(3, args.steps)
         for i in range(nsteps):
@@ -241,6 +242,7 @@ def main():
             one_step(i)
         torch.cuda.synchronize()
         eng._attn_block_fwd = orig_blk
+        model.engine.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
         x_ms = sum(a.elapsed_time(b) for a, b, _ in ev["xattn"])
         x_fl = sum(fl for _, _, fl in ev["xattn"])
         x_ach = x_fl / (x_ms * 1e-3) / 1e12
@@ -257,7 +259,7 @@ def main():
                 "launches_per_step": n_launch // nsteps, "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
                 "flops_per_step": tot_fl / nsteps, "gemm_ms_per_step": round(tot_ms / nsteps, 3),
                 "algorithmic_bytes_per_launch": round(gemm_bytes[0] / n_launch),
-                "measured": f"HIP events around every launch, {nsteps} instrumented steps after the timed region"}
+                "measured": f"HIP events around every launch, {nsteps} instrumented single-stream steps after the timed region"}
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_nt_gemm.json")

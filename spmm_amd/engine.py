@@ -16,6 +16,7 @@ Everything that changes between steps (alpha, lr, dropout seed, loss-gradient sc
 device memory, so the same launch sequence can be captured once into a hipGraph and replayed."""
 from __future__ import annotations
 
+import contextlib
 import os
 from dataclasses import dataclass
 from typing import List, Optional
@@ -109,12 +110,39 @@ class Engine:
         self.train_mode = True
         self.pack_text = os.environ.get("SPMM_PACK_TEXT", "1") != "0"       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
+        # the unimodal text and PV chains (and their backward) are independent: run them on two HIP streams so the small-M
+        # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
+        self.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
+        self._side = None
         self._salt = 0
         self.tape = None
         E, Q = cfg.embed_dim, cfg.queue_size
         self._bank = None          # queue GEMM shadows, sized on first use (depend on the local batch)
 
     # ------------------------------------------------------------------------------------------------ helpers
+    def _fork(self, which: int = 0):
+        """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
+        if not self.multi_stream or self.dev.type != "cuda" or ops._DRY_RUN:
+            return None
+        if self._side is None:
+            self._side = {}
+        if which not in self._side:
+            self._side[which] = torch.cuda.Stream(device=self.dev)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side[which].wait_event(ev)
+        return self._side[which]
+
+    def _join(self, side):
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+
+    @staticmethod
+    def _on(side):
+        return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
     def _new(self, *shape, dtype=BF):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 

@@ -50,46 +50,59 @@ class PretrainStep(Engine):
             mpm_mask = (torch.rand(B, cfg.n_props, device=self.dev) < 0.5).to(torch.float32)
         mpm_mask = mpm_mask.to(torch.float32).contiguous()
 
-        # ---- S1 / S2: student unimodal encoders (:90-95) batched with their causal twins (:224, :242)
+        # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
+        # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
+        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None) else None
+        M = pk["M"] if pk else B * Lt
+        ids2 = torch.cat([ids32, ids32])
+        ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)                     # :99 / :266-269
+        side = self._fork()
+        with self._on(side):
+            x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
+            # P2 (and P4, P6, P8) feed only position 0 of their outputs to a loss (:95, :105, :201), and a padding token is
+            # never attended as a key, so its rows influence nothing: those passes run on the packed valid rows.  The
+            # student's LM pass (P10) keeps every row -- its loss counts the padding targets (:233).
+            if pk:
+                x2 = torch.cat([x2[:B * Lt].index_select(0, pk["rows"]), x2[B * Lt:]])
+                g2 = [Group(0, B, Lt, None, B, q_row0=pk["row0"], q_len=pk["len"], nrows=M), Group(M, B, Lt, mask32, 0)]
+            else:
+                g2 = [Group(0, 2 * B, Lt, torch.cat([mask32, mask32]), B)]
+            y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
+            text_embeds, hidden10 = y2[:M], y2[M:]
+        side_m = self._fork(1)
+        with self._on(side_m):
+            # momentum text branch (:104-105, :215-222), no tape
+            x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
+            if pk:
+                # The teacher's LM logits are read only where the label is a real token (:236-237), and a causal position
+                # sees nothing to its right: P9 (unlike P10) is packed too.
+                x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:].index_select(0, pk["rows"])])
+                g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
+            else:
+                g4 = g2
+            y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False)
+            text_embeds_m, hidden9 = y4[:M], y4[M:]
         x1, esv1 = self.embed_pv("property_encoder.", cp, prop, mpm_mask, 2 * B, B, save)
         g1 = [Group(0, 2 * B, Lp, None, B)]
         y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save)
         prop_embeds, prop_embeds_causal = y1[:B * Lp], y1[B * Lp:]
-        ids2 = torch.cat([ids32, ids32])
-        x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
-        # P2 (and P4, P6, P8) feed only position 0 of their outputs to a loss (:95, :105, :201), and a padding token is
-        # never attended as a key, so its rows influence nothing: those passes run on the packed valid rows.  The LM passes
-        # (P9, P10) keep every row -- their loss counts the padding targets (:233).
-        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None) else None
-        M = pk["M"] if pk else B * Lt
-        if pk:
-            x2 = torch.cat([x2[:B * Lt].index_select(0, pk["rows"]), x2[B * Lt:]])
-            g2 = [Group(0, B, Lt, None, B, q_row0=pk["row0"], q_len=pk["len"], nrows=M), Group(M, B, Lt, mask32, 0)]
-        else:
-            g2 = [Group(0, 2 * B, Lt, torch.cat([mask32, mask32]), B)]
-        y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
-        text_embeds, hidden10 = y2[:M], y2[M:]
-
-        # ---- momentum branch (:98-106, :215-222), no tape
-        ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)                     # :99 / :266-269
         x3, _ = self.embed_pv("property_encoder_m.", cp, prop, mpm_mask, B, B, False)
         prop_embeds_m, _ = self.stack_fwd("property_encoder_m.", cp, range(cp.num_hidden_layers), False, x3,
                                           [Group(0, B, Lp, None, B)], False)
-        x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
+        self._join(side)
+        self._join(side_m)
         if pk:
-            # The teacher's LM logits are read only where the label is a real token (:236-237), and a causal position sees
-            # nothing to its right: P9 (unlike the student's P10, whose loss counts padding targets) is packed too.
-            x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:].index_select(0, pk["rows"])])
-            g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
             g5 = [Group(0, B, Lt, None, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
         else:
-            g4, g5 = g2, [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
-        y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False)
-        text_embeds_m, hidden9 = y4[:M], y4[M:]
-        y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
-        logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
-        if pk:                                                   # the loss kernel indexes [B, Lt, V]
-            logits_m = torch.zeros(B * Lt, logits_m.shape[1], dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
+            g5 = [Group(0, B, Lt, mask32, 0, kv=prop_embeds_m, Lkv=Lp, kv_mask=None)]
+        # The teacher's fusion pass (S5: P9b + LM head, small M) is needed only by the LM loss at the very end: it runs on
+        # the side stream underneath the features / ITA / S6 work below.
+        side5 = self._fork()
+        with self._on(side5):
+            y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
+            logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
+            if pk:                                               # the loss kernel indexes [B, Lt, V]
+                logits_m = torch.zeros(B * Lt, logits_m.shape[1], dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
 
         # ---- features, similarity banks, ITA loss and its gradient w.r.t. the student features (:92-131)
         bank = self._banks(B)
@@ -180,6 +193,7 @@ class PretrainStep(Engine):
         ops.enqueue(feat_tm, P.buffers["text_queue"], *bank["text"], ptr, Bloc=B, advance=True)
 
         # ---- LM loss (:211-238)
+        self._join(side5)
         hid10 = ytext[ytext.shape[0] - B * Lt:]
         logits, lmsv = self.lm_head_fwd("text_encoder.", ct, hid10, save)
         ops.lm_loss(logits, logits_m, ids32, nseq=B, L=Lt, V=ct.vocab_size, alpha=self.alpha, ws=self.icount[0:1], losses=self.losses,
@@ -292,22 +306,24 @@ class PretrainStep(Engine):
                 ops.acc_rows(d_te[:M].view(B, Lt * H)[:, :H], dcls)
         ops.axpy_scalar(P.g("temp").view(1), self.dtemp_ita, scale_ptr=gs[2:3])
 
-        # ---- S2 backward (text layers 0..f-1 on P2 | P10a) and the text embeddings
-        dY2 = self._new(M + B * Lt, H)
-        ops.cast_f32_bf16(d_te[:M].view(-1), dY2[:M].view(-1))
-        dY2[M:].copy_(dXt_lm)
-        dX2 = self.stack_bwd("text_encoder.bert.", ct, range(0, f), T["tape2"], dY2, T["g2"])
-        if pk:                                                  # back to the dense layout of the embedding kernels
-            dense = self._zeros(2 * B * Lt, H)
-            dense[:B * Lt].index_copy_(0, pk["rows"], dX2[:M])
-            dense[B * Lt:].copy_(dX2[M:])
-            dX2 = dense
-        dz2 = self._embed_ln_bwd("text_encoder.bert.", ct, T["esv2"], dX2)
-        tp = "text_encoder.bert.embeddings."
-        ops.embed_bwd(0, dz2, nseq=2 * B, L=Lt, H=H, dpos=P.g(tp + "position_embeddings.weight"),
-                      dtype0=P.g(tp + "token_type_embeddings.weight"), ids=T["ids2"], dword=P.g(tp + "word_embeddings.weight"))
+        # ---- S2 backward (text layers 0..f-1 on P2 | P10a) and the text embeddings -- on the side stream, next to ...
+        side = self._fork()
+        with self._on(side):
+            dY2 = self._new(M + B * Lt, H)
+            ops.cast_f32_bf16(d_te[:M].view(-1), dY2[:M].view(-1))
+            dY2[M:].copy_(dXt_lm)
+            dX2 = self.stack_bwd("text_encoder.bert.", ct, range(0, f), T["tape2"], dY2, T["g2"])
+            if pk:                                              # back to the dense layout of the embedding kernels
+                dense = self._zeros(2 * B * Lt, H)
+                dense[:B * Lt].index_copy_(0, pk["rows"], dX2[:M])
+                dense[B * Lt:].copy_(dX2[M:])
+                dX2 = dense
+            dz2 = self._embed_ln_bwd("text_encoder.bert.", ct, T["esv2"], dX2)
+            tp = "text_encoder.bert.embeddings."
+            ops.embed_bwd(0, dz2, nseq=2 * B, L=Lt, H=H, dpos=P.g(tp + "position_embeddings.weight"),
+                          dtype0=P.g(tp + "token_type_embeddings.weight"), ids=T["ids2"], dword=P.g(tp + "word_embeddings.weight"))
 
-        # ---- S1 backward (PV encoder on P1 | P11) and the PV embedding
+        # ---- ... S1 backward (PV encoder on P1 | P11) and the PV embedding
         dY1 = self._new(2 * B * Lp, H)
         ops.cast_f32_bf16(d_pe.view(-1), dY1[:B * Lp].view(-1))
         dY1[B * Lp:].copy_(dXpv[3 * B:].reshape(B * Lp, H))
@@ -318,4 +334,5 @@ class PretrainStep(Engine):
                       dtype0=P.g(pp + "token_type_embeddings.weight"), pv_x=T["prop"], pv_mask=T["mpm_mask"], src_mod=B,
                       d_w=P.g("property_embed.weight"), d_b=P.g("property_embed.bias"), d_cls=P.g("property_cls"),
                       d_masktok=P.g("property_mask"))
+        self._join(side)
         self.tape = None
