@@ -479,3 +479,49 @@ def test_packed_text_passes_equal_dense_layout(env):
     m = _mk(SPMM, cfg, sd).train()
     assert m.engine._pack_plan(holes.to(torch.int32).cuda(), B, Lt) is None
     assert m.engine._pack_plan(mask.to(torch.int32).cuda(), B, Lt)["M"] == int(mask.sum())
+
+
+def test_full_depth_training_steps_match_oracle(env):
+    """Three optimiser steps of the published architecture (12 text layers / 6 fusion + 6 PV layers, H=768) against the
+    fp32 CPU oracle's trainer: forward, backward, clip, AdamW (reference lr 5e-5), EMA, queue.  Dropout off, recorded
+    bernoulli / negative draws.  Step 0 is a pure forward/backward comparison (losses 1e-3, gradient norm 1e-3 relative).
+    Later steps see parameters that both sides updated: Adam's first steps move every weight by +-lr whatever the gradient's
+    size, so sign flips of near-zero bf16 gradients are amplified -- the unbounded regression loss (5*MPM, which jumps from 6.6
+    to 23 at this random init) is the sensitive one.  Stated tolerances after an update: MLM / ITA / ITM 1 %, 5*MPM 10 %,
+    gradient norm 12 %."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env, layers=(12, 6, 6), Q=64)
+    for c in (cfg.text, cfg.prop, ocfg.text, ocfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20,
+             'cooldown_epochs': 0}
+    tc = {'embed_dim': 256, 'temp': 0.07, 'queue_size': 64, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
+          'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
+    sd = O.init_state_dict(ocfg, seed=17)
+    m = SPMM(config=tc, spmm_config=cfg, loader_len=100)
+    m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+    m.train()
+    ocfg.alpha = 0.4
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    tr = O.OracleTrainer(sd, ocfg, sched, tc['optimizer'], loader_len=100)
+    B, Lt = 8, 32
+    opt = m.optimizers()
+    for s in range(3):
+        prop, ids, mask = O.synthetic_batch(B, Lt, seed=100 + s)
+        mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(s))
+        neg = (torch.arange(B).roll(1 + s), torch.arange(B).roll(2 + s))
+        bidx = 50 + s                                              # alpha ramp mid-way, no scheduler event
+        ref = tr.step(prop, ids, mask, 0, bidx, mpm_mask=mpm, neg_idx=neg, train=True)
+        alpha = tc["alpha"] * min(1., bidx / 100)
+        got = m.fused_step(prop, ids, mask, alpha, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg))).cpu().numpy()
+        gn = float(opt.grad_norm)
+        print(f"step {s}: hip {got} oracle {np.array(ref)} rel {np.abs(got - ref) / np.abs(ref)} grad-norm hip {gn:.4f} oracle {float(tr.grad_norm):.4f}")
+        ref = np.array(ref)
+        if s == 0:
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=0)
+            np.testing.assert_allclose(gn, float(tr.grad_norm), rtol=2e-3)
+        else:
+            np.testing.assert_allclose(got[[0, 2, 3]], ref[[0, 2, 3]], rtol=1e-2, atol=0)
+            np.testing.assert_allclose(got[1], ref[1], rtol=0.1)
+            np.testing.assert_allclose(gn, float(tr.grad_norm), rtol=0.12)
+    assert int(m.queue_ptr) == (3 * B) % 64
