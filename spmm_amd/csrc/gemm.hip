@@ -1164,6 +1164,7 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   return SPMM_OK;
 }
 static int g_krot = 0;
+static int g_force_tile = 0;          // 0: heuristic, 1/2/3: force the 128x128 / 256x128 / 256x256 kernel (tuning sweeps)
 static int g_tile_order = 3;          // row-major, split into 2 column groups when N >= 2048 and K <= 1024: lowest measured L2-miss traffic (profiles/r01_pmc_nt_gemm.txt); launch time is order-insensitive
 static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
 static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
@@ -1280,10 +1281,36 @@ extern "C" void spmm_gemm_set_variant(int v) {
   if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
   if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
   if (v == 700 || v == 701) { g_krot = v - 700; return; }
+  if (v >= 800 && v <= 803) { g_force_tile = v - 800; return; }
   if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
   else g_v2_variant = v;
+}
+
+// Which tile kernel for an M x N output?  Per-tile efficiency (bytes through the per-CU load path per FLOP) favours the big
+// tile, wave quantisation on 256 CUs favours the small one: score = efficiency x fill of the last wave.  The 256x256 and
+// 256x128 kernels hold one workgroup per CU (128 / 144 KiB LDS); the 128x128 kernel (32 KiB) runs several per CU, so its fill
+// is smooth.  Constants from tools/bench_gemm_tiles.py.  Used for the decoder's shapes (M = beams x molecules < 6000), e.g.
+// 5000x768x3072: 640 TF with 128x128 vs 472 with 256x128 vs 292 with 256x256.
+static int pick_tile(int M, int N, int epi) {
+  const bool bf = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD;
+  if (M >= 6000) {
+    // Training-step shapes keep the simple rule (256x256 whenever it gives >= 96 tiles): inside the step the small-M GEMMs run
+    // next to another stream's kernels, which fill the CUs a coarse tiling leaves idle, and the per-tile efficiency of the big
+    // tile wins -- the score below made the whole step 4 % slower (1 497 vs 1 560 molecules/s) although it wins in isolation.
+    const long t3 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    if (bf && t3 >= 96) return 3;
+    return (epi != EPI_F32_ATOMIC) ? 2 : 1;
+  }
+  auto tiles = [&](int bm, int bn) { return (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  auto fill = [](double t) { const double w = (double)(long)((t + 255) / 256); return t / (256.0 * w); };
+  const double t3 = tiles(256, 256), t2 = tiles(256, 128), t1 = tiles(128, 128);
+  const double s3 = bf ? 1.00 * fill(t3) : 0.0;
+  const double s2 = (M >= 512 && epi != EPI_F32_ATOMIC) ? 0.85 * fill(t2) : 0.0;
+  const double s1 = 0.80 * (t1 < 256 ? t1 / 256.0 : 1.0);
+  if (s3 >= s2 && s3 >= s1) return 3;
+  return s2 >= s1 ? 2 : 1;
 }
 
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
@@ -1310,8 +1337,8 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum; p.krot = g_krot;
   SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
-    const long tiles3 = (long)((M + BM3 - 1) / BM3) * ((N + BN3 - 1) / BN3);
-    if ((tiles3 >= 96 || g_v2_variant == 101) && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {
+    const bool want3 = g_force_tile ? g_force_tile == 3 : (pick_tile(M, N, epi) == 3 || g_v2_variant == 101);
+    if (want3 && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {
       int rc3 = launch_v3(epi, p, stream);
       if (rc3 > 0) return rc3;
       if (rc3 == 0) {
@@ -1320,7 +1347,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
       }
     }
   }
-  if (g_gemm_use_glds == 1 && splits == 1 && epi != EPI_F32_ATOMIC && M >= 512) {   // v2: 256x128 tile, 3-stage ring
+  if (g_gemm_use_glds == 1 && splits == 1 && epi != EPI_F32_ATOMIC && M >= 512 && (g_force_tile ? g_force_tile != 1 : pick_tile(M, N, epi) != 1)) {   // v2: 256x128 tile, 3-stage ring
     int rc2 = launch_v2(epi, p, stream);
     if (rc2 > 0) return rc2;
     if (rc2 == 0) {
