@@ -135,6 +135,12 @@ def main():
             torch.distributed.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+        if os.environ.get("SPMM_FORCE_DIST") == "1":
+            # single-rank RCCL group: drives the real collective code path (overlapped per-layer all-reduce on RCCL's stream,
+            # feature all-gather) on a one-GPU box; used by tests/test_step_gpu.py
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     dev = torch.device(f"cuda:{torch.cuda.current_device()}")
 
     from spmm_amd import ops

@@ -24,7 +24,7 @@ def world():
 
 def all_gather_features(t: torch.Tensor) -> torch.Tensor:
     ws = world()
-    if ws == 1:
+    if ws == 1 and not (os.environ.get("SPMM_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -105,7 +105,8 @@ class OverlappedGradSync:
 
 def grad_sync_fn(store=None):
     """None on a single rank; otherwise the overlapped reducer when the parameter layout is given, else the plain bucketed one."""
-    if world() == 1:
+    forced = os.environ.get("SPMM_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()
+    if world() == 1 and not forced:
         return None
     if store is not None and os.environ.get("SPMM_GRAD_OVERLAP", "1") != "0":
         return OverlappedGradSync(store.order, store.offset, store.total)
