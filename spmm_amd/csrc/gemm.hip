@@ -40,6 +40,7 @@ struct GemmP {
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range: 0 n-fastest, 1 m-fastest, 2 blocked (8 m-panels x GN n-tiles)
   int krot;                  // v3: tiles start their k loop at different slices (de-synchronises the CUs' walks over shared W lines)
+  int stagger;               // v3: every other first-wave workgroup sleeps stagger x ~3.9 us so the chip's epilogue store bursts interleave
 };
 
 // LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
@@ -582,6 +583,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
   const int m0 = tile_m * BM3, n0 = tile_n * BN3;
   const int nk = p.K / BK;
+  if (p.stagger && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   f32x16 acc[2][2][2];      // [m half][ni][mi]
 #pragma unroll
@@ -671,6 +675,112 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
     epilogue_bf16<EPI, ABL == 4>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v7: the 256x256x64 tile with FOUR waves (2 x 2), one per SIMD, each owning a 128x128 wave tile = 4 x 4 MFMA tiles
+// (256 fp32 accumulators; the 512-register budget of a lone wave per SIMD holds them next to two sets of fragments).
+// Why: in v3 every k-step pulls (128 + 64) x 128 B of fragments per wave x 8 waves = 192 KiB out of LDS while the LDS-DMA
+// writes 64 KiB into it -- 2048 clocks of the 128 B/clk LDS port, the same as the 2062 MFMA clocks of the step, so the
+// LDS port is a co-bottleneck.  128x128 wave tiles read (128 + 128) x 128 B x 4 = 128 KiB (1024 + 512 clocks).  With a
+// single wave per SIMD there is no other wave to hide LDS latency, so the fragments of k-group kk+1 are fetched before the
+// 16 MFMAs of kk are issued (explicit double buffer).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_v7_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem7[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves, wave tile 128 (m) x 128 (n)
+  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  int tile_m, tile_n;
+  tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
+  const int m0 = tile_m * BM3, n0 = tile_n * BN3;
+  const int nk = p.K / BK;
+
+  f32x16 acc[2][2][2][2];      // [n half][m half][ni][mi]: acc[hn][hm] is the 64x64 block the shared epilogue takes
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][i][j][r] = 0.f;
+
+  // Per-thread source pointers of its 16 chunks of a stage (8 of A, 8 of W), computed once: a k-step only adds BK elements.
+  // Chunk c of an operand: tile row (c*256 + tid) >> 3, physical 16-B slot (tid & 7), logical slot swizzled on the source.
+  const bf16* gsrc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int op = c >> 3, cc = c & 7;
+    const int id = cc * 256 + tid;
+    const int row = id >> 3, ps = id & 7;
+    const int ls = ps ^ ((row >> 1) & 7);
+    const int nrows = op == 0 ? p.M : p.N;
+    int grow = (op == 0 ? m0 : n0) + row;
+    grow = grow < nrows ? grow : nrows - 1;
+    gsrc[c] = (op == 0 ? p.A + (long)grow * p.lda : p.W + (long)grow * p.ldw) + ls * 8;
+  }
+  auto dma = [&](int c, int kt) {                       // chunk c of stage kt
+    char* tile = smem7 + (kt & 1) * STAGE3_BYTES + (c >> 3) * T3_BYTES;
+    const int wave_base = __builtin_amdgcn_readfirstlane(((c & 7) * 256 + (tid & ~63)) * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gsrc[c] + kt * BK), (LDS_AS void*)(tile + wave_base), 16, 0, 0);
+  };
+  auto frags = [&](const char* As, const char* Ws, int kk, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+    const int s = kk * 2 + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ar = wm * 128 + i * 32 + (lane & 31);
+      af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
+      const int wr = wn * 128 + i * 32 + (lane & 31);
+      wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+    }
+  };
+
+#pragma unroll
+  for (int c = 0; c < 16; ++c) dma(c, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
+    const bool more = kt + 1 < nk;
+    const char* As = smem7 + (kt & 1) * STAGE3_BYTES;
+    const char* Ws = As + T3_BYTES;
+    bf16x8 af[2][4], wf[2][4];
+    frags(As, Ws, 0, af[0], wf[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk + 1 < 4) frags(As, Ws, kk + 1, af[(kk + 1) & 1], wf[(kk + 1) & 1]);
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) {
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+          acc[n4 >> 1][m4 >> 1][n4 & 1][m4 & 1] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][n4], af[kk & 1][m4], acc[n4 >> 1][m4 >> 1][n4 & 1][m4 & 1], 0, 0, 0);
+        // the lone wave of this SIMD also has to issue the next stage's DMA: two instructions behind each of the first
+        // eight MFMA groups of the k-step, so the matrix pipe keeps running while the address path takes them
+        if (kk < 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            dma((kk * 4 + n4) * 2, kt + 1);
+            dma((kk * 4 + n4) * 2 + 1, kt + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                     // all waves done with the staging buffers
+  char* wt = smem7 + wave * 16384;                     // 16 KiB private epilogue region per wave
+#pragma unroll
+  for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+      epilogue_bf16<EPI>(p, acc[hn][hm], wt, m0 + wm * 128 + hm * 64, n0 + wn * 128 + hn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1164,6 +1274,7 @@ int launch_v3_il(const GemmP& p, hipStream_t st) {
   return SPMM_OK;
 }
 static int g_krot = 0;
+static int g_stagger = 0;
 static int g_force_tile = 0;          // 0: heuristic, 1/2/3: force the 128x128 / 256x128 / 256x256 kernel (tuning sweeps)
 static int g_tile_order = 3;          // row-major, split into 2 column groups when N >= 2048 and K <= 1024: lowest measured L2-miss traffic (profiles/r01_pmc_nt_gemm.txt); launch time is order-insensitive
 static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
@@ -1184,9 +1295,33 @@ int launch_v3_one(const GemmP& p, hipStream_t st) {
   if (EPI == EPI_BF16 && g_v3_abl == 5) return launch_v3_abl<5>(p, st);
   return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
 }
+static int g_use_v7 = 0;           // 1: four-wave 128x128-wave-tile variant of the 256x256 kernel
+template <int EPI>
+int launch_v7_one(const GemmP& p, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+    if (e != hipSuccess) {
+      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
+      return SPMM_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
+  hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI>), grid, dim3(256), LDS3_BYTES, st, p);
+  return SPMM_OK;
+}
 static int g_use_v4 = 0;
 static int g_use_v5 = 0;           // 0 (default): per-tile v3; 1: persistent v5; 2: persistent + wave-specialised v6 -- all three measure the same
 int launch_v3(int epi, const GemmP& p, hipStream_t st) {
+  if (g_use_v7 && g_v3_abl == 0) {
+    switch (epi) {
+      case EPI_BF16: return launch_v7_one<EPI_BF16>(p, st);
+      case EPI_GELU: return launch_v7_one<EPI_GELU>(p, st);
+      case EPI_GELU_GRAD: return launch_v7_one<EPI_GELU_GRAD>(p, st);
+      default: return -1;
+    }
+  }
   if (g_use_v5 == 2 && !g_use_v4 && g_v3_abl == 0 && p.N <= 4096) {
     switch (epi) {
       case EPI_BF16: return launch_v6_one<EPI_BF16>(p, st);
@@ -1282,6 +1417,8 @@ extern "C" void spmm_gemm_set_variant(int v) {
   if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
   if (v == 700 || v == 701) { g_krot = v - 700; return; }
   if (v >= 800 && v <= 803) { g_force_tile = v - 800; return; }
+  if (v >= 900 && v <= 915) { g_stagger = v - 900; return; }
+  if (v == 1000 || v == 1001) { g_use_v7 = v - 1000; return; }
   if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
   if (v == 200) g_v3_interleave = 0;
   else if (v == 201) g_v3_interleave = 1;
@@ -1334,7 +1471,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum; p.krot = g_krot;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum; p.krot = g_krot; p.stagger = g_stagger;
   SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
     const bool want3 = g_force_tile ? g_force_tile == 3 : (pick_tile(M, N, epi) == 3 || g_v2_variant == 101);

@@ -54,13 +54,14 @@ def test_gemm_bf16_bias(ops, staging, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072), (70000, 768, 128)])
-@pytest.mark.parametrize("use_v4", [0, 1, 2, 3])   # 0: persistent v5, 1: v4 ring, 2: per-tile v3, 3: wave-specialised persistent v6
+@pytest.mark.parametrize("use_v4", [0, 1, 2, 3, 4])   # 0: persistent v5, 1: v4 ring, 2: per-tile v3, 3: wave-specialised persistent v6, 4: four-wave v7
 def test_gemm_v3_256x256_tile(ops, M, N, K, use_v4):
     """The 256x256-tile kernel is only picked for large problems; force it (variant 101) on small/ragged shapes too."""
     from spmm_amd._lib import lib
     lib().cdll.spmm_gemm_set_variant(101)
     lib().cdll.spmm_gemm_set_variant(400 + (use_v4 == 1))
-    lib().cdll.spmm_gemm_set_variant(600 + {0: 1, 1: 0, 2: 0, 3: 2}[use_v4])
+    lib().cdll.spmm_gemm_set_variant(600 + {0: 1, 1: 0, 2: 0, 3: 2, 4: 0}[use_v4])
+    lib().cdll.spmm_gemm_set_variant(1000 + (use_v4 == 4))
     try:
         A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
         bias = rnd(N, seed=23, dtype=torch.float32)
@@ -79,6 +80,7 @@ def test_gemm_v3_256x256_tile(ops, M, N, K, use_v4):
         lib().cdll.spmm_gemm_set_variant(0)
         lib().cdll.spmm_gemm_set_variant(400)
         lib().cdll.spmm_gemm_set_variant(600)
+        lib().cdll.spmm_gemm_set_variant(1000)
 
 
 def test_gemm_strided_operands_and_residual(ops):
