@@ -181,14 +181,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const float inv = 1.f / sum;
   if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
   if (p.drop_thresh16) {
-    const uint64_t seed = *p.seed_ptr ^ p.seed_salt;
-    const uint64_t rowbase = (((uint64_t)seq * p.nH + h) * p.Lq + q) * (uint64_t)p.Lkv;
+    const uint32_t rowkey = drop_rowkey(*p.seed_ptr ^ p.seed_salt, ((uint64_t)seq * p.nH + h) * p.Lq + q);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        st[t][r] = drop_keep(seed, rowbase + kv, p.drop_thresh16) ? st[t][r] * p.drop_scale : 0.f;
+      for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
+        const uint32_t pr = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
+        const uint32_t r0 = drop_pair(rowkey, pr), r1 = drop_pair(rowkey, pr + 1);
+        st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] * p.drop_scale : 0.f;
+        st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] * p.drop_scale : 0.f;
+        st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] * p.drop_scale : 0.f;
+        st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] * p.drop_scale : 0.f;
       }
   }
   // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward
-constexpr int BWD_LDS = 4 * TILE + 3 * 128 * 4;
+constexpr int BWD_LDS = 4 * TILE + 4 * 128 * 4;
 
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   float* mb = (float*)(smem + 4 * TILE);
   float* lse = mb + 128;
   float* Dq = lse + 128;
+  uint32_t* rk = (uint32_t*)(Dq + 128);      // dropout row keys of the 128 query rows
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   const bool drop = p.drop_thresh16 != 0;
   const uint64_t seed = drop ? (*p.seed_ptr ^ p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
+  if (drop && tid < 128) rk[tid] = drop_rowkey(seed, headbase + tid);
   const int NTq = (Lq + 31) >> 5;
 
   // ---- phase A: wave owns query tile `wave` -> D[q] = sum_kv P dP (fp32, exactly consistent with ds) and dQ.
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       dof[kk] = ld_rm(dOs, q, kk * 2 + g);
     }
     const float lq = lse[q];
+    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) : 0u;
     f32x16 st[NT], dp[NT];
     float dloc = 0.f;
 #pragma unroll
@@ -282,6 +288,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
         dp[t] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[t]);
       }
+      uint32_t keepbits = 0xffffu;                     // bit r: probability (q, kv(r)) survived dropout in forward
+      if (drop) {
+        keepbits = 0;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const uint32_t pr2 = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
+          const uint32_t r0 = drop_pair(rowkey, pr2), r1 = drop_pair(rowkey, pr2 + 1);
+          keepbits |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
+          keepbits |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
+          keepbits |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);
+          keepbits |= ((r1 >> 16) >= p.drop_thresh16 ? 8u : 0u) << (gq * 4);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
           const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
           pr = __expf(s - lq);
           dpr = dp[t][r];
-          if (drop) dpr = drop_keep(seed, (headbase + q) * (uint64_t)p.Lkv + kv, p.drop_thresh16) ? dpr * p.drop_scale : 0.f;
+          if (drop) dpr = ((keepbits >> r) & 1u) ? dpr * p.drop_scale : 0.f;
         }
         st[t][r] = pr;
         dp[t][r] = dpr;
@@ -355,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
           float dpr = dp[r];
           pd = pr;
           if (drop) {
-            const bool keep = drop_keep(seed, (headbase + q) * (uint64_t)p.Lkv + kv, p.drop_thresh16);
+            const uint32_t rr = drop_pair(rk[q], (uint32_t)kv >> 1);
+            const bool keep = ((kv & 1) ? (rr >> 16) : (rr & 0xffffu)) >= p.drop_thresh16;
             pd = keep ? pr * p.drop_scale : 0.f;
             dpr = keep ? dpr * p.drop_scale : 0.f;
           }

@@ -53,6 +53,13 @@ __device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
   uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
   return mix32((lo ^ s0) + (hi ^ s1) * 0x9E3779B1u);
 }
+// Attention-probability dropout: the element (row, kv) uses half (kv & 1) of drop_pair(drop_rowkey(seed, row), kv >> 1).
+// One 32-bit key per query row (hashed once per lane) and then 32-bit arithmetic only: a lane that owns four consecutive
+// keys needs two hashes for them.  (The 64-bit counter form below cost 25-30 % of the attention kernels' time.)
+__device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint64_t row) {
+  return mix32((uint32_t)row ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(row >> 32) * 0x9E3779B1u);
+}
+__device__ __forceinline__ uint32_t drop_pair(uint32_t rowkey, uint32_t pair) { return mix32(rowkey + pair); }
 // keep-decision for element idx; thresh16 = round(p * 65536)
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
   uint32_t r = rng_pair(seed, idx >> 1);
