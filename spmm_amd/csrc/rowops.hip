@@ -6,6 +6,7 @@
 // :447-451; BertEmbeddings.forward :193-220; SPMM.forward PV embed/mask/CLS concat SPMM_models.py:82-88;
 // BertPredictionHeadTransform LayerNorm :675; property_mtr_head LayerNorm SPMM_models.py:41.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/spmm_hip.h"
 
 namespace {
@@ -536,7 +537,8 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_bwd: rows=%ld H=%d", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
-  if (g > 2048) g = 2048;
+  static const long gmax = getenv("SPMM_LN_BWD_GRID") ? atol(getenv("SPMM_LN_BWD_GRID")) : 1024;   // 4 workgroups per CU: measured best of 256..4096 (fewer same-address atomics at the end than 2048)
+  if (g > gmax) g = gmax;
   const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
   const float ds = 1.f / (1.f - dropout_p);
   if (H <= 768)
