@@ -55,7 +55,6 @@ class PretrainStep(Engine):
         pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None) else None
         M = pk["M"] if pk else B * Lt
         ids2 = torch.cat([ids32, ids32])
-        ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)                     # :99 / :266-269
         side = self._fork()
         with self._on(side):
             x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
@@ -70,7 +69,14 @@ class PretrainStep(Engine):
             y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
             text_embeds, hidden10 = y2[:M], y2[M:]
         side_m = self._fork(1)
+        ema_done = None
         with self._on(side_m):
+            # EMA of the momentum parameters (:99 / :266-269) at the head of the momentum stream: the student chains do not
+            # read them, so they start at once; the PV momentum pass below waits on `ema_done`
+            ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)
+            if side_m is not None:
+                ema_done = torch.cuda.Event()
+                ema_done.record(side_m)
             # momentum text branch (:104-105, :215-222), no tape
             x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
             if pk:
@@ -86,6 +92,8 @@ class PretrainStep(Engine):
         g1 = [Group(0, 2 * B, Lp, None, B)]
         y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save)
         prop_embeds, prop_embeds_causal = y1[:B * Lp], y1[B * Lp:]
+        if ema_done is not None:
+            torch.cuda.current_stream().wait_event(ema_done)
         x3, _ = self.embed_pv("property_encoder_m.", cp, prop, mpm_mask, B, B, False)
         prop_embeds_m, _ = self.stack_fwd("property_encoder_m.", cp, range(cp.num_hidden_layers), False, x3,
                                           [Group(0, B, Lp, None, B)], False)
