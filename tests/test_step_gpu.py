@@ -544,3 +544,44 @@ def test_rccl_code_path_single_rank(env):
     assert all(np.isfinite(outs[0]))
     # two separate 4-step runs: fp32 atomic accumulation order (bias / LayerNorm gradients) makes them agree to ~5e-4 only
     np.testing.assert_allclose(outs[0], outs[1], rtol=3e-3, atol=0)
+
+
+@pytest.mark.parametrize("case", ["min_len", "full_len_128", "odd_33", "mask_holes", "one_long_rest_short"])
+def test_edge_shapes_match_oracle(env, case):
+    """Ragged and extreme batches, losses vs the fp32 oracle (tiny config, dropout off, fixed draws): the shortest sequences
+    the tokenizer can produce ([CLS] x [SEP]), the longest the kernels take (128, no padding at all: dense path), an odd
+    length, an attention mask with holes (not a prefix: the packed layout must fall back to dense), and one full-length row
+    among minimal ones (maximum padding).  Tolerance 2e-2 absolute as for the golden forwards."""
+    O, SPMM, tiny_config, *_ = env
+    ocfg, cfg = O.tiny_cfg(), tiny_config()
+    for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.closed_form_state_dict(ocfg)
+    g = torch.Generator().manual_seed(5)
+    B, Lt = {"min_len": (4, 3), "full_len_128": (4, 128), "odd_33": (8, 33), "mask_holes": (4, 16), "one_long_rest_short": (8, 64)}[case]
+    prop = torch.randn(B, 53, generator=g)
+    ids = torch.randint(4, 300, (B, Lt), generator=g)
+    ids[:, 0] = 2
+    lens = torch.full((B,), Lt)
+    if case == "odd_33":
+        lens = torch.randint(3, Lt + 1, (B,), generator=g); lens[0] = Lt
+    if case == "one_long_rest_short":
+        lens = torch.full((B,), 3); lens[0] = Lt
+    for i in range(B):
+        ids[i, lens[i] - 1] = 3
+        ids[i, lens[i]:] = 0
+    mask = (ids != 0).long()
+    if case == "mask_holes":
+        mask[1, 5] = 0
+        mask[2, 3:6] = 0
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=g)
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
+    m = _mk(SPMM, cfg, sd).train()
+    losses = m(prop, ids, mask, alpha=0.25, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+    sum(losses).backward()
+    got = np.array([float(x) for x in losses])
+    with torch.no_grad():
+        ref = np.array([float(x) for x in O.spmm_forward(sd, ocfg, prop, ids, mask, 0.25, mpm_mask=mpm, neg_idx=neg, train=True)])
+    print(case, "hip", got, "oracle", ref)
+    assert np.isfinite(got).all() and torch.isfinite(m.store.grad).all()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
