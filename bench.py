@@ -193,7 +193,7 @@ def main():
 
     # ---- per-kernel timing with HIP events on the launch stream: same step, every GEMM / cross-attention launch bracketed.
     roof, xattn = None, None
-    if not args.no_kernel_timing and rank == 0:
+    if not args.no_kernel_timing:      # every rank runs the instrumented steps (they contain the collectives); rank 0 reports
         ev = {"gemm": [], "xattn": []}
         orig_gemm, orig_attn = ops.gemm_nt, ops.attn_fwd
         stream = torch.cuda.current_stream()
