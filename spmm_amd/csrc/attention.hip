@@ -223,13 +223,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 constexpr int BWD_LDS = 4 * TILE + 4 * 128 * 4;
 
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: ceil(max Lq / 32) tiles): a 54 x 54 head takes 34 KiB
+  // instead of 66, and with the 160-VGPR budget of the NT <= 2 instances three workgroups share a CU instead of two.
+  const int kvb = NT * 32 * 128, qb = ((p.Lq + 31) >> 5) * 32 * 128;
   char* Ks = smem;
-  char* Vs = smem + TILE;
-  char* Qs = smem + 2 * TILE;
-  char* dOs = smem + 3 * TILE;
-  float* mb = (float*)(smem + 4 * TILE);
+  char* Vs = smem + kvb;
+  char* Qs = smem + 2 * kvb;
+  char* dOs = Qs + qb;
+  float* mb = (float*)(dOs + qb);
   float* lse = mb + 128;
   float* Dq = lse + 128;
   uint32_t* rk = (uint32_t*)(Dq + 128);      // dropout row keys of the 128 query rows
@@ -490,11 +493,13 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
+  const int nt_b = (Lkv + 31) / 32 > 4 ? 4 : (Lkv + 31) / 32;
+  const size_t lds_b = (size_t)2 * nt_b * 32 * 128 + (size_t)2 * ((Lq + 31) / 32) * 32 * 128 + 4 * 128 * 4;
   switch ((Lkv + 31) / 32) {
-    case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
-    case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
-    case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
-    default: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), BWD_LDS, stream, p); break;
+    case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+    case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+    case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+    default: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
   }
   SPMM_LAUNCH_CHECK("spmm_attn_bwd");
   return SPMM_OK;
