@@ -74,16 +74,20 @@ void spmm_gemm_set_variant(int v);
  * q_row0/q_len ([nseq]) and kv_row0/kv_len ([number of key/value sources]), optional pairs: packed variable-length
  * layouts -- sequence s owns q_len[s] <= Lq rows from row q_row0[s] of Q/O/dO/dQ, source u owns kv_len[u] <= Lkv rows from
  * row kv_row0[u] of K/V (and of dK/dV unless kv_seq is given).  Rows of padding tokens whose outputs never reach a loss
- * (SPMM_models.py:139-206 read only position 0 of those passes) are then simply not computed. */
+ * (SPMM_models.py:139-206 read only position 0 of those passes) are then simply not computed.
+ * Sequences longer than 128 run as <= 128-long query / key chunks over several launches (spmm_amd/ops.py::attn_fwd_long):
+ * q_off / kv_off give the chunk's position for the causal mask; backward d_mode 1 writes only D[q] = sum_kv P dP of this key
+ * chunk to Dbuf [nseq, nH, Lq], d_mode 2 reads the D summed over all key chunks from Dbuf (0: computed in-kernel). */
 int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
                   const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len, void* O,
                   long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross, float dropout_p,
-                  const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+                  const uint64_t* seed_ptr, uint64_t seed_salt, int q_off, int kv_off, spmm_stream_t stream);
 int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
                   const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len,
                   const void* O, long ldo, const float* LSE, const void* dO, long lddo, void* dQ,
                   long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from,
-                  int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, spmm_stream_t stream);
+                  int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, int q_off, int kv_off, int d_mode,
+                  float* Dbuf, spmm_stream_t stream);
 /* out[u] = sum over k in [start[u], start[u+1]) of src[list[k]]  (rows of W bf16 elements, fp32 accumulation, fixed order).
  * Folds the per-query-sequence dK/dV of a cross-attention whose sequences share key/value sources (kv_seq) back onto the
  * unique sources before the K/V weight- and data-gradient GEMMs. */

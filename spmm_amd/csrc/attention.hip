@@ -36,6 +36,10 @@ struct AttnP {
   // source u owns kv_len[u] <= Lkv rows starting at kv_row0[u].  Null = dense layout (row = seq*L + pos).  LSE, kmask and
   // the dropout counter keep the dense [.., Lq, Lkv] indexing, so packed and padded runs draw the same masks.
   const int* q_row0; const int* q_len; const int* kv_row0; const int* kv_len;
+  // Sequences longer than 128 are processed as <= 128-long chunks of queries and keys by several launches (ops.py): q_off /
+  // kv_off are the chunk's positions inside the sequence (causal mask); d_mode 1 = only write D[q] = sum_kv P dP of this key
+  // chunk to Dbuf, 2 = take D[q] (summed over all key chunks by the caller) from Dbuf instead of computing it.
+  int q_off, kv_off, d_mode; float* Dbuf;
   bf16* O; long ldo;              // fwd output (unused by backward)
   float* LSE;                     // [nseq, nH, Lq]
   const bf16* dO; long lddo;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) {
       const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
       const float mv = mb[kv];
-      const float s = mv < 0.f ? -INFINITY : st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+      const float s = mv < 0.f ? -INFINITY : st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
       st[t][r] = s;
       mx = fmaxf(mx, s);
     }
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         const float mv = mb[kv];
         float pr = 0.f, dpr = 0.f;
         if (mv >= 0.f && q < Lq) {
-          const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+          const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
           pr = __expf(s - lq);
           dpr = dp[t][r];
           if (drop) dpr = ((keepbits >> r) & 1u) ? dpr * p.drop_scale : 0.f;
@@ -321,6 +325,11 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
       }
     }
     dloc += __shfl_xor(dloc, 32, 64);
+    if (p.d_mode == 1) {
+      if (g == 0 && q < Lq) p.Dbuf[headbase + q] = dloc;
+    } else if (p.d_mode == 2) {
+      dloc = q < Lq ? p.Dbuf[headbase + q] : 0.f;
+    }
     if (g == 0) Dq[q] = dloc;
     f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         dq[1] = MFMA32(kf[1], dsf, dq[1]);
       }
     }
-    if (q < Lq) {
+    if (q < Lq && p.d_mode != 1) {
       bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
                         dq[dt][gq * 4 + 3] * 0.125f);
     }
   }
+  if (p.d_mode == 1) return;   // partial-D pass: nothing else is written
   __syncthreads();   // D[q] of every query tile is in LDS
 
   // ---- phase B: wave owns kv tile `wave` -> dK, dV   (S[q][kv]: lane = kv column, registers = q rows)
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         float pd = 0.f, ds = 0.f;
         if (mv >= 0.f && q < Lq) {
-          const float sc = s[r] * 0.125f + score_bias(mv > 0.5f, causal, q, kv, p.mask_neg);
+          const float sc = s[r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
           const float pr = __expf(sc - lse[q]);
           float dpr = dp[r];
           pd = pr;
@@ -430,7 +440,7 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
                              const int* kmask, const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0,
                              const int* kv_len, void* O, long ldo, float* LSE, int nseq, int nH, int Lq,
                              int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
-                             uint64_t seed_salt, hipStream_t stream) {
+                             uint64_t seed_salt, int q_off, int kv_off, hipStream_t stream) {
   int rc = check_common("spmm_attn_fwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
   if (rc) return rc;
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_fwd: dropout needs a device seed");
@@ -439,6 +449,7 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
   p.kmask = kmask; p.kv_seq = kv_seq; p.q_row0 = q_row0; p.q_len = q_len; p.kv_row0 = kv_row0; p.kv_len = kv_len;
+  p.q_off = q_off; p.kv_off = kv_off;
   p.O = (bf16*)O; p.ldo = ldo; p.LSE = LSE; p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;
   p.causal_from = is_cross ? nseq : causal_from;
   p.mask_neg = is_cross ? -3.4028234663852886e38f : -10000.f;
@@ -463,12 +474,13 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
                              const int* kv_len, const void* O, long ldo, const float* LSE, const void* dO,
                              long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq,
                              int Lkv, int causal_from, int is_cross, float dropout_p, const uint64_t* seed_ptr,
-                             uint64_t seed_salt, hipStream_t stream) {
+                             uint64_t seed_salt, int q_off, int kv_off, int d_mode, float* Dbuf, hipStream_t stream) {
   int rc = check_common("spmm_attn_bwd", nseq, nH, Lq, Lkv, ldq, ldk, ldv);
   if (rc) return rc;
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr != nullptr, "spmm_attn_bwd: dropout needs a device seed");
   SPMM_CHECK_SHAPE((q_row0 == nullptr) == (q_len == nullptr) && (kv_row0 == nullptr) == (kv_len == nullptr),
                    "spmm_attn_bwd: row0 and len arrays come in pairs");
+  SPMM_CHECK_SHAPE(d_mode == 0 || ((d_mode == 1 || d_mode == 2) && Dbuf != nullptr), "spmm_attn_bwd: d_mode=%d needs Dbuf", d_mode);
   static bool attr_set = false;
   if (!attr_set) {
     const void* fns[4] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
@@ -485,6 +497,7 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;
   p.kmask = kmask; p.kv_seq = kv_seq; p.q_row0 = q_row0; p.q_len = q_len; p.kv_row0 = kv_row0; p.kv_len = kv_len;
+  p.q_off = q_off; p.kv_off = kv_off; p.d_mode = d_mode; p.Dbuf = Dbuf;
   p.O = (bf16*)O; p.ldo = ldo; p.LSE = (float*)LSE; p.dO = (const bf16*)dO; p.lddo = lddo;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
   p.nseq = nseq; p.nH = nH; p.Lq = Lq; p.Lkv = Lkv;

@@ -168,6 +168,25 @@ class Engine:
             ops.colsum_bf16(dY, gb)
         ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
 
+    # ---------------------------------------------------------------------------------------- attention launches
+    @staticmethod
+    def _attn_fwd(Q, K, V, O, lse, *, Lq, Lkv, q_row0=None, q_len=None, kv_row0=None, kv_len=None, **kw):
+        """Kernels keep <= 128 rows of Q / K / V on chip; longer (dense) sequences go through the chunked path of ops.py."""
+        if Lq <= 128 and Lkv <= 128:
+            return ops.attn_fwd(Q, K, V, O, lse, Lq=Lq, Lkv=Lkv, q_row0=q_row0, q_len=q_len, kv_row0=kv_row0, kv_len=kv_len, **kw)
+        if q_row0 is not None or kv_row0 is not None:
+            raise ValueError("packed layouts are limited to 128-token sequences")
+        return ops.attn_fwd_long(Q, K, V, O, lse, Lq=Lq, Lkv=Lkv, **kw)
+
+    @staticmethod
+    def _attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, Lq, Lkv, q_row0=None, q_len=None, kv_row0=None, kv_len=None, **kw):
+        if Lq <= 128 and Lkv <= 128:
+            return ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, Lq=Lq, Lkv=Lkv, q_row0=q_row0, q_len=q_len, kv_row0=kv_row0,
+                                kv_len=kv_len, **kw)
+        if q_row0 is not None or kv_row0 is not None:
+            raise ValueError("packed layouts are limited to 128-token sequences")
+        return ops.attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, Lq=Lq, Lkv=Lkv, **kw)
+
     # ---------------------------------------------------------------------------------------- attention block
     def _attn_block_fwd(self, pfx, c, X, groups, save, cross):
         """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source."""
@@ -185,7 +204,7 @@ class Engine:
                 lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
                 salt = self._next_salt()
                 r = g.rows
-                ops.attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
+                self._attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
                              kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt,
                              q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
                 sv["lse"].append(lse)
@@ -209,7 +228,7 @@ class Engine:
                 salt = self._next_salt()
                 r = g.rows
                 src = g.src
-                ops.attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
+                self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
                              is_cross=True, dropout_p=pa, seed=self.seed, salt=salt, kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
                              kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)
                 sv["KV"].append(KV)
@@ -246,7 +265,7 @@ class Engine:
             dQKV = self._new(M, 3 * H)
             for i, g in enumerate(groups):
                 r = g.rows
-                ops.attn_bwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H],
+                self._attn_bwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H],
                              dQKV[r, H:2 * H], dQKV[r, 2 * H:], nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L, kmask=g.kmask,
                              causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=sv["salt_a"][i],
                              q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
@@ -271,7 +290,7 @@ class Engine:
                     dKV = pool[id(src)][1][g.kv_off * g.Lkv:(g.kv_off + g.nseq) * g.Lkv]
                 else:
                     dKV = self._new(g.nseq * g.Lkv, 2 * H)
-                ops.attn_bwd(Qc[r], KV[:, :H], KV[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQc[r], dKV[:, :H], dKV[:, H:],
+                self._attn_bwd(Qc[r], KV[:, :H], KV[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQc[r], dKV[:, :H], dKV[:, H:],
                              nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask, is_cross=True, dropout_p=pa, seed=self.seed,
                              salt=sv["salt_a"][i], kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
                              kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)

@@ -10,7 +10,8 @@ e.g. d_pv2smiles_batched.py:25-27, d_smiles2pv.py:15-25, d_pv2smiles_single.py:2
     model.property_proj / text_proj / itm_head / property_mtr_head (callables)
 
 They run the same HIP kernels as the training step (inference: no tape, dropout off unless the model is in train mode).
-Sequences up to 128 tokens (the attention kernels keep a whole K/V panel on chip)."""
+Sequences up to 128 tokens run in single attention launches (a whole K/V panel on chip); longer ones (up to the position
+table) through the chunked path of `ops.attn_fwd_long`."""
 from __future__ import annotations
 
 from types import SimpleNamespace
@@ -51,8 +52,8 @@ class BertFacade:
             x, _ = eng.embed_text(self.pfx, c, input_ids.to(dev).to(torch.int32).contiguous(), nseq, L, False)
         else:
             raise ValueError("You have to specify either input_ids or inputs_embeds or encoder_embeds")
-        if L > 128:
-            raise ValueError("sequences longer than 128 tokens are not supported by the gfx950 attention kernels")
+        if L > c.max_position_embeddings:
+            raise ValueError(f"sequence length {L} exceeds the {c.max_position_embeddings} position embeddings")
         kv, Lkv, kvm = None, 0, None
         if encoder_hidden_states is not None:
             Lkv = encoder_hidden_states.shape[1]

@@ -80,22 +80,24 @@ def colsum_bf16(x, out):
 
 
 def attn_fwd(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
-             seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None):
+             seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None, q_off=0, kv_off=0):
     """Q [nseq*Lq, >=nH*64] etc. (2-D views with row strides), O [nseq*Lq, nH*64]; packed layouts via the row0/len arrays."""
     cf = nseq if causal_from is None else causal_from
     _call("spmm_attn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(q_row0),
                _p(q_len), _p(kv_row0), _p(kv_len), _p(O),
-               _row_stride(O), _p(lse), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
+               _row_stride(O), _p(lse), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, int(q_off), int(kv_off), _st())
     return O
 
 
 def attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False,
-             dropout_p=0.0, seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None):
+             dropout_p=0.0, seed=None, salt=0, kv_seq=None, q_row0=None, q_len=None, kv_row0=None, kv_len=None, q_off=0, kv_off=0,
+             d_mode=0, dbuf=None):
     cf = nseq if causal_from is None else causal_from
     _call("spmm_attn_bwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(q_row0),
                _p(q_len), _p(kv_row0), _p(kv_len), _p(O),
                _row_stride(O), _p(lse), _p(dO), _row_stride(dO), _p(dQ), _row_stride(dQ), _p(dK), _row_stride(dK), _p(dV),
-               _row_stride(dV), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, _st())
+               _row_stride(dV), nseq, nH, Lq, Lkv, cf, int(is_cross), float(dropout_p), _p(seed), salt, int(q_off), int(kv_off), int(d_mode),
+               _p(dbuf), _st())
 
 
 def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0):
@@ -276,3 +278,91 @@ def segment_sum_bf16(src, start, lst, out):
     assert start.dtype == torch.int32 and lst.dtype == torch.int32 and start.numel() == U + 1
     _call("spmm_segment_sum_bf16", _p(src), _p(start), _p(lst), _p(out), U, W, _st())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sequences longer than the 128 rows the attention kernels keep on chip (up to the 512 positions of config_bert.json):
+# queries and keys are processed in <= 128-long chunks by several launches and merged here.  Forward merges the per-key-chunk
+# outputs with their log-sum-exp weights (exact, also with dropout: the mask does not depend on the normalisation); backward
+# first sums D[q] = sum_kv P dP over the key chunks (d_mode 1), then runs the gradient launches with that D (d_mode 2).
+# Dense layouts only (optionally with shared key/value sources).
+# ---------------------------------------------------------------------------------------------------------------------
+def _chunks(L, step=128):
+    return [(o, min(step, L - o)) for o in range(0, L, step)]
+
+
+def attn_fwd_long(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0, seed=None,
+                  salt=0, kv_seq=None):
+    if Lq <= 128 and Lkv <= 128:
+        return attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=kmask, causal_from=causal_from, is_cross=is_cross,
+                        dropout_p=dropout_p, seed=seed, salt=salt, kv_seq=kv_seq)
+    dev, H = Q.device, nH * 64
+    nsrc = K.shape[0] // Lkv
+    ar_q = torch.arange(nseq, dtype=torch.int32, device=dev)
+    ar_k = torch.arange(nsrc, dtype=torch.int32, device=dev)
+    Ov = O.view(nseq, Lq, nH, 64)
+    for qi, (q0, ql) in enumerate(_chunks(Lq)):
+        q_row0, q_len = ar_q * Lq + q0, torch.full((nseq,), ql, dtype=torch.int32, device=dev)
+        outs, lses = [], []
+        for ci, (k0, kl) in enumerate(_chunks(Lkv)):
+            Oc = torch.empty(nseq * Lq, H, dtype=BF16, device=dev)
+            lc = torch.empty(nseq, nH, ql, dtype=torch.float32, device=dev)
+            attn_fwd(Q, K, V, Oc, lc, nseq=nseq, nH=nH, Lq=ql, Lkv=kl, kmask=None if kmask is None else kmask[:, k0:k0 + kl].contiguous(),
+                     causal_from=causal_from, is_cross=is_cross, dropout_p=dropout_p, seed=seed, salt=salt + 7919 * (qi * 8 + ci + 1),
+                     kv_seq=kv_seq, q_row0=q_row0, q_len=q_len, kv_row0=ar_k * Lkv + k0,
+                     kv_len=torch.full((nsrc,), kl, dtype=torch.int32, device=dev), q_off=q0, kv_off=k0)
+            outs.append(Oc.view(nseq, Lq, nH, 64)[:, q0:q0 + ql].float())
+            lses.append(lc)
+        L = torch.stack(lses)                                   # [chunks, nseq, nH, ql]
+        tot = torch.logsumexp(L, dim=0)
+        acc = sum(o * torch.exp(l - tot).permute(0, 2, 1)[..., None] for o, l in zip(outs, lses))
+        Ov[:, q0:q0 + ql] = acc.to(BF16)
+        if lse is not None:
+            lse[:, :, q0:q0 + ql] = tot
+    return O
+
+
+def attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
+                  seed=None, salt=0, kv_seq=None):
+    """dK / dV: [nseq*Lkv, H] views when kv_seq is given (per query sequence), else [sources*Lkv, H]."""
+    if Lq <= 128 and Lkv <= 128:
+        return attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=kmask, causal_from=causal_from,
+                        is_cross=is_cross, dropout_p=dropout_p, seed=seed, salt=salt, kv_seq=kv_seq)
+    dev, H = Q.device, nH * 64
+    nsrc = K.shape[0] // Lkv
+    nkv_out = nseq if kv_seq is not None else nsrc
+    ar_q = torch.arange(nseq, dtype=torch.int32, device=dev)
+    ar_k = torch.arange(nsrc, dtype=torch.int32, device=dev)
+    dQ32 = torch.zeros(nseq, Lq, H, dtype=torch.float32, device=dev)
+    dK32 = torch.zeros(nkv_out, Lkv, H, dtype=torch.float32, device=dev)
+    dV32 = torch.zeros(nkv_out, Lkv, H, dtype=torch.float32, device=dev)
+    for qi, (q0, ql) in enumerate(_chunks(Lq)):
+        q_row0, q_len = ar_q * Lq + q0, torch.full((nseq,), ql, dtype=torch.int32, device=dev)
+        lse_i = lse[:, :, q0:q0 + ql].contiguous()
+        calls = []
+        for ci, (k0, kl) in enumerate(_chunks(Lkv)):
+            calls.append(dict(nseq=nseq, nH=nH, Lq=ql, Lkv=kl, kmask=None if kmask is None else kmask[:, k0:k0 + kl].contiguous(),
+                              causal_from=causal_from, is_cross=is_cross, dropout_p=dropout_p, seed=seed,
+                              salt=salt + 7919 * (qi * 8 + ci + 1), kv_seq=kv_seq, q_row0=q_row0, q_len=q_len, kv_row0=ar_k * Lkv + k0,
+                              kv_len=torch.full((nsrc,), kl, dtype=torch.int32, device=dev), q_off=q0, kv_off=k0))
+        dQc = torch.empty(nseq * Lq, H, dtype=BF16, device=dev)
+        D = torch.zeros(nseq, nH, ql, dtype=torch.float32, device=dev)
+        for (k0, kl), kw in zip(_chunks(Lkv), calls):                      # pass 1: D over all key chunks
+            Dc = torch.empty_like(D)
+            tmp = torch.empty((nseq if kv_seq is not None else nsrc) * (kl if kv_seq is not None else Lkv), H, dtype=BF16, device=dev)
+            attn_bwd(Q, K, V, O, lse_i, dO, dQc, tmp, tmp, d_mode=1, dbuf=Dc, **kw)
+            D += Dc
+        for (k0, kl), kw in zip(_chunks(Lkv), calls):                      # pass 2: gradients with the complete D
+            if kv_seq is not None:                                           # per query sequence, dense within the chunk
+                dKc = torch.zeros(nseq * kl, H, dtype=BF16, device=dev); dVc = torch.zeros_like(dKc)
+            else:                                                            # written in place at the sources' rows
+                dKc = torch.zeros(nsrc * Lkv, H, dtype=BF16, device=dev); dVc = torch.zeros_like(dKc)
+            attn_bwd(Q, K, V, O, lse_i, dO, dQc, dKc, dVc, d_mode=2, dbuf=D, **kw)
+            dQ32[:, q0:q0 + ql] += dQc.view(nseq, Lq, H)[:, q0:q0 + ql].float()
+            if kv_seq is not None:
+                dK32[:, k0:k0 + kl] += dKc.view(nseq, kl, H).float(); dV32[:, k0:k0 + kl] += dVc.view(nseq, kl, H).float()
+            else:
+                dK32[:, k0:k0 + kl] += dKc.view(nsrc, Lkv, H)[:, k0:k0 + kl].float(); dV32[:, k0:k0 + kl] += dVc.view(nsrc, Lkv, H)[:, k0:k0 + kl].float()
+    dQ.copy_(dQ32.view(nseq * Lq, H))
+    dK.copy_(dK32.view(nkv_out * Lkv, H))
+    dV.copy_(dV32.view(nkv_out * Lkv, H))

@@ -52,7 +52,7 @@ class PretrainStep(Engine):
 
         # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
         # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
-        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None) else None
+        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None and Lt <= 128) else None   # packed layouts: <= 128 tokens
         M = pk["M"] if pk else B * Lt
         ids2 = torch.cat([ids32, ids32])
         side = self._fork()

@@ -332,6 +332,38 @@ def test_attention_packed_variable_length_layout(ops, is_cross, shared):
         assert torch.equal(dKVp, dKVd[ksel])
 
 
+@pytest.mark.parametrize("nseq,nH,Lq,Lkv,causal_from,is_cross", [(3, 2, 200, 200, 1, False), (2, 2, 256, 256, 0, False), (3, 2, 54, 256, 3, True),
+                                                               (2, 2, 130, 54, 2, True)])
+def test_attention_long_sequences_by_chunks(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
+    """Sequences beyond the 128 rows the kernels keep on chip (up to 256 here): chunked launches merged by log-sum-exp in
+    forward, two-pass D in backward, against the fp32 reference arithmetic."""
+    H = nH * 64
+    qkv, kv, _ = _attn_inputs(nseq, nH, Lq, Lkv, seed=60)
+    g = torch.Generator().manual_seed(61)
+    lens = torch.randint(Lkv // 2, Lkv + 1, (nseq,), generator=g); lens[0] = Lkv
+    mask = (torch.arange(Lkv)[None, :] < lens[:, None]).int().cuda()
+    if is_cross:
+        Q, K, V = qkv[:, :H], kv[:, :H], kv[:, H:]
+    else:
+        Q, K, V = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    dO = rnd(nseq * Lq, H, seed=62)
+    O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda"); lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    kw = dict(nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, causal_from=causal_from, is_cross=is_cross)
+    ops.attn_fwd_long(Q, K, V, O, lse, **kw)
+    q = Q.float().reshape(nseq, Lq, H).requires_grad_(True)
+    k = K.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    v = V.float().reshape(nseq, Lkv, H).requires_grad_(True)
+    ro, rl = ref_attention(q, k, v, mask, nH, causal_from, is_cross)
+    close(lse, rl.detach(), 2e-3, 1e-4, "lse")
+    close(O.view(nseq, Lq, H), ro.detach(), 1.5e-2, 1e-2, "attention out")
+    dQ = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda"); dK = torch.zeros(nseq * Lkv, H, dtype=BF, device="cuda"); dV = torch.zeros_like(dK)
+    ops.attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, **kw)
+    ro.backward(dO.float().view(nseq, Lq, H))
+    for got, ref, nm in ((dQ, q.grad, "dQ"), (dK, k.grad, "dK"), (dV, v.grad, "dV")):
+        ref2 = ref.reshape(got.shape)
+        close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
+
+
 def test_attention_backward_near_constant_values(ops):
     """Regression: in a real model V rows (hence dP) are nearly constant across keys, so ds = P (dP - D) is a small
     difference of large numbers.  D must be the fp32 sum_kv P dP; taking it from rowsum(dO * bf16(O)) gave 50-300 %

@@ -587,3 +587,33 @@ def test_edge_shapes_match_oracle(env, case):
     print(case, "hip", got, "oracle", ref)
     assert np.isfinite(got).all() and torch.isfinite(m.store.grad).all()
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
+
+
+def test_long_sequences_forward_backward_match_oracle(env):
+    """Lt = 160 > 128: the dense step with chunked attention (forward merge by log-sum-exp, two-pass D in backward) vs the
+    oracle's losses, and the gradient norm vs the oracle's autograd."""
+    O, SPMM, tiny_config, *_ = env
+    ocfg, cfg = O.tiny_cfg(), tiny_config()
+    for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.closed_form_state_dict(ocfg)
+    B, Lt = 4, 160
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=31)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(6))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(3))
+    m = _mk(SPMM, cfg, sd).train()
+    losses = m(prop, ids, mask, alpha=0.3, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+    sum(losses).backward()
+    got = np.array([float(x) for x in losses])
+    names = O.trainable_names(ocfg)
+    for n in names:
+        sd[n].requires_grad_(True)
+    O._finish_tied(sd)
+    ref_l = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.3, mpm_mask=mpm, neg_idx=neg, train=True)
+    sum(ref_l).backward()
+    ref = np.array([float(x) for x in ref_l])
+    gn_ref = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
+    gn = m.store.grad.double().norm().item()
+    print("Lt=160 hip", got, "oracle", ref, "grad norm", gn, gn_ref)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
+    assert abs(gn - gn_ref) / gn_ref < 2e-2
