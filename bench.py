@@ -286,7 +286,7 @@ def main():
                       "parallelism": f"dp{world}"},
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
-                                         - padding_saving(B, Lt, n_valid, n_text=nt, fusion=f)) / 1e12, 2),
+                                         - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= 128 else 0.0)) / 1e12, 2),
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses}
