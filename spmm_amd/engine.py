@@ -11,9 +11,13 @@ token-major batches that share weights, so every GEMM sees a large M and weights
   S6  text student    layers f..n-1 : [P5 | P7 | P12(causal)] query-PV rows (4B x 54) ++
                                       [P6 | P8 | P10b(causal)] query-text rows (4B x Lt), cross-attending each other
 
+Three exact work reductions sit on top (spmm_amd/step.py): cross-attention K/V projected once per unique source sequence
+(KVSource), padding-token rows dropped from the passes whose losses read only position 0 (packed layouts), and the
+independent chains S1 | S2 | S4 (and S5 under S6) on separate HIP streams.
+
 There is no autograd inside: forward keeps an explicit tape of the activations backward needs, backward walks it.
 Everything that changes between steps (alpha, lr, dropout seed, loss-gradient scales, queue pointer) is read from
-device memory, so the same launch sequence can be captured once into a hipGraph and replayed."""
+device memory; the one host read per step is the packed row count that sizes the GEMMs (PretrainStep._pack_plan)."""
 from __future__ import annotations
 
 import contextlib

@@ -256,7 +256,8 @@ class SPMM(nn.Module):
 
     def fused_step(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None, grad_sync=None):
         """zero_grad -> forward -> backward (unit loss weights, SPMM_models.py:358) -> [grad all-reduce] -> clip -> AdamW,
-        with no host synchronisation.  Returns the device tensor of the four losses."""
+        with a single host read (the number of non-padding tokens, which sizes the packed GEMMs).  Returns the device tensor of
+        the four losses."""
         eng, opt = self.engine, self.optimizers()
         eng.train_mode = self.training
         eng.alpha.fill_(float(alpha))
