@@ -122,6 +122,38 @@ def fixture_forward(name, cfg, B, Lt, alpha, seed):
     print(name, out["losses"], out["losses2"])
 
 
+def wide_cfg() -> O.SPMMCfg:
+    """The published widths (H=768, 12 heads, I=3072, E=256) at reduced depth: 2 text layers (1 fusion) + 1 PV layer."""
+    t = O.BertCfg(num_hidden_layers=2, fusion_layer=1)
+    p = O.BertCfg(num_hidden_layers=1, fusion_layer=1, vocab_size=1)
+    return O.SPMMCfg(text=t, prop=p, embed_dim=256, queue_size=16)
+
+
+def fixture_wide(name, cfg, B, Lt, alpha, seed):
+    """Losses + gradient norm of the REAL reference at the real widths (train mode, dropout 0): small fixture (inputs are
+    regenerated from the seed, weights are closed-form), pins the oracle and the HIP path beyond the toy width."""
+    torch.manual_seed(1234)
+    m = ref_model(cfg, dropout=0.0)
+    m.train()
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=seed)
+    with Recorder() as rec:
+        losses = m(prop, ids, mask, alpha=alpha)
+    sum(losses).backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+    neg = torch.stack([r.reshape(()) for r in rec.multi])
+    out = dict(alpha=np.float64(alpha), seed=np.int64(seed), B=np.int64(B), Lt=np.int64(Lt), mpm_mask=rec.bern[0].numpy(),
+               prop_neg_idx=neg[:B].numpy(), text_neg_idx=neg[B:].numpy(),
+               losses=np.array([float(x) for x in losses], dtype=np.float64), grad_norm=np.float64(gn),
+               queue_ptr=m.queue_ptr.numpy().copy(), temp=np.float64(m.temp.item()),
+               prop_queue_head=m.prop_queue[:, :B].numpy().copy(), text_queue_head=m.text_queue[:, :B].numpy().copy())
+    for n in ("text_encoder.bert.encoder.layer.1.crossattention.self.key.weight", "property_encoder.encoder.layer.0.intermediate.dense.weight",
+              "text_proj.weight", "itm_head.weight"):
+        g = dict(m.named_parameters())[n].grad
+        out["gradsum::" + n] = np.array([g.double().sum().item(), g.double().abs().sum().item(), g.double().norm().item()])
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, out["losses"], gn)
+
+
 def fixture_train(name, cfg, B, Lt, steps, seed):
     """Train-mode trace with dropout 0 (train() but p=0): losses, grad-norm, lr, temp, ptr, param checksums.
     Drives the reference's own configure_optimizers() (AdamW + scheduler factory) and restates only the
@@ -201,3 +233,4 @@ if __name__ == "__main__":
     fixture_forward("fwd_tiny_b8_l24", cfg, B=8, Lt=24, alpha=0.25, seed=11)
     fixture_train("train_tiny_b4_l16", cfg, B=4, Lt=16, steps=5, seed=21)
     fixture_lr()
+    fixture_wide("fwd_wide768_b4_l16", wide_cfg(), B=4, Lt=16, alpha=0.3, seed=33)
