@@ -646,6 +646,7 @@ class OracleModule:
     def __init__(self, sd: SD, cfg: SPMMCfg):
         self.sd, self.cfg = sd, cfg
         self.property_cls = sd["property_cls"]
+        self.property_mask = sd["property_mask"]
 
     def property_embed(self, x):
         return F.linear(x, self.sd["property_embed.weight"], self.sd["property_embed.bias"])

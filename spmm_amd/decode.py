@@ -14,6 +14,17 @@ import torch
 CLS_ID, SEP_ID = 2, 3           # vocab_bpe_300.txt:3-4
 
 
+def _pick(p: torch.Tensor, k: int, stochastic: bool, generator=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The two k-candidate branches of `generate` (d_pv2smiles_single.py:37-44): the k most probable next tokens, or k
+    tokens drawn without replacement from the next-token distribution.  p: [..., V] probabilities -> (log-probs, ids) [..., k]."""
+    if stochastic:
+        flat = p.reshape(-1, p.shape[-1])
+        ids = torch.multinomial(flat, num_samples=k, replacement=False, generator=generator)
+        return torch.log(flat.gather(1, ids)).reshape(*p.shape[:-1], k), ids.reshape(*p.shape[:-1], k)
+    top = torch.topk(p, k=k, dim=-1)
+    return torch.log(top.values), top.indices
+
+
 @torch.no_grad()
 def next_token_topk(model, prop_embeds: torch.Tensor, text: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """d_pv2smiles_single.generate with stochastic=False, k given: log of the top-k next-token probabilities and their ids.
@@ -28,9 +39,15 @@ def next_token_topk(model, prop_embeds: torch.Tensor, text: torch.Tensor, k: int
 
 
 @torch.no_grad()
-def encode_properties(model, prop: torch.Tensor) -> torch.Tensor:
-    """d_pv2smiles_batched.py:24-27: PV [B,53] -> prop_embeds [B,54,H] (no masking at inference)."""
+def encode_properties(model, prop: torch.Tensor, prop_mask: torch.Tensor | None = None) -> torch.Tensor:
+    """d_pv2smiles_batched.py:24-27: PV [B,53] -> prop_embeds [B,54,H].  prop_mask ([53] or [B,53], 1 = property unknown)
+    substitutes the learned mask token for those entries, as conditional generation on a subset of properties does
+    (d_pv2smiles_single.py:66-70)."""
     feat = model.property_embed(prop.unsqueeze(2))
+    if prop_mask is not None:
+        mk = prop_mask.to(feat.device).to(feat.dtype).reshape(-1, prop.shape[1])[..., None]
+        unk = model.property_mask.detach().to(feat.device).to(feat.dtype).expand(feat.shape[0], feat.shape[1], -1)
+        feat = feat * (1 - mk) + unk * mk
     cls = model.property_cls
     properties = torch.cat([cls.expand(feat.size(0), -1, -1).to(feat.dtype).to(feat.device), feat], dim=1)
     return model.property_encoder(inputs_embeds=properties, return_dict=True).last_hidden_state
@@ -243,13 +260,16 @@ class CachedDecoder:
 
 @torch.no_grad()
 def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
-                        sync_every: int = 4) -> List[List[Tuple[float, List[int]]]]:
+                        sync_every: int = 4, prop_mask: torch.Tensor | None = None, stochastic: bool = False,
+                        generator=None) -> List[List[Tuple[float, List[int]]]]:
     """`beam_search` for N molecules at once (props [N,53]); result[n] is what beam_search(model, props[n]) returns.
     cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
-    through the module API (any model exposing it, e.g. the CPU oracle)."""
+    through the module API (any model exposing it, e.g. the CPU oracle).  prop_mask: properties to leave unspecified
+    (encode_properties).  stochastic=True draws the k candidates of every beam from the next-token distribution instead of
+    taking the k most probable (d_pv2smiles_single.py:37-40); `generator` seeds those draws."""
     if cached is None:
         cached = hasattr(model, "engine")
-    prop_embeds = encode_properties(model, props)
+    prop_embeds = encode_properties(model, props, prop_mask)
     N, dev = prop_embeds.shape[0], prop_embeds.device
     if cached:
         model.engine.train_mode = False
@@ -257,13 +277,13 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     book = BeamBook(N, k, max_steps, dev)
     ids = torch.full((N * k,), CLS_ID, dtype=torch.long, device=dev)
     logits = dec.step(ids, 0).view(N, k, -1)[:, 0]                       # all k rows hold the same [CLS] prefix
-    top = torch.topk(torch.softmax(logits.float(), dim=-1), k=k, dim=-1)
-    book.first(torch.log(top.values), top.indices)
-    ids = top.indices.reshape(N * k)
+    values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
+    book.first(values, indices)
+    ids = indices.reshape(N * k)
     for s in range(max_steps):
         logits = dec.step(ids, s + 1).view(N, k, -1)
-        top = torch.topk(torch.softmax(logits.float(), dim=-1), k=k, dim=-1)
-        parent, tok = book.update(torch.log(top.values), top.indices)
+        values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
+        parent, tok = book.update(values, indices)
         dec.reorder(parent, s + 2)
         ids = tok.reshape(N * k)
         if s % sync_every == sync_every - 1 and bool(book.done.all()):

@@ -654,3 +654,35 @@ def test_wide_model_matches_reference_golden(env, golden_dir):
     np.testing.assert_allclose(sdo["prop_queue"][:, :B].cpu().numpy(), g["prop_queue_head"], atol=2e-3)
     np.testing.assert_allclose(sdo["text_queue"][:, :B].cpu().numpy(), g["text_queue_head"], atol=2e-3)
     assert int(sdo["queue_ptr"]) == int(g["queue_ptr"][0])
+
+
+def test_conditional_and_stochastic_generation(env):
+    """Generation conditioned on a subset of the properties (the rest replaced by the mask token, d_pv2smiles_single.py:66-70)
+    and the stochastic candidate branch (:37-40): the masked PV encoding matches the oracle's, and sampled hypotheses are well
+    formed with scores equal to the teacher-forced log-probabilities of the uncached forward."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd import decode
+    sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), sep_gap=0.4)
+    sd["property_mask"] = torch.randn_like(sd["property_mask"]) * 0.5
+    om = O.OracleModule(sd, O.tiny_cfg())
+    m = _mk(SPMM, tiny_config(), sd).eval()
+    props = torch.randn(4, 53, generator=torch.Generator().manual_seed(8))
+    pmask = torch.zeros(53); pmask[20:] = 1
+    pe_h = decode.encode_properties(m, props, pmask)
+    pe_o = decode.encode_properties(om, props, pmask)
+    assert (pe_h.cpu() - pe_o).abs().max().item() < 6e-2
+    assert (pe_o - decode.encode_properties(om, props)).abs().max().item() > 1e-2           # the mask changes the encoding
+    g = torch.Generator(device="cuda").manual_seed(3)
+    hyps = decode.beam_search_batched(m, props, k=4, max_steps=10, prop_mask=pmask, stochastic=True, generator=g)
+    n = 0
+    for i, hs in enumerate(hyps):
+        for p, seq in hs:
+            n += 1
+            assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and p <= 0.0
+            text = torch.tensor([seq], device="cuda")
+            logits = m.text_encoder(text, attention_mask=torch.ones_like(text), encoder_hidden_states=pe_h[i:i + 1],
+                                    encoder_attention_mask=torch.ones(1, 54, dtype=torch.long, device="cuda"), return_dict=True,
+                                    is_decoder=True, return_logits=True)
+            lp = torch.log_softmax(logits.float(), -1)[0, :-1].gather(1, text[0, 1:, None]).sum().item()
+            assert abs(lp - p) < 3e-2 * (len(seq) - 1)
+    assert n >= 4
