@@ -31,6 +31,7 @@ for s in range(a.steps):
     if s % a.every == 0 or s == a.steps - 1:
         l = losses.cpu().tolist()
         assert all(x == x and abs(x) < 1e6 for x in l), (s, l)
-        print(f"{s:5d} {l[0]:9.4f} {l[1]:9.4f} {l[2]:9.4f} {l[3]:9.4f} {float(opt.grad_norm):10.3f} {float(model.temp):7.4f}", flush=True)
+        print(f"{s:5d} {l[0]:9.4f} {l[1]:9.4f} {l[2]:9.4f} {l[3]:9.4f} {float(opt.grad_norm):10.3f} {float(model.temp):7.4f}"
+              f"   alloc {torch.cuda.memory_allocated() / 2**30:6.1f} GiB  reserved {torch.cuda.memory_reserved() / 2**30:6.1f} GiB", flush=True)
 torch.cuda.synchronize()
 print(f"{a.steps} steps in {time.time() - t0:.1f} s; nan flag {int(model.engine.nan_flag)}; queue_ptr {int(model.queue_ptr)}")
