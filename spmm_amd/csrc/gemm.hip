@@ -124,8 +124,11 @@ __device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2],
     }
 }
 
+// cs_carry (optional): column-sum partials kept in registers across consecutive calls on the SAME columns (the two m-halves of
+// a wave tile); they are flushed with atomics only when `flush` is set -- half the same-address atomics per tile.
 template <int EPI, bool NOSTORE = false, int GMODE = 0>
-__device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const char* t1, int m_base, int n_base, int lane) {
+__device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const char* t1, int m_base, int n_base, int lane,
+                                          float* cs_carry = nullptr, bool flush = true) {
   // all R / G operand loads first: a load placed behind a store to a possibly aliasing pointer would be serialised behind it
   bf16x8 rr[8], gg[8];
   if (p.R || EPI == EPI_GELU_GRAD) {
@@ -148,6 +151,10 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
     }
   }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cs_carry) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cs_carry[e];
+  }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + (lane >> 3), c16 = lane & 7;
@@ -179,6 +186,11 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
       if constexpr (EPI == EPI_GELU && GMODE == 0) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
     }
   }
+  if (p.colsum && cs_carry && !flush) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs_carry[e] = cs[e];
+    return;
+  }
   if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -199,9 +211,10 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
 
 // both halves by the same wave on its private region (same-wave LDS round trip: the compiler's lgkmcnt waits suffice)
 template <int EPI, bool NOSTORE = false, int GMODE = 0>
-__device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane) {
+__device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane,
+                                              float* cs_carry = nullptr, bool flush = true) {
   epi_convert<EPI, GMODE>(p, acc, wtile, wtile + 8192, n_base, lane);
-  epi_store<EPI, NOSTORE, GMODE>(p, wtile, wtile + 8192, m_base, n_base, lane);
+  epi_store<EPI, NOSTORE, GMODE>(p, wtile, wtile + 8192, m_base, n_base, lane, cs_carry, flush);
 }
 
 template <int EPI, bool GLDS>
@@ -672,9 +685,10 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[h][i][j]));
     return;
   }
+  float cs_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // column sums of both m-halves go out in one set of atomics
 #pragma unroll
   for (int h = 0; h < 2; ++h)
-    epilogue_bf16<EPI, ABL == 4>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+    epilogue_bf16<EPI, ABL == 4>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, cs_carry, h == 1);
 }
 
 // ------------------------------------------------------------------------------------------------------------
