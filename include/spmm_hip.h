@@ -106,8 +106,9 @@ int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mea
                 const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, spmm_stream_t stream);
 
 /* One decode step of BertEmbeddings.forward (xbert.py:193-220) at inference: y[r] = LN(word[ids[r]] + pos[pos_index] +
- * type[0]) for `rows` single-token rows (every beam is at the same position). */
-int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const float* word, const float* pos, const float* type0,
+ * type[0]) for `rows` single-token rows (every beam is at the same position).  pos_ptr (optional) overrides pos_index
+ * with a device-resident step counter so that a captured hipGraph of the decode step can be replayed. */
+int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, const float* word, const float* pos, const float* type0,
                            const float* gamma, const float* beta, void* y, long rows, int H, float eps, spmm_stream_t stream);
 
 /* Single-query attention over a key/value cache (xbert.py:305-354 for the newest position only; the cache slots the
@@ -116,10 +117,11 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const float* word, con
  * s(r,j) = anc[r*anc_ld + j] (self-attention: beam ancestry table, cache rows are never moved) or r / kv_div when anc is
  * null (cross-attention: the k beams of a molecule share its PV keys/values).  `group` (R % group == 0) only steers
  * placement: rows n*group .. n*group+group-1 are scheduled next to each other because they read mostly the same lines.
- * No mask: beams carry no padding. */
+ * No mask: beams carry no padding.  t_ptr (optional, device int): the number of valid keys is *t_ptr + 1 (<= Lkv) instead of
+ * Lkv -- the step counter of a replayed hipGraph. */
 int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, const int* anc,
                      int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv, float scale,
-                     spmm_stream_t stream);
+                     const int* t_ptr, spmm_stream_t stream);
 
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings

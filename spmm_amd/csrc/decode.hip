@@ -19,6 +19,7 @@ struct DecAttnP {
   const int* anc; int anc_ld; int kv_div; int group; int nblocks;
   bf16* out; long ldo;
   int R, nH, Lkv; float scale;
+  const int* t_ptr;             // optional device step index: the cache holds positions 0..*t_ptr, i.e. Lkv = *t_ptr + 1 (graph replay)
 };
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
@@ -45,12 +46,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
   }
   const int* anc_row = p.anc ? p.anc + (long)r * p.anc_ld : nullptr;
   const long own = (long)(r / max(p.kv_div, 1)) * p.seq_stride + h * 64 + c * 8;
-  const int niter = (p.Lkv + 7) >> 3;
+  const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
+  const int niter = (Lkv + 7) >> 3;
   float mx = -INFINITY;
   for (int i = 0; i < niter; ++i) {
     const int j = i * 8 + g;
     float part = 0.f;
-    if (j < p.Lkv) {
+    if (j < Lkv) {
       const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * 64 + c * 8 : own) + (long)j * p.tok_stride;
       const bf16x8 kv = *(const bf16x8*)(p.K + off);
 #pragma unroll
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
     part += __shfl_xor(part, 4, 64);
-    if (j < p.Lkv) {
+    if (j < Lkv) {
       if (c == 0) ssc[wave][j] = part;
       mx = fmaxf(mx, part);
     }
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
   float sum = 0.f;
   for (int i = 0; i < niter; ++i) {
     const int j = i * 8 + g;
-    if (j < p.Lkv) {
+    if (j < Lkv) {
       const float e = __expf(ssc[wave][j] - mx);
       sum += e;
       const float pe = (float)(bf16)e;               // the tiled training kernel feeds bf16 probabilities to the PV MFMA
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
 
 extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride,
                                 const int* anc, int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv,
-                                float scale, hipStream_t stream) {
+                                float scale, const int* t_ptr, hipStream_t stream) {
   SPMM_CHECK_SHAPE(R > 0 && nH > 0 && Lkv > 0 && Lkv <= 256, "spmm_decode_attn: R=%d nH=%d Lkv=%d (Lkv <= 256)", R, nH, Lkv);
   SPMM_CHECK_SHAPE((anc != nullptr && anc_ld >= Lkv) || (anc == nullptr && kv_div > 0), "spmm_decode_attn: anc_ld=%d kv_div=%d", anc_ld, kv_div);
   SPMM_CHECK_SHAPE(seq_stride % 8 == 0 && tok_stride % 8 == 0 && ldq >= (long)nH * 64 && ldo >= (long)nH * 64 && ldq % 8 == 0 && ldo % 8 == 0,
@@ -109,7 +111,7 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
   const long waves = (long)R * nH;
   const int nblocks = (int)((waves + 3) / 4);
   DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, anc, anc_ld, kv_div, group, nblocks,
-                (bf16*)out, ldo, R, nH, Lkv, scale};
+                (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr};
   hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
   SPMM_LAUNCH_CHECK("spmm_decode_attn");
   return SPMM_OK;

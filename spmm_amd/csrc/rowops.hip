@@ -281,6 +281,7 @@ struct EmbedP {
   bf16* y; bf16* zout; float* mean_o; float* rstd_o;
   long nseq; int L, H, mode; float eps;
   int pos0;                  // position of l = 0 (decode steps embed one token at position t)
+  const int* pos_ptr;        // ... or read from device memory (graph replay)
   uint32_t thresh16; float dscale; const uint64_t* seed_ptr; uint64_t salt;
 };
 
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(EmbedP p) {
   const long seq = row / p.L;
   const int l = (int)(row - seq * p.L);
   RowVec z, t, o;
-  load_row_f32(p.pos + (long)(l + p.pos0) * p.H, p.H, lane, z);
+  load_row_f32(p.pos + (long)(l + (p.pos_ptr ? *p.pos_ptr : p.pos0)) * p.H, p.H, lane, z);
   load_row_f32(p.type0, p.H, lane, t);
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
@@ -570,14 +571,14 @@ extern "C" int spmm_embed_ln_fwd(int mode, const int* ids, const float* word, co
   return SPMM_OK;
 }
 
-extern "C" int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const float* word, const float* pos, const float* type0,
+extern "C" int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, const float* word, const float* pos, const float* type0,
                                       const float* gamma, const float* beta, void* y, long rows, int H, float eps,
                                       hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && pos_index >= 0 && H % 4 == 0 && H <= 1024, "spmm_embed_step_ln_fwd: rows=%ld pos=%d H=%d", rows, pos_index, H);
   SPMM_CHECK_SHAPE(ids && word && pos && type0 && gamma && beta && y, "spmm_embed_step_ln_fwd: null argument");
   EmbedP p = {};
   p.ids = ids; p.word = word; p.pos = pos; p.type0 = type0; p.gamma = gamma; p.beta = beta; p.y = (bf16*)y;
-  p.nseq = rows; p.L = 1; p.H = H; p.mode = 0; p.eps = eps; p.pos0 = pos_index; p.dscale = 1.f;
+  p.nseq = rows; p.L = 1; p.H = H; p.mode = 0; p.eps = eps; p.pos0 = pos_index; p.pos_ptr = pos_ptr; p.dscale = 1.f;
   hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
   SPMM_LAUNCH_CHECK("spmm_embed_step_ln_fwd");
   return SPMM_OK;

@@ -136,6 +136,33 @@ class BeamBook:
         self.t = t + 1
         return parent, tok
 
+    def update_dev(self, values: torch.Tensor, indices: torch.Tensor, t64: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`update` with the number of tokens held by the live beams (t64: int64 [1]) in device memory and every piece of state
+        updated in place, so that the call sequence is identical at every step (graph replay).  Same decisions as `update`."""
+        N, k, F, L = self.N, self.k, self.F, self.Lmax
+        k2_p = (self.cur_p[:, :, None] + values).reshape(N, k * k)
+        idx = indices.reshape(N, k * k)
+        ends = (idx == SEP_ID) & ~self.done[:, None]
+        e = ends.long()
+        slot = torch.where(ends, self.fin_n[:, None] + torch.cumsum(e, 1) - e, torch.full_like(e, F))
+        self.fin_p.scatter_(1, slot, k2_p)
+        self.fin_len.scatter_(1, slot, (t64 + 1).expand(N, k * k).contiguous())
+        cand = self.tokens[:, :, None, :].expand(N, k, k, L).reshape(N, k * k, L).clone()
+        cand.index_fill_(2, t64, SEP_ID)
+        self.fin_tok.scatter_(1, slot[:, :, None].expand(N, k * k, L), cand)
+        self.fin_n.add_(e.sum(1))
+        k2_p = torch.where(ends, torch.full_like(k2_p, -1e5), k2_p)
+        new_p, flat = torch.topk(k2_p, k, dim=1)
+        parent = flat // k
+        tok = idx.gather(1, flat)
+        live = ~(self.done | (self.fin_n >= k))
+        new_tokens = self.tokens.gather(1, parent[:, :, None].expand(N, k, L)).clone()
+        new_tokens.scatter_(2, t64.view(1, 1, 1).expand(N, k, 1), tok[:, :, None])
+        self.tokens.copy_(torch.where(live[:, None, None], new_tokens, self.tokens))
+        self.cur_p.copy_(torch.where(live[:, None], new_p, self.cur_p))
+        self.done.logical_or_(self.fin_n >= k)
+        return parent, tok
+
     def results(self) -> List[List[Tuple[float, List[int]]]]:
         k, F = self.k, self.F
         p = self.fin_p[:, :F]
@@ -215,12 +242,15 @@ class CachedDecoder:
         return y
 
     @torch.no_grad()
-    def step(self, ids: torch.Tensor, t: int) -> torch.Tensor:
-        """ids [R]: the token at position t of every beam -> fp32 logits [R, V] for position t + 1."""
+    def step(self, ids: torch.Tensor, t: int, t_dev: torch.Tensor | None = None) -> torch.Tensor:
+        """ids [R]: the token at position t of every beam -> fp32 logits [R, V] for position t + 1.
+        t_dev (int32 [1], device): the position comes from device memory instead (t is then ignored), which makes the whole
+        launch sequence independent of the step -- capturable once as a hipGraph and replayed (beam_search_batched(graph=True))."""
         ops, P, c, R, H, nH = self.ops, self.P, self.c, self.R, self.H, self.c.num_attention_heads
         bp = self.pfx + "bert."
         x = self._new(R, H)
-        ops.embed_step_ln_fwd(ids.to(torch.int32).contiguous(), t, x, word=P.w(bp + "embeddings.word_embeddings.weight"),
+        t64 = None if t_dev is None else t_dev.to(torch.int64)
+        ops.embed_step_ln_fwd(ids.to(torch.int32).contiguous(), t, x, pos_ptr=t_dev, word=P.w(bp + "embeddings.word_embeddings.weight"),
                               pos=P.w(bp + "embeddings.position_embeddings.weight"), type0=P.w(bp + "embeddings.token_type_embeddings.weight"),
                               gamma=P.w(bp + "embeddings.LayerNorm.weight"), beta=P.w(bp + "embeddings.LayerNorm.bias"), eps=c.layer_norm_eps)
         for l in range(c.num_hidden_layers):
@@ -229,10 +259,15 @@ class CachedDecoder:
             QKV = self._new(R, 3 * H)
             ops.gemm_nt(x, P.fused(pf + "self.", ("query", "key", "value"), "weight"), QKV,
                         bias=P.fused(pf + "self.", ("query", "key", "value"), "bias", what="w"))
-            self.kc[l][:, t].copy_(QKV[:, H:2 * H])
-            self.vc[l][:, t].copy_(QKV[:, 2 * H:])
+            if t64 is None:
+                self.kc[l][:, t].copy_(QKV[:, H:2 * H])
+                self.vc[l][:, t].copy_(QKV[:, 2 * H:])
+            else:
+                self.kc[l].index_copy_(1, t64, QKV[:, None, H:2 * H])
+                self.vc[l].index_copy_(1, t64, QKV[:, None, 2 * H:])
             ctx = self._new(R, H)
-            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=t + 1, seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k)
+            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=self.Lmax if t64 is not None else t + 1,
+                            seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k, t_ptr=t_dev)
             a = self._attn_out(pf, ctx, x)
             if l >= c.fusion_layer:
                 pf = lp + "crossattention."
@@ -257,16 +292,25 @@ class CachedDecoder:
         self.anc = self.anc.view(N, k, L).gather(1, parent[:, :, None].expand(N, k, L)).reshape(N * k, L).contiguous()
         self.anc[:, t:] = self.rows[:, None]
 
+    @torch.no_grad()
+    def reorder_dev(self, parent: torch.Tensor, t_next64: torch.Tensor):
+        """`reorder` with the next position in device memory and the table updated in place (static address for graph replay)."""
+        N, k, L = self.N, self.k, self.Lmax
+        self.anc.copy_(self.anc.view(N, k, L).gather(1, parent[:, :, None].expand(N, k, L)).reshape(N * k, L))
+        self.anc.index_copy_(1, t_next64, self.rows[:, None])
+
 
 @torch.no_grad()
 def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
                         sync_every: int = 4, prop_mask: torch.Tensor | None = None, stochastic: bool = False,
-                        generator=None) -> List[List[Tuple[float, List[int]]]]:
+                        generator=None, graph: bool = False) -> List[List[Tuple[float, List[int]]]]:
     """`beam_search` for N molecules at once (props [N,53]); result[n] is what beam_search(model, props[n]) returns.
     cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
     through the module API (any model exposing it, e.g. the CPU oracle).  prop_mask: properties to leave unspecified
     (encode_properties).  stochastic=True draws the k candidates of every beam from the next-token distribution instead of
-    taking the k most probable (d_pv2smiles_single.py:37-40); `generator` seeds those draws."""
+    taking the k most probable (d_pv2smiles_single.py:37-40); `generator` seeds those draws.  graph=True (cached, deterministic)
+    captures one decode position -- ~230 launches -- as a hipGraph and replays it: the per-position host cost drops from ~2.3 ms
+    of launch overhead to one graph launch, which is what small batches are bound by."""
     if cached is None:
         cached = hasattr(model, "engine")
     prop_embeds = encode_properties(model, props, prop_mask)
@@ -280,6 +324,8 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
     book.first(values, indices)
     ids = indices.reshape(N * k)
+    if graph and cached and not stochastic:
+        return _decode_graphed(dec, book, ids, N, k, max_steps, sync_every)
     for s in range(max_steps):
         logits = dec.step(ids, s + 1).view(N, k, -1)
         values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
@@ -318,3 +364,37 @@ def smiles_to_pv(model, text_ids: torch.Tensor, text_mask: torch.Tensor, n_props
         out.append(nxt)
         prefix = torch.cat([prefix, model.property_embed(nxt.reshape(B, 1, 1)).to(prefix.dtype)], dim=1)
     return torch.stack(out, dim=-1)
+
+
+def _decode_graphed(dec: "CachedDecoder", book: BeamBook, ids: torch.Tensor, N: int, k: int, max_steps: int, sync_every: int):
+    """The loop of beam_search_batched with every step-dependent scalar in device memory: two eager positions (they also set the
+    kernels' one-time attributes), then one captured position replayed for the rest."""
+    dev = ids.device
+    ids_s = ids.clone()                                          # static input of the graph
+    t_dev = torch.ones(1, dtype=torch.int32, device=dev)         # position of the token in ids_s
+
+    def one_position():
+        t64 = t_dev.to(torch.int64)
+        logits = dec.step(ids_s, 0, t_dev=t_dev).view(N, k, -1)
+        values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, False)
+        parent, tok = book.update_dev(values, indices, t64 + 1)
+        dec.reorder_dev(parent, t64 + 1)
+        ids_s.copy_(tok.reshape(N * k))
+        t_dev.add_(1)
+
+    eager = min(2, max_steps)
+    for _ in range(eager):
+        one_position()
+    steps_left = max_steps - eager
+    if steps_left > 0 and not bool(book.done.all()):
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            one_position()
+        g.replay()                                               # capture records, it does not execute: this is position `eager`
+        for s in range(1, steps_left):
+            if s % sync_every == 0 and bool(book.done.all()):
+                break
+            g.replay()
+    book.t = int(t_dev.item()) + 1
+    return book.results()

@@ -251,23 +251,23 @@ def axpy_scalar(dst, src, *, scale_ptr=None, scale=1.0):
     _call("spmm_axpy_scalar", _p(dst), _p(src), _p(scale_ptr), float(scale), dst.numel(), _st())
 
 
-def embed_step_ln_fwd(ids32, pos_index, y, *, word, pos, type0, gamma, beta, eps=1e-12):
+def embed_step_ln_fwd(ids32, pos_index, y, *, word, pos, type0, gamma, beta, eps=1e-12, pos_ptr=None):
     """One decode step of BertEmbeddings: y[r] = LN(word[ids[r]] + pos[pos_index] + type0)."""
     rows, H = y.shape
     assert ids32.dtype == torch.int32 and ids32.numel() == rows and y.dtype == BF16
-    _call("spmm_embed_step_ln_fwd", _p(ids32), int(pos_index), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(y), rows, H,
+    _call("spmm_embed_step_ln_fwd", _p(ids32), int(pos_index), _p(pos_ptr), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(y), rows, H,
           float(eps), _st())
     return y
 
 
-def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_div=1, group=1, scale=0.125):
+def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_div=1, group=1, scale=0.125, t_ptr=None):
     """Single-query attention over a K/V cache; q/out: [R, >=nH*64] bf16 views, K/V: bf16 views whose element (s, j, h*64+d)
     sits at s*seq_stride + j*tok_stride + h*64 + d from their first element."""
     R = q.shape[0]
     assert q.dtype == BF16 and K.dtype == BF16 and V.dtype == BF16 and out.dtype == BF16
     assert anc is None or (anc.dtype == torch.int32 and anc.shape[0] == R)
     _call("spmm_decode_attn", _p(q), _row_stride(q), _p(K), _p(V), int(seq_stride), int(tok_stride), _p(anc),
-          0 if anc is None else _row_stride(anc), int(kv_div), int(group), _p(out), _row_stride(out), R, nH, Lkv, float(scale), _st())
+          0 if anc is None else _row_stride(anc), int(kv_div), int(group), _p(out), _row_stride(out), R, nH, Lkv, float(scale), _p(t_ptr), _st())
     return out
 
 

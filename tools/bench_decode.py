@@ -14,6 +14,7 @@ ap.add_argument("--chunk", type=int, default=200)
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--uncached", type=int, default=2, help="molecules to time on the per-molecule recompute path")
+ap.add_argument("--graph", type=int, default=0, help="1: replay one captured decode position as a hipGraph")
 a = ap.parse_args()
 torch.manual_seed(0)
 from spmm_amd.config import BertConfig, SPMMConfig
@@ -22,12 +23,12 @@ cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross
 m = SPMM(spmm_config=cfg, no_train=True).eval()
 m.store.refresh_shadows()
 props = torch.randn(a.molecules, 53)
-out = {"k": a.k, "max_steps": a.steps, "molecules": a.molecules, "chunk": a.chunk}
+out = {"k": a.k, "max_steps": a.steps, "molecules": a.molecules, "chunk": a.chunk, "graph": a.graph}
 decode.beam_search_batched(m, props[: min(8, a.molecules)], k=a.k, max_steps=4)        # warm-up
 torch.cuda.synchronize(); t0 = time.perf_counter()
 nfin = 0
 for i in range(0, a.molecules, a.chunk):
-    res = decode.beam_search_batched(m, props[i:i + a.chunk], k=a.k, max_steps=a.steps)
+    res = decode.beam_search_batched(m, props[i:i + a.chunk], k=a.k, max_steps=a.steps, graph=bool(a.graph))
     nfin += sum(len(r) for r in res)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 out["cached_batched_molecules_per_s"] = round(a.molecules / dt, 2)
