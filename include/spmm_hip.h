@@ -46,10 +46,19 @@ const char* spmm_last_error(void);
  * (xbert.py:280-300 query/key/value, :370 attention output.dense, :435 intermediate.dense + erf GELU :436,
  * :448 output.dense, :673 transform.dense, :695 tied decoder; SPMM_models.py:31-42 heads) and, with transposed
  * operands, their dgrad/wgrad GEMMs; also the similarity GEMMs SPMM_models.py:108-111,121-124 (split-bf16 K=3E).
- * colsum (optional, bf16 / GELU-grad epilogues): colsum[n] += sum_m C[m][n] -- the bias gradient when C is a dY. */
+ * colsum (optional, bf16 / GELU-grad epilogues): colsum[n] += sum_m C[m][n] -- the bias gradient when C is a dY.
+ * kernel (per call, no process state): 0 = chosen from the shape; SPMM_GEMM_K128 = 128x128 tile (every epilogue, split-K);
+ * SPMM_GEMM_K256x128 = 256x128 three-stage ring (no atomic epilogue); SPMM_GEMM_K256 = 256x256 tile, one barrier per k-step;
+ * SPMM_GEMM_K256P8 = 256x256 tile on the 8-phase schedule (bf16-output epilogues, K % 128 == 0) -- the default for the
+ * training step's large GEMMs. */
+#define SPMM_GEMM_AUTO 0
+#define SPMM_GEMM_K128 1
+#define SPMM_GEMM_K256x128 2
+#define SPMM_GEMM_K256 3
+#define SPMM_GEMM_K256P8 8
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
-                 void* C2, long ldc2, int epi, float* colsum, spmm_stream_t stream);
+                 void* C2, long ldc2, int epi, float* colsum, int kernel, spmm_stream_t stream);
 /* Weight-gradient GEMM C[N,K] += alpha * A[M,N]^T . B[M,K] straight from the token-major activations (LDS transpose reads,
  * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
  * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
@@ -57,13 +66,7 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
 int spmm_gemm_tn_splits(int M, int N, int K);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
                  long ldc, float* workspace, spmm_stream_t stream);
-void spmm_gemm_tn_set_variant(int v);   /* 1 (default): 128x128 tile; 3: 256x256 tile for large problems; v >= 64: split target (workgroups) */
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
-/* 1 = stage tiles with LDS-DMA (global_load_lds_dwordx4, default), 0 = through registers */
-void spmm_gemm_set_staging(int use_lds_dma);
-/* schedule variant of the 3-stage NT kernel: bit0 s_setprio around MFMA clusters, bit1 DMA issue after the first k-slice,
- * bit2 explicit fragment double-buffering (tuning knob; the default is chosen from measurements) */
-void spmm_gemm_set_variant(int v);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.
  * Replaces BertSelfAttention.forward xbert.py:305-354 incl. the additive masks of :889-948 (self: 0/-10000, causal

@@ -38,9 +38,7 @@ struct GemmP {
   void* C; long ldc;
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
-  int order;                 // tile order inside an XCD's range: 0 n-fastest, 1 m-fastest, 2 blocked (8 m-panels x GN n-tiles)
-  int krot;                  // v3: tiles start their k loop at different slices (de-synchronises the CUs' walks over shared W lines)
-  int stagger;               // v3: every other first-wave workgroup sleeps stagger x ~3.9 us so the chip's epilogue store bursts interleave
+  int order;                 // tile order inside an XCD's range (tile_of): 0 row-major, 3 row-major inside 2 column groups
 };
 
 // LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
@@ -59,35 +57,15 @@ __device__ __forceinline__ void stage_tile_dma(const bf16* __restrict__ src, lon
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
   }
 }
-// Register-staged fallback (same LDS image): load early, write after the MFMA block.
-__device__ __forceinline__ void stage_tile_load(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0,
-                                                int tid, bf16x8 (&r)[4]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int id = c * 256 + tid;
-    const int row = id >> 3, ps = id & 7;
-    const int ls = ps ^ ((row >> 1) & 7);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;
-    r[c] = *(const bf16x8*)(src + (long)grow * ld + k0 + ls * 8);
-  }
-}
-__device__ __forceinline__ void stage_tile_write(char* lds_tile, int tid, const bf16x8 (&r)[4]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) *(bf16x8*)(lds_tile + (c * 256 + tid) * 16) = r[c];
-}
-
 
 // Coalesced bf16 epilogue: a wave's 64x64 output tile goes through LDS (8 KiB per wave per output) so that global
 // stores are 16 B per lane along rows (8 lanes = one 128-B row segment) instead of 8-B fragments scattered over 32 rows.
 // acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5).   Tile rows are 128 B; the 16-B chunk index is
 // XOR-ed with (row & 7) so the row-parallel writes and the row-major reads both spread over the banks.
-// Split in two halves so that a kernel can let DIFFERENT waves do the second half (wave-specialised stores, v6):
-//   epi_convert: accumulators -> scale / bias / GELU -> bf16 tile in LDS       (GMODE 1: pre-activation, 2: activation only)
+//   epi_convert: accumulators -> scale / bias / GELU -> bf16 tile in LDS
 //   epi_store  : LDS tile -> (+R, * gelu'(G)) -> row-coalesced global stores (+ fused column sums)
-template <int EPI, int GMODE = 0>
-__device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2], char* t0, char* t1, int n_base, int lane,
-                                            const float* bias_lds = nullptr) {
+template <int EPI>
+__device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2], char* t0, char* t1, int n_base, int lane) {
   float scale = p.alpha;
   if (p.div_ptr) scale /= *p.div_ptr;
 #pragma unroll
@@ -104,17 +82,13 @@ __device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2],
         if (p.bias) {
           const int n = n_base + col;
           if (n < p.N) {
-            const f32x4 b = bias_lds ? *(const f32x4*)(bias_lds + n) : *(const f32x4*)(p.bias + n);
+            const f32x4 b = *(const f32x4*)(p.bias + n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += b[j];
           }
         }
         const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
-        if constexpr (EPI == EPI_GELU && GMODE == 1) {
-          *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
-        } else if constexpr (EPI == EPI_GELU && GMODE == 2) {
-          *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-        } else if constexpr (EPI == EPI_GELU) {
+        if constexpr (EPI == EPI_GELU) {
           if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
           *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
         } else {
@@ -126,7 +100,7 @@ __device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2],
 
 // cs_carry (optional): column-sum partials kept in registers across consecutive calls on the SAME columns (the two m-halves of
 // a wave tile); they are flushed with atomics only when `flush` is set -- half the same-address atomics per tile.
-template <int EPI, bool NOSTORE = false, int GMODE = 0>
+template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const char* t1, int m_base, int n_base, int lane,
                                           float* cs_carry = nullptr, bool flush = true) {
   // all R / G operand loads first: a load placed behind a store to a possibly aliasing pointer would be serialised behind it
@@ -175,15 +149,14 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
     }
-    if constexpr (NOSTORE) { asm volatile("" :: "v"(o)); continue; }
-    bf16* dst = (EPI == EPI_GELU && GMODE == 1) ? p.C2 + (long)m * p.ldc2 + n : (bf16*)p.C + (long)m * p.ldc + n;
+    bf16* dst = (bf16*)p.C + (long)m * p.ldc + n;
     if (full) {
       *(bf16x8*)dst = o;
-      if constexpr (EPI == EPI_GELU && GMODE == 0) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
+      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
     } else {   // ragged last chunk (N % 8 == 4)
       bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
       *(bf16x4*)dst = lo4;
-      if constexpr (EPI == EPI_GELU && GMODE == 0) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
+      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
     }
   }
   if (p.colsum && cs_carry && !flush) {
@@ -210,14 +183,14 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
 }
 
 // both halves by the same wave on its private region (same-wave LDS round trip: the compiler's lgkmcnt waits suffice)
-template <int EPI, bool NOSTORE = false, int GMODE = 0>
+template <int EPI>
 __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2], char* wtile, int m_base, int n_base, int lane,
                                               float* cs_carry = nullptr, bool flush = true) {
-  epi_convert<EPI, GMODE>(p, acc, wtile, wtile + 8192, n_base, lane);
-  epi_store<EPI, NOSTORE, GMODE>(p, wtile, wtile + 8192, m_base, n_base, lane, cs_carry, flush);
+  epi_convert<EPI>(p, acc, wtile, wtile + 8192, n_base, lane);
+  epi_store<EPI>(p, wtile, wtile + 8192, m_base, n_base, lane, cs_carry, flush);
 }
 
-template <int EPI, bool GLDS>
+template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,30 +217,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  bf16x8 ra[4], rw[4];
   if (nk > 0) {
-    if constexpr (GLDS) {
-      stage_tile_dma(p.A, p.lda, m0, p.M, kbeg, smem, tid);
-      stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg, smem + TILE_BYTES, tid);
-    } else {
-      stage_tile_load(p.A, p.lda, m0, p.M, kbeg, tid, ra);
-      stage_tile_load(p.W, p.ldw, n0, p.N, kbeg, tid, rw);
-      stage_tile_write(smem, tid, ra);
-      stage_tile_write(smem + TILE_BYTES, tid, rw);
-    }
+    stage_tile_dma(p.A, p.lda, m0, p.M, kbeg, smem, tid);
+    stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg, smem + TILE_BYTES, tid);
   }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();   // tile kt landed (vmcnt(0) is part of the barrier's release while LDS-DMA is pending)
     char* cur = smem + (kt & 1) * STAGE_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
     if (kt + 1 < nk) {
-      if constexpr (GLDS) {
-        stage_tile_dma(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, nxt, tid);
-        stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BK, nxt + TILE_BYTES, tid);
-      } else {
-        stage_tile_load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, tid, ra);
-        stage_tile_load(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BK, tid, rw);
-      }
+      stage_tile_dma(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, nxt, tid);
+      stage_tile_dma(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BK, nxt + TILE_BYTES, tid);
     }
     const char* As = cur;
     const char* Ws = cur + TILE_BYTES;
@@ -287,12 +247,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    }
-    if constexpr (!GLDS) {
-      if (kt + 1 < nk) {   // the other buffer was last read in iteration kt-1, before this iteration's barrier
-        stage_tile_write(nxt, tid, ra);
-        stage_tile_write(nxt + TILE_BYTES, tid, rw);
-      }
     }
   }
 
@@ -380,7 +334,7 @@ __device__ __forceinline__ void stage2_dma(const bf16* __restrict__ src, long ld
   }
 }
 
-template <int EPI, int VAR>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,57 +370,25 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr bool PRIO = (VAR & 1) != 0, LATE_DMA = (VAR & 2) != 0, PREFETCH = (VAR & 4) != 0;
-    if (!LATE_DMA && kt + 2 < nk) STAGE2(kt + 2);
+    if (kt + 2 < nk) STAGE2(kt + 2);
     const char* As = smem2 + (kt % 3) * STAGE2_BYTES;
     const char* Ws = As + A2_BYTES;
     const int ar0 = wm * 64 + (lane & 31), wr0 = wn * 64 + (lane & 31);
-    auto ldfrag = [&](int kk, bf16x8 (&af)[2], bf16x8 (&wf)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
       const int s = kk * 2 + (lane >> 5);
+      bf16x8 af[2], wf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ar = ar0 + i * 32, wr = wr0 + i * 32;
         af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
         wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
       }
-    };
-    if constexpr (PREFETCH) {
-      bf16x8 afA[2], wfA[2], afB[2], wfB[2];
-      ldfrag(0, afA, wfA);
 #pragma unroll
-      for (int kk = 0; kk < 4; kk += 2) {
-        ldfrag(kk + 1, afB, wfB);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfA[ni], afA[mi], acc[ni][mi], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (LATE_DMA && kk == 0 && kt + 2 < nk) STAGE2(kt + 2);
-        if (kk + 2 < 4) ldfrag(kk + 2, afA, wfA);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfB[ni], afB[mi], acc[ni][mi], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 af[2], wf[2];
-        ldfrag(kk, af, wf);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (LATE_DMA && kk == 0 && kt + 2 < nk) STAGE2(kt + 2);
-      }
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
   }
 #undef STAGE2
@@ -568,20 +490,7 @@ constexpr int T3_BYTES = 256 * BK * 2;              // 32 KiB per operand tile
 constexpr int STAGE3_BYTES = 2 * T3_BYTES;          // 64 KiB
 constexpr int LDS3_BYTES = 2 * STAGE3_BYTES;        // 128 KiB
 
-// one 16-B chunk per lane (one LDS-DMA wave-instruction) of a 256-row operand tile: chunk group c in 0..3
-__device__ __forceinline__ void dma_one(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0, char* lds_tile, int tid, int c) {
-  const int id = c * 512 + tid;
-  const int row = id >> 3, ps = id & 7;
-  const int ls = ps ^ ((row >> 1) & 7);
-  int grow = row0 + row;
-  grow = grow < nrows ? grow : nrows - 1;
-  const bf16* g = src + (long)grow * ld + k0 + ls * 8;
-  const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
-  __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
-}
-
-// ABL (timing experiments only, results are garbage): 1 = no DMA, 2 = no LDS fragment reads, 3 = MFMA only
-template <int EPI, bool INTERLEAVE, int ABL = 0>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,9 +505,6 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
   const int m0 = tile_m * BM3, n0 = tile_n * BN3;
   const int nk = p.K / BK;
-  if (p.stagger && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   f32x16 acc[2][2][2];      // [m half][ni][mi]
 #pragma unroll
@@ -610,100 +516,223 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
-  const int rot = p.krot ? (tile_m * 5 + tile_n * 3) % nk : 0;
-#define KOF3(kt_) ((((kt_) + rot) >= nk ? (kt_) + rot - nk : (kt_) + rot) * BK)
 #define STAGE3(kt_)                                                                           \
   do {                                                                                        \
     char* b_ = smem3 + ((kt_) & 1) * STAGE3_BYTES;                                            \
-    const int k0_ = KOF3(kt_);                                                                \
-    stage2_dma(p.A, p.lda, m0, p.M, k0_, b_, tid, 4);                                         \
-    stage2_dma(p.W, p.ldw, n0, p.N, k0_, b_ + T3_BYTES, tid, 4);                              \
+    stage2_dma(p.A, p.lda, m0, p.M, (kt_) * BK, b_, tid, 4);                                  \
+    stage2_dma(p.W, p.ldw, n0, p.N, (kt_) * BK, b_ + T3_BYTES, tid, 4);                       \
   } while (0)
 
-  if (ABL != 1 && ABL != 3) STAGE3(0);
-  bf16x8 cst;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cst[e] = (bf16)(0.001f * (lane + e));
+  STAGE3(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
-    const bool more = kt + 1 < nk;
-    if (!INTERLEAVE && more && ABL != 1 && ABL != 3) STAGE3(kt + 1);
+    if (kt + 1 < nk) STAGE3(kt + 1);
     const char* As = smem3 + (kt & 1) * STAGE3_BYTES;
     const char* Ws = As + T3_BYTES;
-    char* nxt = smem3 + ((kt + 1) & 1) * STAGE3_BYTES;
-    const int knext = KOF3(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int s = kk * 2 + (lane >> 5);
       bf16x8 af[4], wf[2];
-      if constexpr (ABL >= 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { af[i] = cst; asm volatile("" : "+v"(af[i])); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { wf[i] = cst; asm volatile("" : "+v"(wf[i])); }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ar = wm * 128 + i * 32 + (lane & 31);
-          af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int wr = wn * 64 + i * 32 + (lane & 31);
-          wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
-        }
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 128 + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int i = 0; i < 2; ++i) {
+        const int wr = wn * 64 + i * 32 + (lane & 31);
+        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
             acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
-        if constexpr (INTERLEAVE) {
-          // one LDS-DMA instruction of the next tile behind every group of 4 MFMAs: the 64 DMA wave-instructions of a
-          // k-step trickle into the address path while the matrix pipe works instead of blocking all waves up front
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            if (h == 0) dma_one(p.A, p.lda, m0, p.M, knext, nxt, tid, kk);
-            else dma_one(p.W, p.ldw, n0, p.N, knext, nxt + T3_BYTES, tid, kk);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
     }
   }
 #undef STAGE3
   __syncthreads();                                     // all waves done with the staging buffers
   char* wt = smem3 + wave * 16384;                     // 16 KiB private epilogue region per wave
-  if constexpr (ABL == 5) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[h][i][j]));
-    return;
-  }
   float cs_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // column sums of both m-halves go out in one set of atomics
 #pragma unroll
   for (int h = 0; h < 2; ++h)
-    epilogue_bf16<EPI, ABL == 4>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, cs_carry, h == 1);
+    epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, cs_carry, h == 1);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// v7: the 256x256x64 tile with FOUR waves (2 x 2), one per SIMD, each owning a 128x128 wave tile = 4 x 4 MFMA tiles
-// (256 fp32 accumulators; the 512-register budget of a lone wave per SIMD holds them next to two sets of fragments).
-// Why: in v3 every k-step pulls (128 + 64) x 128 B of fragments per wave x 8 waves = 192 KiB out of LDS while the LDS-DMA
-// writes 64 KiB into it -- 2048 clocks of the 128 B/clk LDS port, the same as the 2062 MFMA clocks of the step, so the
-// LDS port is a co-bottleneck.  128x128 wave tiles read (128 + 128) x 128 B x 4 = 128 KiB (1024 + 512 clocks).  With a
-// single wave per SIMD there is no other wave to hide LDS latency, so the fragments of k-group kk+1 are fetched before the
-// 16 MFMAs of kk are issued (explicit double buffer).
+// p8: the 256x256x64 tile on an 8-phase schedule (cdna_hip_programming.md, "The 256^2 8-phase template"): the default
+// kernel for the bf16-output GEMMs of the training step.  8 waves as 2(m) x 4(n), wave tile 128x64 = four 64x32
+// quadrants; v_mfma_f32_16x16x32_bf16, 16 per quadrant per K-tile.  What differs from v3:
+//  * A K-tile is staged as FOUR 16-KiB half-tiles (A-h0, A-h1, W-h0, W-h1; half h of an operand = the rows every wave
+//    needs for its quadrants (h, *) resp. (*, h)), one half-tile = 2 LDS-DMA instructions per thread per PHASE, so the DMA
+//    stream trickles through the whole K-tile instead of arriving as one burst behind a barrier.
+//  * A phase = {LDS fragment reads of one quadrant's new operand half (12 / 4 / 8 / 0 ds_read_b128) || 2 LDS-DMA issues}
+//    -> s_barrier -> 16 MFMA -> s_barrier.  The two wave rows (wr = 0 / 1; one wave of each per SIMD) run ONE barrier apart,
+//    so on every SIMD one wave feeds the matrix pipe while its partner reads LDS / issues DMA.
+//  * The DMA queue is never drained inside the loop: one counted s_waitcnt vmcnt(6) per K-tile (phase 4 / 8) leaves the
+//    three newest half-tiles in flight across the raw s_barriers; three half-tiles (2-3 phases = 1-1.5k cycles) of latency
+//    tolerance per load.  Fragment reads are inline-asm ds_read_b128, invisible to the compiler's waitcnt pass (which
+//    would otherwise wait for every pending LDS-DMA before any LDS read); their completion is the explicit lgkmcnt(0)
+//    in front of each MFMA cluster.
+// Hazards (all by construction, never by timing; "phase" = two barriers):
+//  RAW  a half-tile is read only in a phase AFTER the phase whose first barrier follows the vmcnt that retired it:
+//       phase 4's wait retires the whole next K-tile, read in phases 5-7; phase 8's the one read in phases 1-3.
+//  WAR  a slot is restaged >= 2 phases after the phase that read it (A-h0: read P1, restaged P3; W-h1: P2 -> P4; A-h1: P3 ->
+//       next P1), or 1 phase after when an lgkmcnt BEFORE the reading phase's first barrier retired the reads (W-h0: the
+//       four W reads are issued first in P1 and retired by lgkmcnt(8) there; restaged in P2).
+// LDS image of a half-tile: 128 rows x 128 B, 16-B slot index XOR (row>>1)&7 (on the DMA source address and on the read
+// address): every ds_read_b128 lane group of the 16x16x32 operand pattern hits 16 distinct slots.
+constexpr int P8_HT = 128 * BK * 2;        // half-tile: 128 rows x 64 k = 16 KiB
+constexpr int P8_BUF = 4 * P8_HT;          // K-tile: A-h0 | A-h1 | W-h0 | W-h1 = 64 KiB
+constexpr int P8_LDS = 2 * P8_BUF;         // 128 KiB
+
+template <int OFF>
+__device__ __forceinline__ void p8_dsr(bf16x8& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// acc[mi][ni] = D[n][m] of a 16x16 block: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j -> the same 64x64 bf16 LDS
+// tile image as epi_convert (consumed by epi_store).
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_v7_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem7[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves, wave tile 128 (m) x 128 (n)
+__device__ __forceinline__ void epi_convert16(const GemmP& p, f32x4 (&acc)[4][4], char* t0, char* t1, int n_base, int lane) {
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = ni * 16 + 4 * (lane >> 4);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n_base + col < p.N) b = *(const f32x4*)(p.bias + n_base + col);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = mi * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] * scale + b[j];
+      const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
+      if constexpr (EPI == EPI_GELU) {
+        if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+      } else {
+        *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// Epilogue of an INTERIOR tile (no bounds checks): the wave's whole 128x64 block in one go.  The accumulators are scaled /
+// biased / activated, rounded to bf16 and written to a 128-row x 128-B image in the wave's private 16-KiB LDS region (16-B chunk
+// index XOR row&7), read back row-major and stored as FULL 128-B lines: 8 lanes x 16 B per row, 8 rows per wave instruction.
+// (tools/store_bench.cpp: a CU sustains ~45 B/clk with full-line stores, 12 B/clk with 64-B row segments, 6 B/clk with the raw
+// 32-B accumulator layout -- hence the LDS transposition.)  Same arithmetic as epi_convert16 + epi_store.
+template <bool GELU>   // one 64-row half of the wave's block: bf16(v) or bf16(gelu(v)), v = alpha * acc + bias
+__device__ __forceinline__ void p8_write_half(f32x4 (&acc)[4][4], char* img, float scale, const f32x4 (&b)[4], int lane) {
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int row = mi * 16 + m;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[mi][ni][j] * scale + b[ni][j];
+        if constexpr (GELU) v[j] = gelu_erf(v[j]);
+      }
+      const int off = row * 128 + ((((ni * 2 + (g >> 1)) ^ (row & 7)) << 4) | ((g & 1) << 3));
+      *(bf16x4*)(img + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void p8_epilogue_full(const GemmP& p, f32x4 (&acc)[2][4][4], char* wt, int m_base, int n_base, int lane) {
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+  f32x4 b[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + 4 * (lane >> 4));
+  }
+  const int r8 = lane >> 3, c16 = lane & 7;
+  const long n = n_base + c16 * 8;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    char* img = wt + h * 8192;                         // 64 rows x 128 B
+    const long mrow = m_base + h * 64 + r8;
+    // operands of the store pass first: their latency hides behind the conversion
+    bf16x8 ex[8];
+    if (EPI == EPI_GELU_GRAD || (EPI == EPI_BF16 && p.R)) {
+      const bf16* src = EPI == EPI_GELU_GRAD ? p.G : p.R;
+      const long ld = EPI == EPI_GELU_GRAD ? p.ldg : p.ldr;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) ex[it] = *(const bf16x8*)(src + (mrow + it * 8) * ld + n);
+    }
+    if constexpr (EPI == EPI_GELU) {
+      if (p.C2) {
+        p8_write_half<false>(acc[h], img, scale, b, lane);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + r8;
+          *(bf16x8*)(p.C2 + (mrow + it * 8) * p.ldc2 + n) = *(const bf16x8*)(img + row * 128 + ((c16 ^ (row & 7)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      p8_write_half<true>(acc[h], img, scale, b, lane);
+    } else {
+      p8_write_half<false>(acc[h], img, scale, b, lane);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + r8;
+      bf16x8 o = *(const bf16x8*)(img + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if constexpr (EPI == EPI_BF16) {
+        if (p.R) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)ex[it][e]);
+        }
+      }
+      if constexpr (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)ex[it][e]));
+      }
+      if constexpr (EPI != EPI_GELU) {
+        if (p.colsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
+        }
+      }
+      *(bf16x8*)((bf16*)p.C + (mrow + it * 8) * p.ldc + n) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (EPI != EPI_GELU) {
+    if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        cs[e] = v;
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(p.colsum + n + e, cs[e]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem8[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves, wave tile 128 (m) x 64 (n)
   const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
   int t;
   {
@@ -713,653 +742,211 @@ __global__ __launch_bounds__(256) void gemm_nt_v7_kernel(GemmP p) {
   int tile_m, tile_n;
   tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
   const int m0 = tile_m * BM3, n0 = tile_n * BN3;
-  const int nk = p.K / BK;
+  const int nk = p.K / BK;                           // even, >= 2 (launcher)
 
-  f32x16 acc[2][2][2][2];      // [n half][m half][ni][mi]: acc[hn][hm] is the 64x64 block the shared epilogue takes
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][i][j][r] = 0.f;
-
-  // Per-thread source pointers of its 16 chunks of a stage (8 of A, 8 of W), computed once: a k-step only adds BK elements.
-  // Chunk c of an operand: tile row (c*256 + tid) >> 3, physical 16-B slot (tid & 7), logical slot swizzled on the source.
-  const bf16* gsrc[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int op = c >> 3, cc = c & 7;
-    const int id = cc * 256 + tid;
-    const int row = id >> 3, ps = id & 7;
-    const int ls = ps ^ ((row >> 1) & 7);
-    const int nrows = op == 0 ? p.M : p.N;
-    int grow = (op == 0 ? m0 : n0) + row;
-    grow = grow < nrows ? grow : nrows - 1;
-    gsrc[c] = (op == 0 ? p.A + (long)grow * p.lda : p.W + (long)grow * p.ldw) + ls * 8;
-  }
-  auto dma = [&](int c, int kt) {                       // chunk c of stage kt
-    char* tile = smem7 + (kt & 1) * STAGE3_BYTES + (c >> 3) * T3_BYTES;
-    const int wave_base = __builtin_amdgcn_readfirstlane(((c & 7) * 256 + (tid & ~63)) * 16);
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gsrc[c] + kt * BK), (LDS_AS void*)(tile + wave_base), 16, 0, 0);
-  };
-  auto frags = [&](const char* As, const char* Ws, int kk, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
-    const int s = kk * 2 + (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ar = wm * 128 + i * 32 + (lane & 31);
-      af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-      const int wr = wn * 128 + i * 32 + (lane & 31);
-      wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
-    }
-  };
-
-#pragma unroll
-  for (int c = 0; c < 16; ++c) dma(c, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();                                   // tile kt landed; everyone finished reading the other stage
-    const bool more = kt + 1 < nk;
-    const char* As = smem7 + (kt & 1) * STAGE3_BYTES;
-    const char* Ws = As + T3_BYTES;
-    bf16x8 af[2][4], wf[2][4];
-    frags(As, Ws, 0, af[0], wf[0]);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk + 1 < 4) frags(As, Ws, kk + 1, af[(kk + 1) & 1], wf[(kk + 1) & 1]);
-#pragma unroll
-      for (int n4 = 0; n4 < 4; ++n4) {
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
-          acc[n4 >> 1][m4 >> 1][n4 & 1][m4 & 1] =
-              __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][n4], af[kk & 1][m4], acc[n4 >> 1][m4 >> 1][n4 & 1][m4 & 1], 0, 0, 0);
-        // the lone wave of this SIMD also has to issue the next stage's DMA: two instructions behind each of the first
-        // eight MFMA groups of the k-step, so the matrix pipe keeps running while the address path takes them
-        if (kk < 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            dma((kk * 4 + n4) * 2, kt + 1);
-            dma((kk * 4 + n4) * 2 + 1, kt + 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-  }
-  __syncthreads();                                     // all waves done with the staging buffers
-  char* wt = smem7 + wave * 16384;                     // 16 KiB private epilogue region per wave
-#pragma unroll
-  for (int hn = 0; hn < 2; ++hn)
-#pragma unroll
-    for (int hm = 0; hm < 2; ++hm)
-      epilogue_bf16<EPI>(p, acc[hn][hm], wt, m0 + wm * 128 + hm * 64, n0 + wn * 128 + hn * 64, lane);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// v5: PERSISTENT v3.  One 512-thread workgroup per CU walks its share of the 256x256 tiles; the k-steps of consecutive
-// tiles form one continuous double-buffered stream, so the next tile's first stage is already in flight while the current
-// tile's epilogue runs, no workgroup dispatch sits between tiles, and the epilogue's (fire-and-forget) global stores drain
-// under the next tile's MFMAs.  Motivation (ablation on 93184x3072x768): 790 TF as launched per tile, 1035 with the stores
-// skipped, 1268 with no epilogue.  Workgroup b keeps XCD b%8 and takes tiles start_x + (b>>3) + j*(blocks per XCD) of that
-// XCD's contiguous range, so the tiles an XCD runs concurrently stay neighbours (same A panels in its L2).
-// The epilogue uses only the 64-KiB stage that was just consumed (8 KiB per wave); GELU's two outputs go out in two passes.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem5[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
-  const int nk = p.K / BK;
-  // this workgroup's tiles
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int q = nt >> 3, r = nt & 7;
-  const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int xn = xcd < r ? q + 1 : q;
-  const int my_tiles = lb < xn ? (xn - lb + bpx - 1) / bpx : 0;
-  if (my_tiles == 0) return;
-  const long S = (long)my_tiles * nk;
-
-  f32x16 acc[2][2][2];
+  f32x4 acc[2][4][4];                                // [m half][mi][ni], 128 accumulators
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging cursor (one step ahead of the compute cursor)
-  int sj = 0, skt = 0, sm0, sn0;
+  // ---- LDS-DMA sources.  DMA instruction i (0/1) of a half-tile: chunk id = i*512 + tid -> half-tile row lr = id >> 3,
+  // physical slot id & 7 (LDS destination is lane-linear), logical k-slot = slot ^ ((lr >> 1) & 7).
+  // A-h: lr -> tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W-h: lr -> tile column (lr >> 5) * 64 + h * 32 + (lr & 31).
+  uint32_t offA[2][2], offW[2][2];                   // byte offsets from p.A / p.W (+ k), [half][instruction]
   {
-    int tm, tn;
-    tile_of(xs + lb, ntm, ntn, p.order, tm, tn);
-    sm0 = tm * BM3; sn0 = tn * BN3;
-  }
-  int cm0 = sm0, cn0 = sn0, ckt = 0;
-  auto stage = [&](long g) {
-    char* b_ = smem5 + (g & 1) * STAGE3_BYTES;
-    stage2_dma(p.A, p.lda, sm0, p.M, skt * BK, b_, tid, 4);
-    stage2_dma(p.W, p.ldw, sn0, p.N, skt * BK, b_ + T3_BYTES, tid, 4);
-    if (++skt == nk) {
-      skt = 0;
-      ++sj;
-      if (sj < my_tiles) {
-        int tm, tn;
-        tile_of(xs + lb + sj * bpx, ntm, ntn, p.order, tm, tn);
-        sm0 = tm * BM3; sn0 = tn * BN3;
-      }
-    }
-  };
-  stage(0);
-  int cj = 0;
-  for (long g = 0; g < S; ++g) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage g landed (issued a whole k-step ago); older epilogue stores done
-    __builtin_amdgcn_s_barrier();
-    if (g + 1 < S) stage(g + 1);
-    const char* As = smem5 + (g & 1) * STAGE3_BYTES;
-    const char* Ws = As + T3_BYTES;
+    const uint32_t ls16 = (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int s = kk * 2 + (lane >> 5);
-      bf16x8 af[4], wf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ar = wm * 128 + i * 32 + (lane & 31);
-        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-      }
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int wr = wn * 64 + i * 32 + (lane & 31);
-        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
+        int row = m0 + i * 128 + h * 64 + (tid >> 3);
+        row = row < p.M ? row : p.M - 1;               // clamped rows are computed and never stored
+        offA[h][i] = (uint32_t)row * (uint32_t)(p.lda * 2) + ls16;
+        int col = n0 + (i * 2 + (tid >> 8)) * 64 + h * 32 + ((tid >> 3) & 31);
+        col = col < p.N ? col : p.N - 1;
+        offW[h][i] = (uint32_t)col * (uint32_t)(p.ldw * 2) + ls16;
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
-    }
-    if (++ckt == nk) {      // tile finished: epilogue out of the stage that was just consumed; stage g+1 keeps landing meanwhile
-      ckt = 0;
-      __builtin_amdgcn_s_barrier();                      // every wave is done reading stage g
-      char* wt = smem5 + (g & 1) * STAGE3_BYTES + wave * 8192;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if constexpr (EPI == EPI_GELU) {
-          if (p.C2) epilogue_bf16<EPI_GELU, false, 1>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
-          epilogue_bf16<EPI_GELU, false, 2>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
-        } else {
-          epilogue_bf16<EPI>(p, acc[h], wt, cm0 + wm * 128 + h * 64, cn0 + wn * 64, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
-      }
-      ++cj;
-      if (cj < my_tiles) {
-        int tm, tn;
-        tile_of(xs + lb + cj * bpx, ntm, ntn, p.order, tm, tn);
-        cm0 = tm * BM3; cn0 = tn * BN3;
-      }
-    }
   }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// v6: v5 + WAVE SPECIALISATION.  vmcnt is an in-order per-wave counter that also counts stores, so in v5 every wave had to
-// see its own epilogue stores (a chip-wide 32-MiB burst ~ 8 us at HBM write speed) complete before it could consume the next
-// LDS-DMA stage: the stores never overlapped the next tile.  Here waves 4-7 ("loaders") issue ALL LDS-DMA and the R / G
-// fix-up loads and never store; every wave converts its accumulators into its 8-KiB LDS region; waves 0-3 ("storers") issue
-// ALL global stores (two regions each) and contain no VMEM load at all (the bias vector is staged into LDS once per kernel),
-// so nothing in a storer ever waits on vmcnt and the stores drain under the next tile's MFMAs.
-constexpr int BIAS6_BYTES = 16384;                  // bias staged in LDS: N <= 4096
-constexpr int LDS6_BYTES = LDS3_BYTES + BIAS6_BYTES;
-
-// loader waves: tile[row][*] (+)= R, *= gelu'(G), in place in LDS (16 B per lane, row-coalesced global loads)
-template <int EPI>
-__device__ __forceinline__ void epi_fixup(const GemmP& p, char* t0, int m_base, int n_base, int lane) {
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-    const int m = m_base + row, n = n_base + c16 * 8;
-    if (m >= p.M || n >= p.N) continue;
-    const int off = row * 128 + ((c16 ^ (row & 7)) << 4);
-    const bool full = n + 8 <= p.N;
-    bf16x8 o = *(const bf16x8*)(t0 + off);
-    if (p.R) {
-      bf16x8 r = {};
-      if (full) r = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
-      else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); r[0] = h4[0]; r[1] = h4[1]; r[2] = h4[2]; r[3] = h4[3]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)r[e]);
-    }
-    if constexpr (EPI == EPI_GELU_GRAD) {
-      bf16x8 x = {};
-      if (full) x = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
-      else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); x[0] = h4[0]; x[1] = h4[1]; x[2] = h4[2]; x[3] = h4[3]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)x[e]));
-    }
-    *(bf16x8*)(t0 + off) = o;
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_v6_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem6[];
-  float* bias_lds = (float*)(smem6 + LDS3_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const bool loader = wave >= 4;
-  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
-  const int nk = p.K / BK;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int q = nt >> 3, r = nt & 7;
-  const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int xn = xcd < r ? q + 1 : q;
-  const int my_tiles = lb < xn ? (xn - lb + bpx - 1) / bpx : 0;
-  if (my_tiles == 0) return;
-  const long S = (long)my_tiles * nk;
-  if (p.bias) {
-    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias[i];
-  }
-  GemmP pe = p;                                   // epilogue view: R / G are applied by the loaders' fix-up, not by epi_store
-  pe.R = nullptr;
-
-  f32x16 acc[2][2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
-
-  int sj = 0, skt = 0, sm0, sn0;
-  {
-    int tm, tn;
-    tile_of(xs + lb, ntm, ntn, p.order, tm, tn);
-    sm0 = tm * BM3; sn0 = tn * BN3;
-  }
-  int cm0 = sm0, cn0 = sn0, ckt = 0, cj = 0;
-  // loaders only: 2048 chunks per operand tile / 256 loader threads = 8 LDS-DMA instructions per operand per stage
-  auto stage = [&](long g) {
-    char* b_ = smem6 + (g & 1) * STAGE3_BYTES;
-    const int lt = tid - 256;
-#pragma unroll
-    for (int op = 0; op < 2; ++op) {
-      const bf16* src = op ? p.W : p.A;
-      const long ld = op ? p.ldw : p.lda;
-      const int row0 = op ? sn0 : sm0, nrows = op ? p.N : p.M;
-      char* tile = b_ + op * T3_BYTES;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int id = c * 256 + lt;
-        const int row = id >> 3, ps = id & 7;
-        const int ls = ps ^ ((row >> 1) & 7);
-        int grow = row0 + row;
-        grow = grow < nrows ? grow : nrows - 1;
-        const bf16* gp = src + (long)grow * ld + skt * BK + ls * 8;
-        const int wave_base = __builtin_amdgcn_readfirstlane((c * 256 + (lt & ~63)) * 16);
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gp, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
-      }
-    }
-  };
-  auto advance_stage = [&]() {
-    if (++skt == nk) {
-      skt = 0;
-      ++sj;
-      if (sj < my_tiles) {
-        int tm, tn;
-        tile_of(xs + lb + sj * bpx, ntm, ntn, p.order, tm, tn);
-        sm0 = tm * BM3; sn0 = tn * BN3;
-      }
-    }
-  };
-  if (loader) stage(0);
-  advance_stage();
-  for (long g = 0; g < S; ++g) {
-    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loaders' DMA of stage g (and fix-up loads) landed
-    __builtin_amdgcn_s_barrier();
-    if (g + 1 < S) {
-      if (loader) stage(g + 1);
-      advance_stage();
-    }
-    const char* As = smem6 + (g & 1) * STAGE3_BYTES;
-    const char* Ws = As + T3_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int s = kk * 2 + (lane >> 5);
-      bf16x8 af[4], wf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ar = wm * 128 + i * 32 + (lane & 31);
-        af[i] = *(const bf16x8*)(As + ar * 128 + ((s ^ ((ar >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wr = wn * 64 + i * 32 + (lane & 31);
-        wf[i] = *(const bf16x8*)(Ws + wr * 128 + ((s ^ ((wr >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
-    }
-    if (++ckt == nk) {
-      ckt = 0;
-      char* base = smem6 + (g & 1) * STAGE3_BYTES;         // the stage just consumed: 8 regions of 8 KiB
-      char* mine = base + wave * 8192;
-      constexpr bool FIX = (EPI == EPI_GELU_GRAD);
-      const bool fix = FIX || p.R != nullptr;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        constexpr int NPASS = (EPI == EPI_GELU) ? 2 : 1;
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-          if (EPI == EPI_GELU && pass == 0 && !p.C2) continue;
-          __builtin_amdgcn_s_barrier();                    // regions free: main-loop reads / previous stores' LDS reads done
-          if constexpr (EPI == EPI_GELU) {
-            if (pass == 0) epi_convert<EPI_GELU, 1>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
-            else epi_convert<EPI_GELU, 2>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
-          } else {
-            epi_convert<EPI, 0>(p, acc[h], mine, mine, cn0 + wn * 64, lane, bias_lds);
-          }
-          __builtin_amdgcn_s_barrier();
-          if (fix) {                                        // loaders patch R / gelu'(G) into two regions each
-            if (loader) {
-#pragma unroll
-              for (int rr = 0; rr < 2; ++rr) {
-                const int w2 = (wave - 4) + rr * 4;
-                epi_fixup<EPI>(p, base + w2 * 8192, cm0 + (w2 >> 2) * 128 + h * 64, cn0 + (w2 & 3) * 64, lane);
-              }
-            }
-            __builtin_amdgcn_s_barrier();
-          }
-          if (!loader) {                                    // storers: two regions each, no VMEM loads in this path
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-              const int w2 = wave + rr * 4;
-              const char* reg = base + w2 * 8192;
-              const int mb = cm0 + (w2 >> 2) * 128 + h * 64, nb = cn0 + (w2 & 3) * 64;
-              if constexpr (EPI == EPI_GELU) {
-                if (pass == 0) epi_store<EPI_GELU, false, 1>(pe, reg, reg, mb, nb, lane);
-                else epi_store<EPI_GELU, false, 2>(pe, reg, reg, mb, nb, lane);
-              } else if constexpr (EPI == EPI_GELU_GRAD) {
-                epi_store<EPI_BF16, false, 0>(pe, reg, reg, mb, nb, lane);      // gelu' already applied by the fix-up
-              } else {
-                epi_store<EPI, false, 0>(pe, reg, reg, mb, nb, lane);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
-      }
-      ++cj;
-      if (cj < my_tiles) {
-        int tm, tn;
-        tile_of(xs + lb + cj * bpx, ntm, ntn, p.order, tm, tn);
-        cm0 = tm * BM3; cn0 = tn * BN3;
-      }
-    }
-  }
-}
-
-template <int EPI>
-int launch_v6_one(const GemmP& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS6_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  const long nt = (long)((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
-  int nb = nt >= 256 ? 256 : (int)((nt + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_nt_v6_kernel<EPI>), dim3(nb), dim3(512), LDS6_BYTES, st, p);
-  return SPMM_OK;
-}
-
-template <int EPI>
-int launch_v5_one(const GemmP& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  const long nt = (long)((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
-  int nb = nt >= 256 ? 256 : (int)((nt + 7) / 8) * 8;     // one workgroup per CU, a multiple of the 8 XCDs
-  hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI>), dim3(nb), dim3(512), LDS3_BYTES, st, p);
-  return SPMM_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// v4: the 256x256 tile with a FOUR-slot ring of BK=32 stages (4 x 32 KiB = 128 KiB), three stages always in flight.
-// Model behind it (PMC + aliasing experiments): the loop is DMA-latency bound, throughput ~ bytes in flight / latency;
-// v3 keeps 64 KiB in flight per CU (=> ~25 GB/s/CU at the ~2.5 us it takes a stage to land, 39 % MFMA busy), this ring
-// keeps 96 KiB in flight.  LDS rows are 64 B here, so the 16-B slot index is XOR-ed with (row>>2)&3.
-constexpr int BK4 = 32;
-constexpr int T4_BYTES = 256 * BK4 * 2;             // 16 KiB per operand tile
-constexpr int STAGE4_BYTES = 2 * T4_BYTES;          // 32 KiB
-constexpr int LDS4_BYTES = 4 * STAGE4_BYTES;        // 128 KiB
-
-__device__ __forceinline__ void dma4(const bf16* __restrict__ src, long ld, int row0, int nrows, int k0, char* lds_tile, int tid) {
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int id = c * 512 + tid;
-    const int row = id >> 2, ps = id & 3;
-    const int ls = ps ^ ((row >> 2) & 3);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;
-    const bf16* g = src + (long)grow * ld + k0 + ls * 8;
-    const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds_tile + wave_base), 16, 0, 0);
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_v4_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem4[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
-  int t;
-  {
-    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
-  int tile_m, tile_n;
-  tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
-  const int m0 = tile_m * BM3, n0 = tile_n * BN3;
-  const int nk = p.K / BK4;
-
-  f32x16 acc[2][2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-
-#define STAGE4(kt_)                                                                       \
-  do {                                                                                    \
-    char* b_ = smem4 + ((kt_) & 3) * STAGE4_BYTES;                                        \
-    dma4(p.A, p.lda, m0, p.M, (kt_) * BK4, b_, tid);                                      \
-    dma4(p.W, p.ldw, n0, p.N, (kt_) * BK4, b_ + T4_BYTES, tid);                           \
+  const char* gA = (const char*)p.A;
+  const char* gW = (const char*)p.W;
+#define P8_STG(GB, O, SLOT)                                                                                               \
+  do {                                                                                                                    \
+    char* d_ = smem8 + (SLOT) + wave * 1024;                                                                              \
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((GB) + (O)[0]), (LDS_AS void*)d_, 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((GB) + (O)[1]), (LDS_AS void*)(d_ + 8192), 16, 0, 0);        \
   } while (0)
+#define P8_STG_A(H, BUF, KT) P8_STG(gA + (size_t)(KT) * (BK * 2), offA[H], (BUF) * P8_BUF + (H) * P8_HT)
+#define P8_STG_W(H, BUF, KT) P8_STG(gW + (size_t)(KT) * (BK * 2), offW[H], (BUF) * P8_BUF + (2 + (H)) * P8_HT)
 
-  STAGE4(0);
-  if (nk > 1) STAGE4(1);
-  if (nk > 2) STAGE4(2);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; the 4 DMA instructions of each younger stage may still be in flight
-    const int younger = min(nk - 1 - kt, 2);
-    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // also: everyone is done reading slot (kt-1)&3 == (kt+3)&3
-    if (kt + 3 < nk) STAGE4(kt + 3);
-    const char* As = smem4 + (kt & 3) * STAGE4_BYTES;
-    const char* Ws = As + T4_BYTES;
+  // ---- fragment read addresses (16x16x32 operand: lane -> row lane & 15, k-slot kk*4 + (lane >> 4))
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem8;
+  uint32_t aad[2][2], wad[2][2];                     // [buffer][kk]
+  {
+    const uint32_t sw = (uint32_t)((lane >> 1) & 7), r16 = (uint32_t)(lane & 15), q = (uint32_t)(lane >> 4);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int s = kk * 2 + (lane >> 5);
-      bf16x8 af[4], wf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ar = wm * 128 + i * 32 + (lane & 31);
-        af[i] = *(const bf16x8*)(As + ar * 64 + ((s ^ ((ar >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wr = wn * 64 + i * 32 + (lane & 31);
-        wf[i] = *(const bf16x8*)(Ws + wr * 64 + ((s ^ ((wr >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[h][ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[h * 2 + mi], acc[h][ni][mi], 0, 0, 0);
+      const uint32_t slot = ((((uint32_t)kk * 4 + q) ^ sw) << 4);
+      aad[0][kk] = lds0 + ((uint32_t)wr * 64 + r16) * 128 + slot;
+      wad[0][kk] = lds0 + 2 * P8_HT + ((uint32_t)wc * 32 + r16) * 128 + slot;
+      aad[1][kk] = aad[0][kk] + P8_BUF;
+      wad[1][kk] = wad[0][kk] + P8_BUF;
     }
   }
-#undef STAGE4
-  __builtin_amdgcn_s_barrier();
-  char* wt = smem4 + wave * 16384;
+  bf16x8 fa[4][2], fw0[2][2], fw1[2][2];             // A half [mi][kk]; W halves [ni][kk]
+#define P8_RD_A(BUF, H)                                                                       \
+  do {                                                                                        \
+    p8_dsr<(H) * P8_HT + 0 * 2048>(fa[0][0], aad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 1 * 2048>(fa[1][0], aad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 2 * 2048>(fa[2][0], aad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 3 * 2048>(fa[3][0], aad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 0 * 2048>(fa[0][1], aad[BUF][1]);                                    \
+    p8_dsr<(H) * P8_HT + 1 * 2048>(fa[1][1], aad[BUF][1]);                                    \
+    p8_dsr<(H) * P8_HT + 2 * 2048>(fa[2][1], aad[BUF][1]);                                    \
+    p8_dsr<(H) * P8_HT + 3 * 2048>(fa[3][1], aad[BUF][1]);                                    \
+  } while (0)
+#define P8_RD_W(BUF, H, FW)                                                                   \
+  do {                                                                                        \
+    p8_dsr<(H) * P8_HT + 0 * 2048>(FW[0][0], wad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 1 * 2048>(FW[1][0], wad[BUF][0]);                                    \
+    p8_dsr<(H) * P8_HT + 0 * 2048>(FW[0][1], wad[BUF][1]);                                    \
+    p8_dsr<(H) * P8_HT + 1 * 2048>(FW[1][1], wad[BUF][1]);                                    \
+  } while (0)
+  // one quadrant x K=64: 16 MFMA, 8 independent accumulators between dependent pairs
+#define P8_MM(H, NH, FW)                                                                                        \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                         \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                         \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                                         \
+      acc[H][mi_][(NH) * 2 + ni_] =                                                                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[ni_][kk_], fa[mi_][kk_], acc[H][mi_][(NH) * 2 + ni_], 0, 0, 0); \
+  } while (0)
+#define P8_BAR() __builtin_amdgcn_s_barrier()
+#define P8_SB() __builtin_amdgcn_sched_barrier(0)
+#define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  // barrier -> operands landed -> MFMA cluster at raised priority -> barrier
+#define P8_COMPUTE(H, NH, FW)                    \
+  do {                                           \
+    P8_BAR();                                    \
+    P8_LGKM0();                                  \
+    P8_SB();                                     \
+    __builtin_amdgcn_s_setprio(1);               \
+    P8_MM(H, NH, FW);                            \
+    __builtin_amdgcn_s_setprio(0);               \
+    P8_SB();                                     \
+    P8_BAR();                                    \
+    P8_SB();                                     \
+  } while (0)
+
+  // ---- prologue: K-tile 0 complete, the first three half-tiles of K-tile 1 in flight
+  P8_STG_A(0, 0, 0); P8_STG_W(0, 0, 0); P8_STG_W(1, 0, 0); P8_STG_A(1, 0, 0);
+  P8_STG_W(0, 1, 1); P8_STG_A(0, 1, 1); P8_STG_W(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  P8_BAR();
+  P8_SB();
+  if (wr == 1) P8_BAR();                             // the second wave row runs one barrier behind the first
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    const bool more = kt + 2 < nk;                   // wave-uniform
+    // ---------------- K-tile kt (buffer 0)
+    P8_RD_W(0, 0, fw0); P8_SB(); P8_RD_A(0, 0);                                   // phase 1
+    P8_STG_A(1, 1, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                            // the four W-h0 reads: slot free for phase 2
+    P8_COMPUTE(0, 0, fw0);
+    P8_RD_W(0, 1, fw1);                                                           // phase 2
+    if (more) P8_STG_W(0, 0, kt + 2);
+    P8_COMPUTE(0, 1, fw1);
+    P8_RD_A(0, 1);                                                                // phase 3
+    if (more) P8_STG_A(0, 0, kt + 2);
+    P8_COMPUTE(1, 1, fw1);
+    if (more) {                                                                   // phase 4
+      P8_STG_W(1, 0, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            // K-tile kt+1 complete (this wave's pieces)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    P8_COMPUTE(1, 0, fw0);
+    // ---------------- K-tile kt+1 (buffer 1)
+    P8_RD_W(1, 0, fw0); P8_SB(); P8_RD_A(1, 0);                                   // phase 5
+    if (more) P8_STG_A(1, 0, kt + 2);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    P8_COMPUTE(0, 0, fw0);
+    P8_RD_W(1, 1, fw1);                                                           // phase 6
+    if (more) P8_STG_W(0, 1, kt + 3);
+    P8_COMPUTE(0, 1, fw1);
+    P8_RD_A(1, 1);                                                                // phase 7
+    if (more) P8_STG_A(0, 1, kt + 3);
+    P8_COMPUTE(1, 1, fw1);
+    if (more) {                                                                   // phase 8
+      P8_STG_W(1, 1, kt + 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            // K-tile kt+2 complete
+    }
+    P8_COMPUTE(1, 0, fw0);
+  }
+  if (wr == 0) P8_BAR();                             // re-join the two wave rows: every wave is past its last LDS read
+#undef P8_STG
+#undef P8_STG_A
+#undef P8_STG_W
+#undef P8_RD_A
+#undef P8_RD_W
+#undef P8_MM
+#undef P8_COMPUTE
+
+  char* wt = smem8 + wave * 16384;                   // 16 KiB private epilogue region per wave
+  if (m0 + BM3 <= p.M && n0 + BN3 <= p.N) {          // interior tile: no bounds checks
+    p8_epilogue_full<EPI>(p, acc, wt, m0 + wr * 128, n0 + wc * 64, lane);
+    return;
+  }
+  float cs_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    epilogue_bf16<EPI>(p, acc[h], wt, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+  for (int h = 0; h < 2; ++h) {
+    epi_convert16<EPI>(p, acc[h], wt, wt + 8192, n0 + wc * 64, lane);
+    epi_store<EPI>(p, wt, wt + 8192, m0 + wr * 128 + h * 64, n0 + wc * 64, lane, cs_carry, h == 1);
+  }
+}
+#undef P8_BAR
+#undef P8_SB
+#undef P8_LGKM0
+
+// ---- launchers.  The dynamic-LDS attribute of a kernel is raised exactly once (function-local static: thread-safe).
+template <typename K>
+int raise_lds(K kernel, int bytes, const char* what) {
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    spmm_set_error("spmm_gemm_nt: cannot raise the dynamic LDS of %s to %d: %s", what, bytes, hipGetErrorString(e));
+    return SPMM_ERR_LAUNCH;
+  }
+  return SPMM_OK;
 }
 
 template <int EPI>
-int launch_v4_one(const GemmP& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS4_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
+int launch_p8_one(const GemmP& p, hipStream_t st) {
+  static const int rc = raise_lds(gemm_nt_p8_kernel<EPI>, P8_LDS, "the 8-phase kernel");
+  if (rc != SPMM_OK) return rc;
   dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_v4_kernel<EPI>), grid, dim3(512), LDS4_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI>), grid, dim3(512), P8_LDS, st, p);
   return SPMM_OK;
+}
+int launch_p8(int epi, const GemmP& p, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch_p8_one<EPI_BF16>(p, st);
+    case EPI_GELU: return launch_p8_one<EPI_GELU>(p, st);
+    case EPI_GELU_GRAD: return launch_p8_one<EPI_GELU_GRAD>(p, st);
+    default: return -1;
+  }
 }
 
-template <int EPI, bool IL>
-int launch_v3_il(const GemmP& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, IL>), grid, dim3(512), LDS3_BYTES, st, p);
-  return SPMM_OK;
-}
-static int g_krot = 0;
-static int g_stagger = 0;
-static int g_force_tile = 0;          // 0: heuristic, 1/2/3: force the 128x128 / 256x128 / 256x256 kernel (tuning sweeps)
-static int g_tile_order = 3;          // row-major, split into 2 column groups when N >= 2048 and K <= 1024: lowest measured L2-miss traffic (profiles/r01_pmc_nt_gemm.txt); launch time is order-insensitive
-static int g_v3_abl = 0;           // timing ablations of v3 (0 = none)
-static int g_v3_interleave = 0;   // interleaving the DMA issue with the MFMA groups measured equal / slightly worse
-template <int ABL>
-int launch_v3_abl(const GemmP& p, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI_BF16, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI_BF16, false, ABL>), grid, dim3(512), LDS3_BYTES, st, p);
-  return SPMM_OK;
-}
 template <int EPI>
 int launch_v3_one(const GemmP& p, hipStream_t st) {
-  if (EPI == EPI_BF16 && g_v3_abl == 1) return launch_v3_abl<1>(p, st);
-  if (EPI == EPI_BF16 && g_v3_abl == 2) return launch_v3_abl<2>(p, st);
-  if (EPI == EPI_BF16 && g_v3_abl == 3) return launch_v3_abl<3>(p, st);
-  if (EPI == EPI_BF16 && g_v3_abl == 4) return launch_v3_abl<4>(p, st);
-  if (EPI == EPI_BF16 && g_v3_abl == 5) return launch_v3_abl<5>(p, st);
-  return g_v3_interleave ? launch_v3_il<EPI, true>(p, st) : launch_v3_il<EPI, false>(p, st);
-}
-static int g_use_v7 = 0;           // 1: four-wave 128x128-wave-tile variant of the 256x256 kernel
-template <int EPI>
-int launch_v7_one(const GemmP& p, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS3_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
+  static const int rc = raise_lds(gemm_nt_v3_kernel<EPI>, LDS3_BYTES, "the 256x256 kernel");
+  if (rc != SPMM_OK) return rc;
   dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI>), grid, dim3(256), LDS3_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI>), grid, dim3(512), LDS3_BYTES, st, p);
   return SPMM_OK;
 }
-static int g_use_v4 = 0;
-static int g_use_v5 = 0;           // 0 (default): per-tile v3; 1: persistent v5; 2: persistent + wave-specialised v6 -- all three measure the same
 int launch_v3(int epi, const GemmP& p, hipStream_t st) {
-  if (g_use_v7 && g_v3_abl == 0) {
-    switch (epi) {
-      case EPI_BF16: return launch_v7_one<EPI_BF16>(p, st);
-      case EPI_GELU: return launch_v7_one<EPI_GELU>(p, st);
-      case EPI_GELU_GRAD: return launch_v7_one<EPI_GELU_GRAD>(p, st);
-      default: return -1;
-    }
-  }
-  if (g_use_v5 == 2 && !g_use_v4 && g_v3_abl == 0 && p.N <= 4096) {
-    switch (epi) {
-      case EPI_BF16: return launch_v6_one<EPI_BF16>(p, st);
-      case EPI_GELU: return launch_v6_one<EPI_GELU>(p, st);
-      case EPI_GELU_GRAD: return launch_v6_one<EPI_GELU_GRAD>(p, st);
-      default: return -1;
-    }
-  }
-  if (g_use_v5 && !g_use_v4 && g_v3_abl == 0) {
-    switch (epi) {
-      case EPI_BF16: return launch_v5_one<EPI_BF16>(p, st);
-      case EPI_GELU: return launch_v5_one<EPI_GELU>(p, st);
-      case EPI_GELU_GRAD: return launch_v5_one<EPI_GELU_GRAD>(p, st);
-      default: return -1;
-    }
-  }
-  if (g_use_v4) {
-    switch (epi) {
-      case EPI_BF16: return launch_v4_one<EPI_BF16>(p, st);
-      case EPI_GELU: return launch_v4_one<EPI_GELU>(p, st);
-      case EPI_GELU_GRAD: return launch_v4_one<EPI_GELU_GRAD>(p, st);
-      default: return -1;
-    }
-  }
   switch (epi) {
     case EPI_BF16: return launch_v3_one<EPI_BF16>(p, st);
     case EPI_GELU: return launch_v3_one<EPI_GELU>(p, st);
@@ -1368,75 +955,43 @@ int launch_v3(int epi, const GemmP& p, hipStream_t st) {
   }
 }
 
-static int g_v2_variant = 0;
-template <int EPI, int VAR>
-int launch_v2_var(const GemmP& p, dim3 grid, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
-    if (e != hipSuccess) {
-      spmm_set_error("spmm_gemm_nt: cannot raise dynamic LDS to %d: %s", LDS2_BYTES, hipGetErrorString(e));
-      return SPMM_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, VAR>), grid, dim3(512), LDS2_BYTES, st, p);
+template <int EPI>
+int launch_v2_one(const GemmP& p, hipStream_t st) {
+  static const int rc = raise_lds(gemm_nt_v2_kernel<EPI>, LDS2_BYTES, "the 256x128 kernel");
+  if (rc != SPMM_OK) return rc;
+  dim3 grid(((p.M + BM2 - 1) / BM2) * ((p.N + BN - 1) / BN));
+  hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI>), grid, dim3(512), LDS2_BYTES, st, p);
   return SPMM_OK;
 }
-template <int EPI>
-int launch_v2_one(const GemmP& p, dim3 grid, hipStream_t st) {
-  switch (g_v2_variant) {
-    case 1: return launch_v2_var<EPI, 1>(p, grid, st);
-    case 2: return launch_v2_var<EPI, 2>(p, grid, st);
-    case 3: return launch_v2_var<EPI, 3>(p, grid, st);
-    case 4: return launch_v2_var<EPI, 4>(p, grid, st);
-    case 5: return launch_v2_var<EPI, 5>(p, grid, st);
-    case 7: return launch_v2_var<EPI, 7>(p, grid, st);
-    default: return launch_v2_var<EPI, 0>(p, grid, st);
-  }
-}
 int launch_v2(int epi, const GemmP& p, hipStream_t st) {
-  dim3 grid(((p.M + BM2 - 1) / BM2) * ((p.N + BN - 1) / BN));
   switch (epi) {
-    case EPI_BF16: return launch_v2_one<EPI_BF16>(p, grid, st);
-    case EPI_GELU: return launch_v2_one<EPI_GELU>(p, grid, st);
-    case EPI_F32: return launch_v2_one<EPI_F32>(p, grid, st);
-    case EPI_GELU_GRAD: return launch_v2_one<EPI_GELU_GRAD>(p, grid, st);
-    case EPI_F32_ACC: return launch_v2_one<EPI_F32_ACC>(p, grid, st);
+    case EPI_BF16: return launch_v2_one<EPI_BF16>(p, st);
+    case EPI_GELU: return launch_v2_one<EPI_GELU>(p, st);
+    case EPI_F32: return launch_v2_one<EPI_F32>(p, st);
+    case EPI_GELU_GRAD: return launch_v2_one<EPI_GELU_GRAD>(p, st);
+    case EPI_F32_ACC: return launch_v2_one<EPI_F32_ACC>(p, st);
     default: return -1;
   }
 }
 
-template <bool GLDS>
-int launch(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
+int launch_v1(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
   switch (epi) {
-    case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<EPI_BF16, GLDS>), grid, dim3(256), 0, st, p); break;
-    case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU, GLDS>), grid, dim3(256), 0, st, p); break;
-    case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32, GLDS>), grid, dim3(256), 0, st, p); break;
-    case EPI_F32_ATOMIC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ATOMIC, GLDS>), grid, dim3(256), 0, st, p); break;
-    case EPI_GELU_GRAD: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU_GRAD, GLDS>), grid, dim3(256), 0, st, p); break;
-    case EPI_F32_ACC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ACC, GLDS>), grid, dim3(256), 0, st, p); break;
-    default: spmm_set_error("spmm_gemm_nt: unknown epilogue %d", epi); return SPMM_ERR_UNSUPPORTED;
+    case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<EPI_BF16>), grid, dim3(256), 0, st, p); break;
+    case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32_ATOMIC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ATOMIC>), grid, dim3(256), 0, st, p); break;
+    case EPI_GELU_GRAD: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU_GRAD>), grid, dim3(256), 0, st, p); break;
+    case EPI_F32_ACC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ACC>), grid, dim3(256), 0, st, p); break;
+    default: return -1;
   }
   return SPMM_OK;
 }
 
-}  // namespace
-
-static int g_gemm_use_glds = 1;    // 1: LDS-DMA staging, 0: register staging (v1 only), 2: force the v1 kernel with LDS-DMA
-extern "C" void spmm_gemm_set_staging(int use_lds_dma) { g_gemm_use_glds = use_lds_dma; }
-extern "C" void spmm_gemm_set_variant(int v) {
-  if (v >= 300 && v <= 304) { g_tile_order = v - 300; return; }
-  if (v == 400 || v == 401) { g_use_v4 = v - 400; return; }
-  if (v >= 500 && v <= 505) { g_v3_abl = v - 500; return; }
-  if (v == 700 || v == 701) { g_krot = v - 700; return; }
-  if (v >= 800 && v <= 803) { g_force_tile = v - 800; return; }
-  if (v >= 900 && v <= 915) { g_stagger = v - 900; return; }
-  if (v == 1000 || v == 1001) { g_use_v7 = v - 1000; return; }
-  if (v >= 600 && v <= 602) { g_use_v5 = v - 600; return; }   // 600: v3 per-tile launch, 601: persistent v5, 602: wave-specialised v6
-  if (v == 200) g_v3_interleave = 0;
-  else if (v == 201) g_v3_interleave = 1;
-  else g_v2_variant = v;
+inline bool is_bf16_epi(int epi) { return epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD; }
+// the 8-phase kernel walks K two tiles at a time and addresses its DMA sources with 32-bit byte offsets
+inline bool p8_ok(const GemmP& p, int epi) {
+  return is_bf16_epi(epi) && p.K % 128 == 0 && (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 32) &&
+         (unsigned long)p.N * (unsigned long)p.ldw * 2ul < (1ul << 32);
 }
 
 // Which tile kernel for an M x N output?  Per-tile efficiency (bytes through the per-CU load path per FLOP) favours the big
@@ -1444,8 +999,8 @@ extern "C" void spmm_gemm_set_variant(int v) {
 // 256x128 kernels hold one workgroup per CU (128 / 144 KiB LDS); the 128x128 kernel (32 KiB) runs several per CU, so its fill
 // is smooth.  Constants from tools/bench_gemm_tiles.py.  Used for the decoder's shapes (M = beams x molecules < 6000), e.g.
 // 5000x768x3072: 640 TF with 128x128 vs 472 with 256x128 vs 292 with 256x256.
-static int pick_tile(int M, int N, int epi) {
-  const bool bf = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD;
+int pick_tile(int M, int N, int epi) {
+  const bool bf = is_bf16_epi(epi);
   if (M >= 6000) {
     // Training-step shapes keep the simple rule (256x256 whenever it gives >= 96 tiles): inside the step the small-M GEMMs run
     // next to another stream's kernels, which fill the CUs a coarse tiling leaves idle, and the per-tile efficiency of the big
@@ -1464,52 +1019,56 @@ static int pick_tile(int M, int N, int epi) {
   return s2 >= s1 ? 2 : 1;
 }
 
+}  // namespace
+
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
                             const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
                             const void* G, long ldg, void* C, long ldc, void* C2, long ldc2, int epi, float* colsum,
-                            hipStream_t stream) {
+                            int kernel, hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(K % 64 == 0, "spmm_gemm_nt: K=%d must be a multiple of 64", K);
   SPMM_CHECK_SHAPE(N % 4 == 0, "spmm_gemm_nt: N=%d must be a multiple of 4", N);
   SPMM_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0, "spmm_gemm_nt: lda/ldw must be multiples of 8 elements");
   SPMM_CHECK_SHAPE(ldc % 4 == 0, "spmm_gemm_nt: ldc must be a multiple of 4");
-  SPMM_CHECK_SHAPE(epi == EPI_F32 || epi == EPI_F32_ATOMIC || epi == EPI_F32_ACC || (ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!G || ldg % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0),
+  SPMM_CHECK_SHAPE(!is_bf16_epi(epi) || (ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!G || ldg % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0),
                    "spmm_gemm_nt: bf16 outputs need 16-B aligned rows (ldc/ldr/ldg/ldc2 multiples of 8)");
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
+  SPMM_CHECK_SHAPE(epi >= EPI_BF16 && epi <= EPI_F32_ACC, "spmm_gemm_nt: unknown epilogue %d", epi);
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
   SPMM_CHECK_SHAPE(epi != EPI_GELU_GRAD || G != nullptr, "spmm_gemm_nt: GELU-grad epilogue needs G");
+  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
   int ksplit = ((K / 64 + splits - 1) / splits) * 64;
   splits = (K + ksplit - 1) / ksplit;
   GemmP p;
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.order = (g_tile_order >= 3 && K > 1024) ? 0 : g_tile_order; p.colsum = colsum; p.krot = g_krot; p.stagger = g_stagger;
-  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
-  if (g_gemm_use_glds == 1 && splits == 1 && g_v2_variant != 100) {   // v3: 256x256 tile when it still fills the chip
-    const bool want3 = g_force_tile ? g_force_tile == 3 : (pick_tile(M, N, epi) == 3 || g_v2_variant == 101);
-    if (want3 && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD)) {
-      int rc3 = launch_v3(epi, p, stream);
-      if (rc3 > 0) return rc3;
-      if (rc3 == 0) {
-        SPMM_LAUNCH_CHECK("spmm_gemm_nt(v3)");
-        return SPMM_OK;
-      }
-    }
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum;
+  // tile order 3 (row-major inside two column groups, so an XCD's W panel stays L2-resident) when W is wide and K short:
+  // the lowest HBM-side traffic measured (profiles/r01_pmc_nt_gemm.txt); launch time itself is order-insensitive
+  p.order = K > 1024 ? 0 : 3;
+
+  // kernel: 0 = choose (below); 1 = 128x128 (all epilogues, split-K); 2 = 256x128 three-stage ring (no atomics);
+  // 3 = 256x256 one-barrier-per-k-step (bf16 outputs); 8 = 256x256 8-phase (bf16 outputs, K % 128 == 0)
+  int k = kernel;
+  if (k == 0) {
+    const int tile = splits > 1 ? 1 : pick_tile(M, N, epi);
+    k = tile == 3 ? (p8_ok(p, epi) ? 8 : 3) : tile;
+    if (k == 2 && (epi == EPI_F32_ATOMIC || M < 512)) k = 1;
   }
-  if (g_gemm_use_glds == 1 && splits == 1 && epi != EPI_F32_ATOMIC && M >= 512 && (g_force_tile ? g_force_tile != 1 : pick_tile(M, N, epi) != 1)) {   // v2: 256x128 tile, 3-stage ring
-    int rc2 = launch_v2(epi, p, stream);
-    if (rc2 > 0) return rc2;
-    if (rc2 == 0) {
-      SPMM_LAUNCH_CHECK("spmm_gemm_nt(v2)");
-      return SPMM_OK;
-    }
-  }
-  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, 1, splits);
-  int rc = g_gemm_use_glds ? launch<true>(epi, p, grid, stream) : launch<false>(epi, p, grid, stream);
-  if (rc != SPMM_OK) return rc;
+  SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 8, "spmm_gemm_nt: unknown kernel selector %d", kernel);
+  SPMM_CHECK_SHAPE(k != 8 || p8_ok(p, epi), "spmm_gemm_nt: the 8-phase kernel needs a bf16-output epilogue, K %% 128 == 0 and operands < 4 GiB");
+  SPMM_CHECK_SHAPE(k != 3 || is_bf16_epi(epi), "spmm_gemm_nt: the 256x256 kernel has bf16-output epilogues only");
+  SPMM_CHECK_SHAPE(k != 2 || epi != EPI_F32_ATOMIC, "spmm_gemm_nt: the 256x128 kernel has no atomic epilogue");
+  SPMM_CHECK_SHAPE(k == 1 || splits == 1, "spmm_gemm_nt: split-K runs on the 128x128 kernel only");
+  int rc;
+  if (k == 8) rc = launch_p8(epi, p, stream);
+  else if (k == 3) rc = launch_v3(epi, p, stream);
+  else if (k == 2) rc = launch_v2(epi, p, stream);
+  else rc = launch_v1(epi, p, dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splits), stream);
+  if (rc > 0) return rc;
+  if (rc < 0) { spmm_set_error("spmm_gemm_nt: epilogue %d is not built for kernel %d", epi, k); return SPMM_ERR_UNSUPPORTED; }
   SPMM_LAUNCH_CHECK("spmm_gemm_nt");
   return SPMM_OK;
 }

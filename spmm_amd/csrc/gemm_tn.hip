@@ -206,155 +206,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// v3: 256 (n) x 256 (k) output tile, 512 threads (8 waves as 2(n) x 4(k), 128x64 per wave), two 64-KiB stages of
-// [64 reduction rows][256 columns] per operand (512-B LDS rows).  Same reasoning as the NT v3 kernel: the 128x128 tile is
-// bound by the L2->LDS stream (32 KiB per 512 MFMA cycles), 256x256 needs 64 KiB per 2048.
-constexpr int BT3 = 256;
-constexpr int TILE3_BYTES = BR * BT3 * 2;     // 32 KiB
-constexpr int STAGE3_BYTES = 2 * TILE3_BYTES; // 64 KiB
-constexpr int TN3_LDS = 2 * STAGE3_BYTES;     // 128 KiB
-
-__device__ __forceinline__ int tn3_off(int row, int c16) { return row * 512 + ((c16 ^ ((row & 3) << 2)) << 4); }
-
-__device__ __forceinline__ void tn3_stage_dma(const bf16* __restrict__ src, long ld, int m0, int col0, int ncols, char* tile, int tid) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int id = c * 512 + tid;
-    const int row = id >> 5, pc = id & 31;
-    const int lc = pc ^ ((row & 3) << 2);
-    int col = col0 + lc * 8;
-    col = col < ncols ? col : ((ncols - 1) & ~7);
-    const bf16* g = src + (long)(m0 + row) * ld + col;
-    const int wave_base = __builtin_amdgcn_readfirstlane((c * 512 + (tid & ~63)) * 16);
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(tile + wave_base), 16, 0, 0);
-  }
-}
-__device__ __forceinline__ void tn3_stage_regs(const bf16* __restrict__ src, long ld, int m0, int M, int col0, int ncols, char* tile, int tid) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int id = c * 512 + tid;
-    const int row = id >> 5, pc = id & 31;
-    const int lc = pc ^ ((row & 3) << 2);
-    int col = col0 + lc * 8;
-    col = col < ncols ? col : ((ncols - 1) & ~7);
-    bf16x8 v;
-    if (m0 + row < M) {
-      v = *(const bf16x8*)(src + (long)(m0 + row) * ld + col);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-    }
-    *(bf16x8*)(tile + id * 16) = v;
-  }
-}
-__device__ __forceinline__ unsigned tn3_addr(const char* tile, int mb, int colb, int i16, int h) {
-  const int col = colb + (i16 & 3) * 4;
-  const int r = mb + 4 * h + (i16 >> 2);
-  return (unsigned)(size_t)(tile + tn3_off(r, col >> 3) + (col & 7) * 2);
-}
-// 12 transpose reads of one 16-row k-slice: four 32-column blocks of A (n) and two of B (k); one wait.
-__device__ __forceinline__ void tn3_frags(const char* As, const char* Bs, int mb, int ncol, int kcol, int i16, bf16x8 (&af)[4], bf16x8 (&bfr)[2]) {
-  unsigned ad[12];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) { ad[2 * b] = tn3_addr(As, mb, ncol + 32 * b, i16, 0); ad[2 * b + 1] = tn3_addr(As, mb, ncol + 32 * b, i16, 1); }
-#pragma unroll
-  for (int b = 0; b < 2; ++b) { ad[8 + 2 * b] = tn3_addr(Bs, mb, kcol + 32 * b, i16, 0); ad[9 + 2 * b] = tn3_addr(Bs, mb, kcol + 32 * b, i16, 1); }
-  bf16x4 r[12];
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %13\n\tds_read_b64_tr_b16 %2, %14\n\tds_read_b64_tr_b16 %3, %15\n\t"
-      "ds_read_b64_tr_b16 %4, %16\n\tds_read_b64_tr_b16 %5, %17\n\tds_read_b64_tr_b16 %6, %18\n\tds_read_b64_tr_b16 %7, %19\n\t"
-      "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %21\n\tds_read_b64_tr_b16 %10, %22\n\tds_read_b64_tr_b16 %11, %23\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]),
-        "=&v"(r[10]), "=&v"(r[11])
-      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "v"(ad[8]), "v"(ad[9]), "v"(ad[10]),
-        "v"(ad[11])
-      : "memory");
-#pragma unroll
-  for (int b = 0; b < 4; ++b) af[b] = tn_join(r[2 * b], r[2 * b + 1]);
-#pragma unroll
-  for (int b = 0; b < 2; ++b) bfr[b] = tn_join(r[8 + 2 * b], r[9 + 2 * b]);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <bool SLAB>
-__global__ __launch_bounds__(512) void gemm_tn_v3_kernel(TnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 2, wk = wave & 3;           // wave tile 128 (n) x 64 (k)
-  const int i16 = lane & 15, j = lane >> 4;
-  const int ntn = (p.N + BT3 - 1) / BT3, ntk = (p.K + BT3 - 1) / BT3, nt = ntn * ntk;
-  int t;
-  {
-    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
-  const int n0 = (t / ntk) * BT3, k0 = (t % ntk) * BT3;
-  const int mbeg = blockIdx.z * p.rsplit;
-  const int mend = min(p.M, mbeg + p.rsplit);
-  const int nsteps = (mend - mbeg + BR - 1) / BR;
-
-  f32x16 acc[2][4];   // [ki][ni]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  auto stage = [&](int s, char* buf) {
-    const int m0 = mbeg + s * BR;
-    if (m0 + BR <= p.M) {
-      tn3_stage_dma(p.A, p.lda, m0, n0, p.N, buf, tid);
-      tn3_stage_dma(p.B, p.ldb, m0, k0, p.K, buf + TILE3_BYTES, tid);
-    } else {
-      tn3_stage_regs(p.A, p.lda, m0, p.M, n0, p.N, buf, tid);
-      tn3_stage_regs(p.B, p.ldb, m0, p.M, k0, p.K, buf + TILE3_BYTES, tid);
-    }
-  };
-  if (nsteps > 0) stage(0, smem3);
-  for (int s = 0; s < nsteps; ++s) {
-    __syncthreads();
-    char* cur = smem3 + (s & 1) * STAGE3_BYTES;
-    if (s + 1 < nsteps) stage(s + 1, smem3 + ((s + 1) & 1) * STAGE3_BYTES);
-    const char* As = cur;
-    const char* Bs = cur + TILE3_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[4], bfr[2];
-      tn3_frags(As, Bs, kk * 16 + (j >> 1) * 8, wn * 128 + (j & 1) * 16, wk * 64 + (j & 1) * 16, i16, af, bfr);
-#pragma unroll
-      for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[ki][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ki], af[ni], acc[ki][ni], 0, 0, 0);
-    }
-  }
-  float* out = SLAB ? p.slab + (long)blockIdx.z * p.N * p.K : p.C;
-  const long ldo = SLAB ? p.K : p.ldc;
-#pragma unroll
-  for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 128 + ni * 32 + (lane & 31);
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int k = k0 + wk * 64 + ki * 32 + 8 * g + 4 * (lane >> 5);
-        if (k >= p.K) continue;
-        f32x4* dst = (f32x4*)(out + (long)n * ldo + k);
-        f32x4 v = {acc[ki][ni][g * 4] * p.alpha, acc[ki][ni][g * 4 + 1] * p.alpha, acc[ki][ni][g * 4 + 2] * p.alpha,
-                   acc[ki][ni][g * 4 + 3] * p.alpha};
-        if constexpr (!SLAB) {
-          const f32x4 o = *dst;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        }
-        *dst = v;
-      }
-    }
-}
-
 // C[n*ldc + k] += sum_z slab[z][n][k]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int N, int K4, float* __restrict__ C,
                                                           long ldc) {
@@ -418,15 +269,13 @@ extern "C" long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits) {
   return splits > 1 ? (long)splits * N * K * 4 : 0;
 }
 
-static int g_tn_variant = 1;     // 1 (default): 128x128 kernel, two workgroups per CU; 3: 256x256 tile for big problems (measured slower)
-static int g_tn_target = 1000;   // ~2 full rounds of the 2 x 256 resident workgroups (measured: 640 -> 1000 = +20..45 % on the big shapes)    // target number of workgroups (tiles x splits) for the 128x128 kernel
-extern "C" void spmm_gemm_tn_set_variant(int v) { if (v >= 64) g_tn_target = v; else g_tn_variant = v; }
-static bool tn_use_v3(int M, int N, int K) { return g_tn_variant == 3 && N >= 256 && K >= 256 && M >= 2048; }
+// target number of workgroups (tiles x splits): ~2 full rounds of the 2 x 256 resident workgroups (measured: 640 -> 1000 =
+// +20..45 % on the training step's shapes)
+constexpr int TN_TARGET_WGS = 1000;
 
 extern "C" int spmm_gemm_tn_splits(int M, int N, int K) {
-  const int bt = tn_use_v3(M, N, K) ? BT3 : BT;
-  const int tiles = ((N + bt - 1) / bt) * ((K + bt - 1) / bt);
-  int s = ((bt == BT3 ? 256 : g_tn_target) + tiles / 2) / tiles;
+  const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
+  int s = (TN_TARGET_WGS + tiles / 2) / tiles;
   const int maxs = (M / BR) / 16 > 0 ? (M / BR) / 16 : 1;   // at least 16 reduction steps per split
   if (s > maxs) s = maxs;
   return s < 1 ? 1 : s;
@@ -446,30 +295,6 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
   TnP p;
   p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.rsplit = rsplit;
   p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha;
-  if (tn_use_v3(M, N, K)) {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_tn_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN3_LDS);
-      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN3_LDS);
-      if (e1 != hipSuccess || e2 != hipSuccess) {
-        spmm_set_error("spmm_gemm_tn: cannot raise dynamic LDS to %d", TN3_LDS);
-        return SPMM_ERR_LAUNCH;
-      }
-      attr = true;
-    }
-    const int tiles3 = ((N + BT3 - 1) / BT3) * ((K + BT3 - 1) / BT3);
-    dim3 grid3(tiles3, 1, splits);
-    if (splits > 1) {
-      hipLaunchKernelGGL(gemm_tn_v3_kernel<true>, grid3, dim3(512), TN3_LDS, stream, p);
-      long blocks = ((long)N * (K / 4) + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, splits, N, K / 4, C, ldc);
-    } else {
-      hipLaunchKernelGGL(gemm_tn_v3_kernel<false>, grid3, dim3(512), TN3_LDS, stream, p);
-    }
-    SPMM_LAUNCH_CHECK("spmm_gemm_tn(v3)");
-    return SPMM_OK;
-  }
   const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
   dim3 grid(tiles, 1, splits);
   if (splits > 1) {

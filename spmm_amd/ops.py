@@ -45,8 +45,9 @@ def _row_stride(t):
     return t.stride(0)
 
 
-def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None):
-    """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride)."""
+def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None, kernel=0):
+    """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride).  kernel: 0 = chosen from the shape,
+    1 / 2 / 3 / 8 force a tile kernel (SPMM_GEMM_* in include/spmm_hip.h)."""
     M, Ka = A.shape
     N = W.shape[0]
     K = Ka if K is None else K
@@ -57,7 +58,7 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
         assert C.dtype == torch.float32
     _call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
                float(alpha), _p(R), 0 if R is None else _row_stride(R), _p(G), 0 if G is None else _row_stride(G),
-               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), _st())
+               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), int(kernel), _st())
     return C
 
 

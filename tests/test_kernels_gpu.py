@@ -34,53 +34,57 @@ def close(got, ref, atol, rtol, name=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("staging", [1, 0])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (216, 300, 128), (6912, 768, 768), (100, 64, 3072),
                                    (512, 2304, 768)])
-def test_gemm_bf16_bias(ops, staging, M, N, K):
-    from spmm_amd._lib import lib
-    lib().cdll.spmm_gemm_set_staging(staging)
-    try:
-        A, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
-        bias = rnd(N, seed=3, dtype=torch.float32)
-        Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")     # bf16 rows must be 16-B aligned
-        C = Cbuf[:, :N]
-        ops.gemm_nt(A, W, C, bias=bias)
-        ref = A.float() @ W.float().t() + bias
-        close(C, ref, 2e-2, 1e-2, "gemm bf16")
-        assert (Cbuf[:, N:] == 7.0).all()
-    finally:
-        lib().cdll.spmm_gemm_set_staging(1)
+def test_gemm_bf16_bias(ops, M, N, K):
+    A, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")     # bf16 rows must be 16-B aligned
+    C = Cbuf[:, :N]
+    ops.gemm_nt(A, W, C, bias=bias)
+    ref = A.float() @ W.float().t() + bias
+    close(C, ref, 2e-2, 1e-2, "gemm bf16")
+    assert (Cbuf[:, N:] == 7.0).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072), (70000, 768, 128)])
-@pytest.mark.parametrize("use_v4", [0, 1, 2, 3, 4])   # 0: persistent v5, 1: v4 ring, 2: per-tile v3, 3: wave-specialised persistent v6, 4: four-wave v7
-def test_gemm_v3_256x256_tile(ops, M, N, K, use_v4):
-    """The 256x256-tile kernel is only picked for large problems; force it (variant 101) on small/ragged shapes too."""
-    from spmm_amd._lib import lib
-    lib().cdll.spmm_gemm_set_variant(101)
-    lib().cdll.spmm_gemm_set_variant(400 + (use_v4 == 1))
-    lib().cdll.spmm_gemm_set_variant(600 + {0: 1, 1: 0, 2: 0, 3: 2, 4: 0}[use_v4])
-    lib().cdll.spmm_gemm_set_variant(1000 + (use_v4 == 4))
-    try:
-        A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
-        bias = rnd(N, seed=23, dtype=torch.float32)
-        R = rnd(M, (N + 7) // 8 * 8, seed=24)[:, :N]
-        Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")
-        ops.gemm_nt(A, W, Cbuf[:, :N], bias=bias, R=R)
-        ref = A.float() @ W.float().t() + bias + R.float()
-        close(Cbuf[:, :N], ref, 3e-2, 1e-2, "gemm v3")
-        assert (Cbuf[:, N:] == 7.0).all()
-        C, C2 = torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda"), torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda")
-        ops.gemm_nt(A, W, C[:, :N], bias=bias, epi=ops.EPI_GELU, C2=C2[:, :N])
-        pre = A.float() @ W.float().t() + bias
-        close(C2[:, :N], pre, 3e-2, 1e-2, "v3 pre")
-        close(C[:, :N], torch.nn.functional.gelu(pre), 3e-2, 1e-2, "v3 gelu")
-    finally:
-        lib().cdll.spmm_gemm_set_variant(0)
-        lib().cdll.spmm_gemm_set_variant(400)
-        lib().cdll.spmm_gemm_set_variant(600)
-        lib().cdll.spmm_gemm_set_variant(1000)
+# kernel selector of spmm_gemm_nt (include/spmm_hip.h): 1 = 128x128, 2 = 256x128 ring, 3 = 256x256, 8 = 256x256 8-phase
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072), (70000, 768, 128)])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 8])
+def test_gemm_tile_kernels(ops, M, N, K, kernel):
+    """Every tile kernel forced on small / ragged / large shapes (the heuristic alone would never run the big tiles there):
+    bias + residual epilogue, GELU with pre-activation output, and untouched padding columns."""
+    A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
+    bias = rnd(N, seed=23, dtype=torch.float32)
+    R = rnd(M, (N + 7) // 8 * 8, seed=24)[:, :N]
+    Cbuf = torch.full((M, (N + 7) // 8 * 8), 7.0, dtype=BF, device="cuda")
+    ops.gemm_nt(A, W, Cbuf[:, :N], bias=bias, R=R, kernel=kernel)
+    ref = A.float() @ W.float().t() + bias + R.float()
+    close(Cbuf[:, :N], ref, 3e-2, 1e-2, f"gemm kernel {kernel}")
+    assert (Cbuf[:, N:] == 7.0).all()
+    C, C2 = torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda"), torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda")
+    ops.gemm_nt(A, W, C[:, :N], bias=bias, epi=ops.EPI_GELU, C2=C2[:, :N], kernel=kernel)
+    pre = A.float() @ W.float().t() + bias
+    close(C2[:, :N], pre, 3e-2, 1e-2, "pre-activation")
+    close(C[:, :N], torch.nn.functional.gelu(pre), 3e-2, 1e-2, "gelu")
+    G = rnd(M, (N + 7) // 8 * 8, seed=25)[:, :N]
+    D = torch.empty(M, Cbuf.shape[1], dtype=BF, device="cuda")
+    cs = torch.ones(N, device="cuda")
+    ops.gemm_nt(A, W, D[:, :N], epi=ops.EPI_GELU_GRAD, G=G, colsum=cs, kernel=kernel)
+    close(cs, 1.0 + D[:, :N].float().sum(0), 5e-2 * math.sqrt(M / 256), 2e-3, "fused column sums")
+    g = G.float().requires_grad_(True)
+    torch.nn.functional.gelu(g).sum().backward()
+    close(D[:, :N], (A.float() @ W.float().t()) * g.grad, 3e-2, 1.5e-2, "gelu grad")
+
+
+def test_gemm_kernel_selector_rejects_unsupported(ops):
+    A, W = rnd(256, 192), rnd(256, 192)
+    C = torch.empty(256, 256, dtype=BF, device="cuda")
+    with pytest.raises(RuntimeError, match="8-phase"):
+        ops.gemm_nt(A, W, C, kernel=8)          # K = 192 is not a multiple of 128
+    with pytest.raises(RuntimeError, match="bf16-output"):
+        ops.gemm_nt(A, W, torch.empty(256, 256, device="cuda"), epi=ops.EPI_F32, kernel=3)
+    with pytest.raises(RuntimeError, match="selector"):
+        ops.gemm_nt(A, W, C, kernel=5)
 
 
 def test_gemm_strided_operands_and_residual(ops):

@@ -1,0 +1,183 @@
+// Standalone check + timing of spmm_gemm_nt's tile kernels through the C ABI (no Python, no torch: starts in a second on a
+// fresh GPU box).  Build: make -C tools  ->  build/gemm_bench.   Usage:
+//   gemm_bench check                       every kernel vs a host fp64 reference on sampled rows, ragged and full shapes
+//   gemm_bench time M N K [epi] [rounds]   interleaved rounds of kernels 3 (256x256, one barrier per k-step) and 8 (8-phase)
+// Operands are uniform random in [-1, 1) (cdna_hip_programming.md 5.4 rule 25: never time on zeros).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include "../include/spmm_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static float urand() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (float)((rng_state >> 40) & 0xffffff) / 8388608.0f - 1.0f; }
+
+struct Buf {
+  void* d = nullptr; size_t bytes = 0;
+  void alloc(size_t b) { bytes = b; CK(hipMalloc(&d, b)); }
+  ~Buf() { if (d) (void)hipFree(d); }
+};
+static std::vector<uint16_t> rand_bf16(size_t n, float scale) { std::vector<uint16_t> v(n); for (auto& x : v) x = f2bf(urand() * scale); return v; }
+
+static int run(int kernel, int epi, const Buf& A, const Buf& W, int M, int N, int K, const float* bias, const Buf* R, const Buf* G, Buf& C, Buf* C2,
+               float* colsum, hipStream_t st) {
+  return spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, bias, nullptr, 1.0f, R ? R->d : nullptr, N, G ? G->d : nullptr, N, C.d, N, C2 ? C2->d : nullptr, N,
+                      epi, colsum, kernel, st);
+}
+
+static double gelu(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752)); }
+static double gelu_grad(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752)) + x * 0.3989422804014327 * exp(-0.5 * x * x); }
+
+static int check_one(int kernel, int epi, int M, int N, int K) {
+  auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f), hR = rand_bf16((size_t)M * N, 1.0f), hG = rand_bf16((size_t)M * N, 1.0f);
+  std::vector<float> hb(N);
+  for (auto& x : hb) x = urand();
+  Buf A, W, R, G, C, C2, bias, cs;
+  A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); R.alloc(hR.size() * 2); G.alloc(hG.size() * 2); C.alloc((size_t)M * N * 2); C2.alloc((size_t)M * N * 2);
+  bias.alloc(N * 4); cs.alloc(N * 4);
+  CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
+  CK(hipMemcpy(R.d, hR.data(), R.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(G.d, hG.data(), G.bytes, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias.d, hb.data(), bias.bytes, hipMemcpyHostToDevice));
+  CK(hipMemset(C.d, 0x7f, C.bytes)); CK(hipMemset(C2.d, 0x7f, C2.bytes)); CK(hipMemset(cs.d, 0, cs.bytes));
+  const bool use_r = epi == SPMM_EPI_BF16, use_cs = epi != SPMM_EPI_GELU;
+  int rc = run(kernel, epi, A, W, M, N, K, (const float*)bias.d, use_r ? &R : nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C,
+               epi == SPMM_EPI_GELU ? &C2 : nullptr, use_cs ? (float*)cs.d : nullptr, 0);
+  if (rc) { printf("  kernel %d epi %d %dx%dx%d: rc=%d %s\n", kernel, epi, M, N, K, rc, spmm_last_error()); return 1; }
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> hC((size_t)M * N), hC2((size_t)M * N);
+  std::vector<float> hcs(N);
+  CK(hipMemcpy(hC.data(), C.d, C.bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(hC2.data(), C2.d, C2.bytes, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hcs.data(), cs.d, cs.bytes, hipMemcpyDeviceToHost));
+  // host reference on a sample of rows (all columns): first / last rows of every 256-row tile edge plus random rows
+  std::vector<int> rows;
+  for (int r : {0, 1, 15, 16, 63, 64, 127, 128, 129, 191, 192, 255, 256, 257}) if (r < M) rows.push_back(r);
+  for (int r = M - 3; r < M; ++r) if (r >= 0) rows.push_back(r);
+  for (int i = 0; i < 40; ++i) rows.push_back((int)(fabsf(urand()) * (M - 1)));
+  std::sort(rows.begin(), rows.end()); rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  double maxerr = 0; long bad = 0;
+  for (int m : rows)
+    for (int n = 0; n < N; ++n) {
+      double acc = 0;
+      for (int k = 0; k < K; ++k) acc += (double)bf2f(hA[(size_t)m * K + k]) * (double)bf2f(hW[(size_t)n * K + k]);
+      acc += hb[n];
+      double ref = acc, ref2 = 0; bool has2 = false;
+      if (epi == SPMM_EPI_BF16) ref = (double)bf2f(f2bf((float)acc)) + bf2f(hR[(size_t)m * N + n]);   // the kernel rounds to bf16 before adding R
+      else if (epi == SPMM_EPI_GELU) { ref = gelu(acc); ref2 = acc; has2 = true; }
+      else if (epi == SPMM_EPI_GELU_GRAD) ref = acc * gelu_grad((double)bf2f(hG[(size_t)m * N + n]));
+      const double got = bf2f(hC[(size_t)m * N + n]);
+      double err = fabs(got - ref), tol = 2e-2 + 1e-2 * fabs(ref);
+      if (has2) { const double e2 = fabs(bf2f(hC2[(size_t)m * N + n]) - ref2); if (e2 > 2e-2 + 1e-2 * fabs(ref2)) { ++bad; } if (e2 > maxerr) maxerr = e2; }
+      if (err > tol) { if (bad < 5) printf("    bad C[%d][%d] = %g, ref %g\n", m, n, got, ref); ++bad; }
+      if (err > maxerr) maxerr = err;
+    }
+  // column sums against the DEVICE output itself (every row, so untouched / doubly written rows show up here)
+  double cserr = 0;
+  if (use_cs) {
+    std::vector<double> s(N, 0.0);
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) s[n] += bf2f(hC[(size_t)m * N + n]);
+    for (int n = 0; n < N; ++n) { double e = fabs(s[n] - hcs[n]) / (1.0 + fabs(s[n])); if (e > cserr) cserr = e; }
+    if (cserr > 2e-3) ++bad;
+  }
+  // every element must have been written exactly with a finite value (0x7f7f pattern = 3.39e38 would blow the sums up)
+  long untouched = 0;
+  for (size_t i = 0; i < hC.size(); ++i) if (hC[i] == 0x7f7f) ++untouched;
+  if (untouched) ++bad;
+  printf("  kernel %d epi %d %6dx%5dx%5d: max err %.3g  colsum rel err %.2g  untouched %ld  %s\n", kernel, epi, M, N, K, maxerr, cserr, untouched, bad ? "FAIL" : "ok");
+  return bad ? 1 : 0;
+}
+
+static int cmd_check() {
+  int fails = 0;
+  const int shapes[][3] = {{256, 256, 128}, {512, 768, 768}, {1000, 2304, 128}, {216, 304, 256}, {513, 520, 3072}, {6912, 768, 768}, {3000, 3072, 768}};
+  for (int kernel : {8, 3, 2, 1})
+    for (auto& s : shapes)
+      for (int epi : {SPMM_EPI_BF16, SPMM_EPI_GELU, SPMM_EPI_GELU_GRAD}) fails += check_one(kernel, epi, s[0], s[1], s[2]);
+  // repeated launches of one shape must agree bit for bit (a racy schedule shows up as run-to-run differences)
+  {
+    const int M = 8192, N = 3072, K = 768;
+    auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
+    Buf A, W, C0, C1; A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); C0.alloc((size_t)M * N * 2); C1.alloc((size_t)M * N * 2);
+    CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
+    run(1, SPMM_EPI_BF16, A, W, M, N, K, nullptr, nullptr, nullptr, C0, nullptr, nullptr, 0);
+    std::vector<uint16_t> ref((size_t)M * N), got((size_t)M * N);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(ref.data(), C0.d, C0.bytes, hipMemcpyDeviceToHost));
+    long diffs = 0, worst = 0;
+    for (int it = 0; it < 20; ++it) {
+      CK(hipMemset(C1.d, 0, C1.bytes));
+      run(8, SPMM_EPI_BF16, A, W, M, N, K, nullptr, nullptr, nullptr, C1, nullptr, nullptr, 0);
+      CK(hipDeviceSynchronize()); CK(hipMemcpy(got.data(), C1.d, C1.bytes, hipMemcpyDeviceToHost));
+      long d = 0;
+      for (size_t i = 0; i < got.size(); ++i) if (fabsf(bf2f(got[i]) - bf2f(ref[i])) > 0.02f + 0.01f * fabsf(bf2f(ref[i]))) ++d;
+      diffs += d; worst = std::max(worst, d);
+    }
+    printf("  8-phase vs 128x128 kernel, full %dx%dx%d output, 20 launches: %ld elements off (worst launch %ld)  %s\n", M, N, K, diffs, worst, diffs ? "FAIL" : "ok");
+    fails += diffs != 0;
+  }
+  printf("%s\n", fails ? "CHECK FAILED" : "CHECK OK");
+  return fails ? 1 : 0;
+}
+
+static int cmd_time(int M, int N, int K, int epi, int rounds) {
+  auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
+  Buf A, W, C, C2, G, bias;
+  A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); C.alloc((size_t)M * N * 2); C2.alloc((size_t)M * N * 2); G.alloc((size_t)M * N * 2); bias.alloc(N * 4);
+  CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
+  { auto hG = rand_bf16((size_t)M * N, 1.0f); CK(hipMemcpy(G.d, hG.data(), G.bytes, hipMemcpyHostToDevice)); }
+  CK(hipMemset(bias.d, 0, bias.bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int kernels[] = {3, 8};
+  std::vector<float> best(2, 1e30f), med[2];
+  const int iters = 10;
+  for (int r = 0; r < rounds; ++r)
+    for (int ki = 0; ki < 2; ++ki) {
+      for (int w = 0; w < 2; ++w) run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C, epi == SPMM_EPI_GELU ? &C2 : nullptr, nullptr, 0);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) {
+        int rc = run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C, epi == SPMM_EPI_GELU ? &C2 : nullptr, nullptr, 0);
+        if (rc) { printf("rc=%d %s\n", rc, spmm_last_error()); return 1; }
+      }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+      best[ki] = std::min(best[ki], ms); med[ki].push_back(ms);
+    }
+  const double fl = 2.0 * M * N * K;
+  printf("%6d x %5d x %5d epi %d :", M, N, K, epi);
+  for (int ki = 0; ki < 2; ++ki) {
+    std::sort(med[ki].begin(), med[ki].end());
+    const float m = med[ki][med[ki].size() / 2];
+    printf("  k%d %8.1f us %7.1f TF (best %7.1f)", kernels[ki], m * 1e3, fl / (m * 1e-3) / 1e12, fl / (best[ki] * 1e-3) / 1e12);
+  }
+  printf("\n");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "check")) return cmd_check();
+  if (argc >= 5 && !strcmp(argv[1], "time"))
+    return cmd_time(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 5);
+  if (argc >= 2 && !strcmp(argv[1], "step")) {   // the training step's dominant shapes (B=128, Lt=128: ~84k fusion tokens)
+    int rc = 0;
+    const int M = 84000;
+    rc |= cmd_time(M, 3072, 768, SPMM_EPI_GELU, 5);
+    rc |= cmd_time(M, 3072, 768, SPMM_EPI_GELU_GRAD, 5);
+    rc |= cmd_time(M, 3072, 768, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(M, 768, 768, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(M, 2304, 768, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(M, 768, 3072, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(32768, 768, 768, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(13824, 3072, 768, SPMM_EPI_GELU, 5);
+    rc |= cmd_time(4096, 4096, 4096, SPMM_EPI_BF16, 5);
+    rc |= cmd_time(8192, 8192, 8192, SPMM_EPI_BF16, 3);
+    return rc;
+  }
+  fprintf(stderr, "usage: gemm_bench check | time M N K [epi] [rounds] | step\n");
+  return 2;
+}

@@ -3,9 +3,7 @@ step, 3 launches each, plus a 16 B/lane streaming copy of known size used to cal
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spmm_amd import ops
-from spmm_amd._lib import lib
-if len(sys.argv) > 1:
-    lib().cdll.spmm_gemm_set_variant(int(sys.argv[1]))
+KERNEL = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # spmm_gemm_nt kernel selector (0 = default choice)
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -17,7 +15,7 @@ for M, N, K, epi in shapes:
     A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16()
     b = torch.zeros(N, device=dev); C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     for _ in range(3):
-        ops.gemm_nt(A, W, C, bias=b, epi=epi)
+        ops.gemm_nt(A, W, C, bias=b, epi=epi, C2=torch.empty_like(C) if epi == ops.EPI_GELU else None, kernel=KERNEL)
     torch.cuda.synchronize()
     del A, W, C
 print("ok")
