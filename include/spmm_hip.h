@@ -41,6 +41,9 @@ const char* spmm_last_error(void);
 #define SPMM_EPI_F32_ATOMIC 3  /* C(f32) += alpha*acc  with atomicAdd (split-K allowed)                  */
 #define SPMM_EPI_GELU_GRAD 4   /* C(bf16) = acc * gelu_erf'(G)                                           */
 #define SPMM_EPI_F32_ACC 5     /* C(f32) += alpha*acc + bias   (plain read-modify-write, single owner)   */
+#define SPMM_EPI_GELU_DERIV 6  /* pre = acc + bias ; C(bf16) = gelu_erf(pre) ; C2(bf16) = gelu_erf'(pre): the FFN forward keeps  */
+                               /* the derivative (one shared exp) so that the backward epilogue is SPMM_EPI_MUL                  */
+#define SPMM_EPI_MUL 7         /* C(bf16) = alpha*acc * G      (G bf16, e.g. the stored gelu'; colsum allowed)                   */
 
 /* C[M,N] = A[M,K] . W[N,K]^T on MFMA (bf16 in, fp32 accumulate).  Replaces every nn.Linear on the path
  * (xbert.py:280-300 query/key/value, :370 attention output.dense, :435 intermediate.dense + erf GELU :436,

@@ -111,6 +111,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// gelu(x) and gelu'(x) together: exp(-x^2/2) serves both the erf (A&S 7.1.26: erf(z) = 1 - poly(t) exp(-z^2), z = x / sqrt 2)
+// and the density term, so the derivative costs two extra FMAs in the forward epilogue and the backward epilogue becomes a
+// plain multiply (SPMM_EPI_GELU_DERIV / SPMM_EPI_MUL).
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
+  const float az = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * az);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-0.5f * x * x);
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+  g = x * cdf;
+  dg = cdf + x * (0.3989422804014327f * e);
+}
+
 __device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) {
   bf16x4 r; r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d; return r;
 }

@@ -23,7 +23,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
 
-enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5 };
+enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5, EPI_GELU_DERIV = 6, EPI_MUL = 7 };
+// bf16-output epilogues (LDS-transposed, row-coalesced stores): BF16, GELU (C2 = pre-activation), GELU_DERIV (C2 = gelu'(pre)),
+// GELU_GRAD (C = acc * gelu'(G), G = pre-activation), MUL (C = acc * G, G = a stored derivative)
+constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU || e == EPI_GELU_GRAD || e == EPI_GELU_DERIV || e == EPI_MUL; }
 
 struct GemmP {
   const bf16* A; long lda;
@@ -34,9 +37,9 @@ struct GemmP {
   const float* div_ptr;      // optional device scalar: acc /= *div_ptr
   float alpha;               // acc *= alpha
   const bf16* R; long ldr;   // optional bf16 addend (residual-gradient accumulate)
-  const bf16* G; long ldg;   // EPI_GELU_GRAD: pre-activation
+  const bf16* G; long ldg;   // EPI_GELU_GRAD: pre-activation; EPI_MUL: the factor
   void* C; long ldc;
-  bf16* C2; long ldc2;       // EPI_GELU: pre-activation output
+  bf16* C2; long ldc2;       // EPI_GELU: pre-activation output; EPI_GELU_DERIV: gelu'(pre-activation)
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range (tile_of): 0 row-major, 3 row-major inside 2 column groups
 };
@@ -91,6 +94,12 @@ __device__ __forceinline__ void epi_convert(const GemmP& p, f32x16 (&acc)[2][2],
         if constexpr (EPI == EPI_GELU) {
           if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
           *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else if constexpr (EPI == EPI_GELU_DERIV) {
+          float gv[4], dv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gelu_erf_both(v[j], gv[j], dv[j]);
+          if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(dv[0], dv[1], dv[2], dv[3]);
+          *(bf16x4*)(t0 + off) = to_bf16x4(gv[0], gv[1], gv[2], gv[3]);
         } else {
           *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
         }
@@ -105,7 +114,7 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
                                           float* cs_carry = nullptr, bool flush = true) {
   // all R / G operand loads first: a load placed behind a store to a possibly aliasing pointer would be serialised behind it
   bf16x8 rr[8], gg[8];
-  if (p.R || EPI == EPI_GELU_GRAD) {
+  if (p.R || EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), c16 = lane & 7;
@@ -118,7 +127,7 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
         if (full) rr[it] = *(const bf16x8*)(p.R + (long)m * p.ldr + n);
         else { const bf16x4 h4 = *(const bf16x4*)(p.R + (long)m * p.ldr + n); rr[it][0] = h4[0]; rr[it][1] = h4[1]; rr[it][2] = h4[2]; rr[it][3] = h4[3]; }
       }
-      if constexpr (EPI == EPI_GELU_GRAD) {
+      if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
         if (full) gg[it] = *(const bf16x8*)(p.G + (long)m * p.ldg + n);
         else { const bf16x4 h4 = *(const bf16x4*)(p.G + (long)m * p.ldg + n); gg[it][0] = h4[0]; gg[it][1] = h4[1]; gg[it][2] = h4[2]; gg[it][3] = h4[3]; }
       }
@@ -145,6 +154,10 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)gg[it][e]));
     }
+    if constexpr (EPI == EPI_MUL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * (float)gg[it][e]);
+    }
     if (p.colsum) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
@@ -152,11 +165,11 @@ __device__ __forceinline__ void epi_store(const GemmP& p, const char* t0, const 
     bf16* dst = (bf16*)p.C + (long)m * p.ldc + n;
     if (full) {
       *(bf16x8*)dst = o;
-      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
+      if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_DERIV) { if (p.C2) *(bf16x8*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x8*)(t1 + off); }
     } else {   // ragged last chunk (N % 8 == 4)
       bf16x4 lo4; lo4[0] = o[0]; lo4[1] = o[1]; lo4[2] = o[2]; lo4[3] = o[3];
       *(bf16x4*)dst = lo4;
-      if constexpr (EPI == EPI_GELU) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
+      if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_DERIV) { if (p.C2) *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = *(const bf16x4*)(t1 + off); }
     }
   }
   if (p.colsum && cs_carry && !flush) {
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     }
   }
 
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELU_GRAD) {
+  if constexpr (epi_is_bf16(EPI)) {
     __syncthreads();                                  // every wave is done reading the staging buffers
     epilogue_bf16<EPI>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
     return;
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
   }
 #undef STAGE2
 
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_GELU_GRAD) {
+  if constexpr (epi_is_bf16(EPI)) {
     __builtin_amdgcn_s_barrier();                     // no DMA pending (vmcnt(0) above); all waves done with the ring
     epilogue_bf16<EPI>(p, acc, smem2 + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
     return;
@@ -586,140 +599,171 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
 // address): every ds_read_b128 lane group of the 16x16x32 operand pattern hits 16 distinct slots.
 constexpr int P8_HT = 128 * BK * 2;        // half-tile: 128 rows x 64 k = 16 KiB
 constexpr int P8_BUF = 4 * P8_HT;          // K-tile: A-h0 | A-h1 | W-h0 | W-h1 = 64 KiB
-constexpr int P8_LDS = 2 * P8_BUF;         // 128 KiB
+constexpr int P8_LDS = 2 * P8_BUF;         // 128 KiB ring
+constexpr int P8_XLDS = 8 * 4096;          // + 4 KiB per wave for the epilogue's transposition (outside the ring)
 
 template <int OFF>
 __device__ __forceinline__ void p8_dsr(bf16x8& d, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// acc[mi][ni] = D[n][m] of a 16x16 block: m = mi*16 + (lane&15), n = ni*16 + 4*(lane>>4) + j -> the same 64x64 bf16 LDS
-// tile image as epi_convert (consumed by epi_store).
-template <int EPI>
-__device__ __forceinline__ void epi_convert16(const GemmP& p, f32x4 (&acc)[4][4], char* t0, char* t1, int n_base, int lane) {
-  float scale = p.alpha;
-  if (p.div_ptr) scale /= *p.div_ptr;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int col = ni * 16 + 4 * (lane >> 4);
-    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n_base + col < p.N) b = *(const f32x4*)(p.bias + n_base + col);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int row = mi * 16 + (lane & 15);
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] * scale + b[j];
-      const int off = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 4) << 1));
-      if constexpr (EPI == EPI_GELU) {
-        if (p.C2) *(bf16x4*)(t1 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
-        *(bf16x4*)(t0 + off) = to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-      } else {
-        *(bf16x4*)(t0 + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+// Epilogue of the 8-phase kernel.  The wave's 128x64 block leaves as FULL 128-B lines, 8 rows per store instruction
+// (tools/store_bench.cpp: a CU sustains ~37-45 B/clk with full-line stores from 8 consecutive lanes, 26 B/clk when a row's 8
+// lanes are scattered over the wave, 12 B/clk with 64-B row segments, 6 B/clk with the raw 32-B accumulator pieces), so each
+// 16-row block is transposed through LDS -- through a 4-KiB per-wave slice of the 32 KiB the operand ring does NOT use, so the
+// ring is free for the next tile's DMA while the epilogue runs.  The LDS accesses are inline asm: C++ accesses would make the
+// compiler wait for every pending LDS-DMA (the next tile's pieces issued by `hook`) before each of them.
+//   accumulator layout (16x16 block mi, ni): lane (m = lane & 15, g = lane >> 4) holds row mi*16 + m, columns ni*16 + 4g .. +3
+//   image of a block: 16 rows x 128 B, 16-B chunk index XOR (row & 7); written 8 B per lane, read 16 B per lane row-major.
+// INTERIOR: the whole 256x256 tile is inside the matrix (no predicates).  `hook(blk)` runs after the stores of block blk.
+struct P8Out { uint32_t d[4]; };
+__device__ __forceinline__ uint32_t p8_pack2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float p8_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float p8_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void p8_dsw64(uint32_t addr, uint32_t a, uint32_t b) {
+  u32x2 v = {a, b};
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void p8_dsr128u(u32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// Epilogue of an INTERIOR tile (no bounds checks): the wave's whole 128x64 block in one go.  The accumulators are scaled /
-// biased / activated, rounded to bf16 and written to a 128-row x 128-B image in the wave's private 16-KiB LDS region (16-B chunk
-// index XOR row&7), read back row-major and stored as FULL 128-B lines: 8 lanes x 16 B per row, 8 rows per wave instruction.
-// (tools/store_bench.cpp: a CU sustains ~45 B/clk with full-line stores, 12 B/clk with 64-B row segments, 6 B/clk with the raw
-// 32-B accumulator layout -- hence the LDS transposition.)  Same arithmetic as epi_convert16 + epi_store.
-template <bool GELU>   // one 64-row half of the wave's block: bf16(v) or bf16(gelu(v)), v = alpha * acc + bias
-__device__ __forceinline__ void p8_write_half(f32x4 (&acc)[4][4], char* img, float scale, const f32x4 (&b)[4], int lane) {
-  const int m = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = mi * 16 + m;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[mi][ni][j] * scale + b[ni][j];
-        if constexpr (GELU) v[j] = gelu_erf(v[j]);
-      }
-      const int off = row * 128 + ((((ni * 2 + (g >> 1)) ^ (row & 7)) << 4) | ((g & 1) << 3));
-      *(bf16x4*)(img + off) = to_bf16x4(v[0], v[1], v[2], v[3]);
-    }
-  }
-}
-
-template <int EPI>
-__device__ __forceinline__ void p8_epilogue_full(const GemmP& p, f32x4 (&acc)[2][4][4], char* wt, int m_base, int n_base, int lane) {
+// HAS_EX: an R (EPI_BF16) / G (EPI_GELU_GRAD) operand is read.  Its loads and their uses are unconditional (edge tiles clamp the
+// address): a load whose use sits behind a different branch would stay "pending" in the compiler's waitcnt model at the top of the
+// K loop and cost a vmcnt(0) -- a drain of the DMA pipeline -- on every iteration.
+template <int EPI, bool INTERIOR, bool HAS_EX, typename Hook>
+__device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[2][4][4], uint32_t xb /* LDS byte address of the wave's 4 KiB */,
+                                                   int m_base, int n_base, int lane, Hook hook) {
   float scale = p.alpha;
   if (p.div_ptr) scale /= *p.div_ptr;
+  const int m = lane & 15, g = lane >> 4, r8 = lane >> 3, c16 = lane & 7;
   f32x4 b[4];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + 4 * (lane >> 4));
+  for (int ni = 0; ni < 4; ++ni) b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      if (INTERIOR || n_base + ni * 16 + 4 * g < p.N) b[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + 4 * g);
   }
-  const int r8 = lane >> 3, c16 = lane & 7;
+  uint32_t wad[4];                                              // write address of the (ni) piece: row m, columns ni*16 + 4g
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) wad[ni] = xb + (uint32_t)(m * 128 + ((((ni * 2 + (g >> 1)) ^ (m & 7)) << 4) | ((g & 1) << 3)));
+  const uint32_t rad = xb + (uint32_t)(r8 * 128 + ((c16 ^ (r8 & 7)) << 4));   // rows r8 and r8 + 8 (+1024 B), chunk c16
   const long n = n_base + c16 * 8;
+  const bool n_ok = INTERIOR || n < p.N;                        // N % 8 == 0: a chunk is all in or all out
+  const long row0 = m_base + r8;
+  bf16* cp = (bf16*)p.C + row0 * p.ldc + n;
+  constexpr bool GELU2 = EPI == EPI_GELU || EPI == EPI_GELU_DERIV;    // two outputs
+  bf16* c2p = GELU2 && p.C2 ? p.C2 + row0 * p.ldc2 + n : nullptr;
+  u32x4 ex[8];                                                  // R / G pieces of one 64-row half in the store layout, all in flight at once
+  const bf16* esrc = (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) ? p.G : p.R;
+  const long eld = (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) ? p.ldg : p.ldr;
+  const long nn = n_ok ? n : 0;
+#define P8_LOAD_EX(H)                                                          \
+  if constexpr (HAS_EX) {                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                         \
+      long r_ = row0 + (H) * 64 + i_ * 8;                                      \
+      if (!INTERIOR) r_ = r_ < p.M ? r_ : p.M - 1;                             \
+      ex[i_] = *(const u32x4*)(esrc + r_ * eld + nn);                          \
+    }                                                                          \
+  }
+  P8_LOAD_EX(0);
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    char* img = wt + h * 8192;                         // 64 rows x 128 B
-    const long mrow = m_base + h * 64 + r8;
-    // operands of the store pass first: their latency hides behind the conversion
-    bf16x8 ex[8];
-    if (EPI == EPI_GELU_GRAD || (EPI == EPI_BF16 && p.R)) {
-      const bf16* src = EPI == EPI_GELU_GRAD ? p.G : p.R;
-      const long ld = EPI == EPI_GELU_GRAD ? p.ldg : p.ldr;
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int it = 0; it < 8; ++it) ex[it] = *(const bf16x8*)(src + (mrow + it * 8) * ld + n);
-    }
-    if constexpr (EPI == EPI_GELU) {
-      if (p.C2) {
-        p8_write_half<false>(acc[h], img, scale, b, lane);
+    for (int mi = 0; mi < 4; ++mi) {
+      const int blk = h * 4 + mi;
+      const uint32_t bo = (blk & 1) * 2048;                     // two images per wave: block b+1 is written while b's reads return
+      const bool ok1 = INTERIOR || (n_ok && row0 + blk * 16 < p.M), ok2 = INTERIOR || (n_ok && row0 + blk * 16 + 8 < p.M);
+      float v[4][4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int row = it * 8 + r8;
-          *(bf16x8*)(p.C2 + (mrow + it * 8) * p.ldc2 + n) = *(const bf16x8*)(img + row * 128 + ((c16 ^ (row & 7)) << 4));
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[ni][j] = acc[h][mi][ni][j] * scale + b[ni][j];
+      u32x4 o1, o2;
+      if constexpr (GELU2) {
+        float w[4][4];                                          // second output: pre-activation (GELU) or gelu'(pre) (GELU_DERIV)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (EPI == EPI_GELU) { w[ni][j] = v[ni][j]; v[ni][j] = gelu_erf(v[ni][j]); }
+            else { const float x = v[ni][j]; gelu_erf_both(x, v[ni][j], w[ni][j]); }
+          }
+        if (c2p) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(w[ni][0], w[ni][1]), p8_pack2(w[ni][2], w[ni][3]));
+          p8_dsr128u<0>(o1, rad + bo);
+          p8_dsr128u<1024>(o2, rad + bo);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (ok1) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2) = o1;
+          if (ok2) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2 + 8 * p.ldc2) = o2;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      p8_write_half<true>(acc[h], img, scale, b, lane);
-    } else {
-      p8_write_half<false>(acc[h], img, scale, b, lane);
-    }
+      // (the same wave's LDS operations execute in order: the image writes below cannot pass the reads above)
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + r8;
-      bf16x8 o = *(const bf16x8*)(img + row * 128 + ((c16 ^ (row & 7)) << 4));
-      if constexpr (EPI == EPI_BF16) {
-        if (p.R) {
+      for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
+      p8_dsr128u<0>(o1, rad + bo);
+      p8_dsr128u<1024>(o2, rad + bo);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EPI == EPI_BF16 && HAS_EX) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)ex[it][e]);
+        for (int d = 0; d < 4; ++d) {
+          o1[d] = p8_pack2(p8_lo(o1[d]) + p8_lo(ex[2 * mi][d]), p8_hi(o1[d]) + p8_hi(ex[2 * mi][d]));
+          o2[d] = p8_pack2(p8_lo(o2[d]) + p8_lo(ex[2 * mi + 1][d]), p8_hi(o2[d]) + p8_hi(ex[2 * mi + 1][d]));
         }
       }
       if constexpr (EPI == EPI_GELU_GRAD) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * gelu_erf_grad((float)ex[it][e]));
-      }
-      if constexpr (EPI != EPI_GELU) {
-        if (p.colsum) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
+        for (int d = 0; d < 4; ++d) {
+          o1[d] = p8_pack2(p8_lo(o1[d]) * gelu_erf_grad(p8_lo(ex[2 * mi][d])), p8_hi(o1[d]) * gelu_erf_grad(p8_hi(ex[2 * mi][d])));
+          o2[d] = p8_pack2(p8_lo(o2[d]) * gelu_erf_grad(p8_lo(ex[2 * mi + 1][d])), p8_hi(o2[d]) * gelu_erf_grad(p8_hi(ex[2 * mi + 1][d])));
         }
       }
-      *(bf16x8*)((bf16*)p.C + (mrow + it * 8) * p.ldc + n) = o;
+      if constexpr (EPI == EPI_MUL) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          o1[d] = p8_pack2(p8_lo(o1[d]) * p8_lo(ex[2 * mi][d]), p8_hi(o1[d]) * p8_hi(ex[2 * mi][d]));
+          o2[d] = p8_pack2(p8_lo(o2[d]) * p8_lo(ex[2 * mi + 1][d]), p8_hi(o2[d]) * p8_hi(ex[2 * mi + 1][d]));
+        }
+      }
+      if constexpr (!GELU2) {
+        if (p.colsum) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (ok1) { cs[2 * d] += p8_lo(o1[d]); cs[2 * d + 1] += p8_hi(o1[d]); }
+            if (ok2) { cs[2 * d] += p8_lo(o2[d]); cs[2 * d + 1] += p8_hi(o2[d]); }
+          }
+        }
+      }
+      if (ok1) *(u32x4*)(cp + (long)blk * 16 * p.ldc) = o1;
+      if (ok2) *(u32x4*)(cp + (long)blk * 16 * p.ldc + 8 * p.ldc) = o2;
+      hook(blk);
+      if (blk == 3) { P8_LOAD_EX(1); }
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if constexpr (EPI != EPI_GELU) {
+#undef P8_LOAD_EX
+  if constexpr (!GELU2) {
     if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = cs[e];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        cs[e] = v;
+        float t = cs[e];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        cs[e] = t;
       }
-      if (lane < 8) {
+      if (lane < 8 && n_ok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(p.colsum + n + e, cs[e]);
       }
@@ -727,6 +771,10 @@ __device__ __forceinline__ void p8_epilogue_full(const GemmP& p, f32x4 (&acc)[2]
   }
 }
 
+// Persistent: gridDim.x workgroups (<= one per CU) walk the tile list with stride gridDim.x, so a CU pays the workgroup
+// launch, the kernel-argument fetch and the address set-up once, and the tile boundary is {epilogue from registers -> DMA
+// prologue of the next tile} instead of {drain, exit, dispatch, prologue}.  (PMC at 84000x3072x768, one workgroup per tile:
+// the MFMA pipe was busy 49 % of the CU-busy cycles against 82 % at 4096^3 -- ~10 us of boundary per 13.6-us main loop.)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem8[];
@@ -734,42 +782,38 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves, wave tile 128 (m) x 64 (n)
   const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
-  int t;
-  {
-    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
-  int tile_m, tile_n;
-  tile_of(t, ntm, ntn, p.order, tile_m, tile_n);
-  const int m0 = tile_m * BM3, n0 = tile_n * BN3;
   const int nk = p.K / BK;                           // even, >= 2 (launcher)
 
   f32x4 acc[2][4][4];                                // [m half][mi][ni], 128 accumulators
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define P8_ZERO()                                                              \
+  _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                             \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) acc[h_][i_][j_] = f32x4{0.f, 0.f, 0.f, 0.f}
+  P8_ZERO();
 
   // ---- LDS-DMA sources.  DMA instruction i (0/1) of a half-tile: chunk id = i*512 + tid -> half-tile row lr = id >> 3,
   // physical slot id & 7 (LDS destination is lane-linear), logical k-slot = slot ^ ((lr >> 1) & 7).
   // A-h: lr -> tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W-h: lr -> tile column (lr >> 5) * 64 + h * 32 + (lr & 31).
   uint32_t offA[2][2], offW[2][2];                   // byte offsets from p.A / p.W (+ k), [half][instruction]
-  {
-    const uint32_t ls16 = (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int row = m0 + i * 128 + h * 64 + (tid >> 3);
-        row = row < p.M ? row : p.M - 1;               // clamped rows are computed and never stored
-        offA[h][i] = (uint32_t)row * (uint32_t)(p.lda * 2) + ls16;
-        int col = n0 + (i * 2 + (tid >> 8)) * 64 + h * 32 + ((tid >> 3) & 31);
-        col = col < p.N ? col : p.N - 1;
-        offW[h][i] = (uint32_t)col * (uint32_t)(p.ldw * 2) + ls16;
-      }
-  }
+  const uint32_t ls16 = (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+  int m0, n0;
+#define P8_TILE(VB)                                                                                           \
+  do {                                                                                                        \
+    const int b_ = (VB), q_ = nt >> 3, r_ = nt & 7, xcd_ = b_ & 7, i_ = b_ >> 3;                              \
+    const int t_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + i_;                     \
+    int tm_, tn_;                                                                                             \
+    tile_of(t_, ntm, ntn, p.order, tm_, tn_);                                                                 \
+    m0 = tm_ * BM3; n0 = tn_ * BN3;                                                                           \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                        \
+      int row_ = m0 + j_ * 128 + h_ * 64 + (tid >> 3);                                                        \
+      row_ = row_ < p.M ? row_ : p.M - 1;              /* clamped rows are computed and never stored */       \
+      offA[h_][j_] = (uint32_t)row_ * (uint32_t)(p.lda * 2) + ls16;                                           \
+      int col_ = n0 + (j_ * 2 + (tid >> 8)) * 64 + h_ * 32 + ((tid >> 3) & 31);                               \
+      col_ = col_ < p.N ? col_ : p.N - 1;                                                                     \
+      offW[h_][j_] = (uint32_t)col_ * (uint32_t)(p.ldw * 2) + ls16;                                           \
+    }                                                                                                         \
+  } while (0)
   const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W;
 #define P8_STG(GB, O, SLOT)                                                                                               \
@@ -780,6 +824,12 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   } while (0)
 #define P8_STG_A(H, BUF, KT) P8_STG(gA + (size_t)(KT) * (BK * 2), offA[H], (BUF) * P8_BUF + (H) * P8_HT)
 #define P8_STG_W(H, BUF, KT) P8_STG(gW + (size_t)(KT) * (BK * 2), offW[H], (BUF) * P8_BUF + (2 + (H)) * P8_HT)
+  // K-tile 0 complete + the first three half-tiles of K-tile 1: what the main loop expects to find in flight
+#define P8_PROLOGUE()                                                                        \
+  do {                                                                                       \
+    P8_STG_A(0, 0, 0); P8_STG_W(0, 0, 0); P8_STG_W(1, 0, 0); P8_STG_A(1, 0, 0);              \
+    P8_STG_W(0, 1, 1); P8_STG_A(0, 1, 1); P8_STG_W(1, 1, 1);                                 \
+  } while (0)
 
   // ---- fragment read addresses (16x16x32 operand: lane -> row lane & 15, k-slot kk*4 + (lane >> 4))
   const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem8;
@@ -840,52 +890,113 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
     P8_SB();                                     \
   } while (0)
 
-  // ---- prologue: K-tile 0 complete, the first three half-tiles of K-tile 1 in flight
-  P8_STG_A(0, 0, 0); P8_STG_W(0, 0, 0); P8_STG_W(1, 0, 0); P8_STG_A(1, 0, 0);
-  P8_STG_W(0, 1, 1); P8_STG_A(0, 1, 1); P8_STG_W(1, 1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#ifdef P8_PROFILE
+  unsigned long long* prof = (unsigned long long*)p.colsum + (size_t)blockIdx.x * 16 * 8;
+  p.colsum = nullptr;
+  int prof_i = 0;
+#define P8_STAMP(K) do { if (prof && tid == 0 && prof_i < 16) prof[prof_i * 8 + (K)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define P8_STAMP(K) do { } while (0)
+#endif
+  int vb = blockIdx.x;
+  P8_TILE(vb);
+  P8_PROLOGUE();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile 0 landed, three half-tiles of K-tile 1 in flight
   P8_BAR();
   P8_SB();
-  if (wr == 1) P8_BAR();                             // the second wave row runs one barrier behind the first
+  if (wr == 1) P8_BAR();                             // the second wave row runs one barrier behind the first, for the whole launch
+  for (;;) {
+    P8_STAMP(0);
+    // The K-tile stream does not stop at a tile boundary: the LAST K-tile pair of a tile stages the first two K-tiles of the
+    // workgroup's next tile (same slots, same phases, same counted waits), so the next main loop finds exactly what the
+    // prologue would have left -- K-tile 0 landed, three half-tiles of K-tile 1 in flight -- and the boundary is the epilogue alone.
+    const int cm0 = m0, cn0 = n0;
+    const int vbn = vb + (int)gridDim.x;
+    const bool has_next = vbn < nt;                  // wave-uniform
+    for (int kt = 0; kt < nk; kt += 2) {
+      const bool last = kt + 2 >= nk;
+      const bool more = !last || has_next;
+      int kn = kt + 2;                               // K-tile (of the tile whose offsets are loaded) staged from phase 2 on
+      // ---------------- K-tile kt (buffer 0)
+      P8_RD_W(0, 0, fw0); P8_SB(); P8_RD_A(0, 0);                                 // phase 1
+      P8_STG_A(1, 1, kt + 1);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                          // the four W-h0 reads: slot free for phase 2
+      P8_COMPUTE(0, 0, fw0);
+      if (last && has_next) { P8_TILE(vbn); kn = 0; }                             // from here on the DMA sources are the next tile's
+      P8_RD_W(0, 1, fw1);                                                         // phase 2
+      if (more) P8_STG_W(0, 0, kn);
+      P8_COMPUTE(0, 1, fw1);
+      P8_RD_A(0, 1);                                                              // phase 3
+      if (more) P8_STG_A(0, 0, kn);
+      P8_COMPUTE(1, 1, fw1);
+      if (more) {                                                                 // phase 4
+        P8_STG_W(1, 0, kn);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          // K-tile kt+1 complete (this wave's pieces)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      P8_COMPUTE(1, 0, fw0);
+      // ---------------- K-tile kt+1 (buffer 1)
+      P8_RD_W(1, 0, fw0); P8_SB(); P8_RD_A(1, 0);                                 // phase 5
+      if (more) P8_STG_A(1, 0, kn);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      P8_COMPUTE(0, 0, fw0);
+      P8_RD_W(1, 1, fw1);                                                         // phase 6
+      if (more) P8_STG_W(0, 1, kn + 1);
+      P8_COMPUTE(0, 1, fw1);
+      P8_RD_A(1, 1);                                                              // phase 7
+      if (more) P8_STG_A(0, 1, kn + 1);
+      P8_COMPUTE(1, 1, fw1);
+      if (more) {                                                                 // phase 8
+        P8_STG_W(1, 1, kn + 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          // the next K-tile for buffer 0 complete
+      }
+      P8_COMPUTE(1, 0, fw0);
+    }
+    P8_STAMP(2);
 
-  for (int kt = 0; kt < nk; kt += 2) {
-    const bool more = kt + 2 < nk;                   // wave-uniform
-    // ---------------- K-tile kt (buffer 0)
-    P8_RD_W(0, 0, fw0); P8_SB(); P8_RD_A(0, 0);                                   // phase 1
-    P8_STG_A(1, 1, kt + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                            // the four W-h0 reads: slot free for phase 2
-    P8_COMPUTE(0, 0, fw0);
-    P8_RD_W(0, 1, fw1);                                                           // phase 2
-    if (more) P8_STG_W(0, 0, kt + 2);
-    P8_COMPUTE(0, 1, fw1);
-    P8_RD_A(0, 1);                                                                // phase 3
-    if (more) P8_STG_A(0, 0, kt + 2);
-    P8_COMPUTE(1, 1, fw1);
-    if (more) {                                                                   // phase 4
-      P8_STG_W(1, 0, kt + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            // K-tile kt+1 complete (this wave's pieces)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- tile boundary: every wave writes its own 128x64 block (no barrier; the wave rows stay one barrier apart)
+    {
+      // everything the epilogue derives from the lane id is computed HERE, per tile: hoisted out of the tile loop it would live
+      // across the main loop and spill
+      // ... and so is everything it derives from the kernel arguments (row strides x block offsets, pointers): the copies below
+      // are opaque to loop-invariant code motion.  (Hoisted, they cost 50 spilled VGPRs and the compiler's vmcnt(0) on the
+      // first use of a reloaded value INSIDE the K loop -- which drains the DMA pipeline on every iteration.)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      GemmP q = p;
+      asm volatile("" : "+s"(q.C), "+s"(q.ldc), "+s"(q.C2), "+s"(q.ldc2));
+      asm volatile("" : "+s"(q.R), "+s"(q.ldr), "+s"(q.G), "+s"(q.ldg));
+      asm volatile("" : "+s"(q.bias), "+s"(q.colsum), "+s"(q.div_ptr), "+s"(q.alpha), "+s"(q.M), "+s"(q.N));
+      auto hook = [](int) {};
+      const uint32_t xb = lds0 + P8_LDS + wave * 4096;
+      const int mb = cm0 + wr * 128, nb = cn0 + wc * 64;
+      const bool interior = cm0 + BM3 <= q.M && cn0 + BN3 <= q.N;
+      if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
+        if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
+      } else if (EPI == EPI_BF16 && q.R != nullptr) {
+        if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
+      } else {
+        if (interior) p8_epilogue_blocks<EPI, true, false>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, false>(q, acc, xb, mb, nb, lane_e, hook);
+      }
     }
-    P8_COMPUTE(1, 0, fw0);
-    // ---------------- K-tile kt+1 (buffer 1)
-    P8_RD_W(1, 0, fw0); P8_SB(); P8_RD_A(1, 0);                                   // phase 5
-    if (more) P8_STG_A(1, 0, kt + 2);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    P8_COMPUTE(0, 0, fw0);
-    P8_RD_W(1, 1, fw1);                                                           // phase 6
-    if (more) P8_STG_W(0, 1, kt + 3);
-    P8_COMPUTE(0, 1, fw1);
-    P8_RD_A(1, 1);                                                                // phase 7
-    if (more) P8_STG_A(0, 1, kt + 3);
-    P8_COMPUTE(1, 1, fw1);
-    if (more) {                                                                   // phase 8
-      P8_STG_W(1, 1, kt + 3);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                            // K-tile kt+2 complete
-    }
-    P8_COMPUTE(1, 0, fw0);
+    P8_STAMP(4);
+#ifdef P8_PROFILE
+    ++prof_i;
+#endif
+    if (!has_next) break;
+    vb = vbn;
+    P8_SB();
+    P8_ZERO();
   }
-  if (wr == 0) P8_BAR();                             // re-join the two wave rows: every wave is past its last LDS read
+  if (wr == 0) P8_BAR();                             // balance the barrier count of the two wave rows
+#undef P8_ZERO
+#undef P8_STAMP
+#undef P8_TILE
+#undef P8_PROLOGUE
 #undef P8_STG
 #undef P8_STG_A
 #undef P8_STG_W
@@ -893,22 +1004,10 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
 #undef P8_RD_W
 #undef P8_MM
 #undef P8_COMPUTE
-
-  char* wt = smem8 + wave * 16384;                   // 16 KiB private epilogue region per wave
-  if (m0 + BM3 <= p.M && n0 + BN3 <= p.N) {          // interior tile: no bounds checks
-    p8_epilogue_full<EPI>(p, acc, wt, m0 + wr * 128, n0 + wc * 64, lane);
-    return;
-  }
-  float cs_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    epi_convert16<EPI>(p, acc[h], wt, wt + 8192, n0 + wc * 64, lane);
-    epi_store<EPI>(p, wt, wt + 8192, m0 + wr * 128 + h * 64, n0 + wc * 64, lane, cs_carry, h == 1);
-  }
-}
 #undef P8_BAR
 #undef P8_SB
 #undef P8_LGKM0
+}
 
 // ---- launchers.  The dynamic-LDS attribute of a kernel is raised exactly once (function-local static: thread-safe).
 template <typename K>
@@ -922,18 +1021,23 @@ int raise_lds(K kernel, int bytes, const char* what) {
 }
 
 template <int EPI>
-int launch_p8_one(const GemmP& p, hipStream_t st) {
-  static const int rc = raise_lds(gemm_nt_p8_kernel<EPI>, P8_LDS, "the 8-phase kernel");
+int launch_p8_one(const GemmP& p, hipStream_t st, bool persist) {
+  static const int rc = raise_lds(gemm_nt_p8_kernel<EPI>, P8_LDS + P8_XLDS, "the 8-phase kernel");
   if (rc != SPMM_OK) return rc;
-  dim3 grid(((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3));
-  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI>), grid, dim3(512), P8_LDS, st, p);
+  const int nt = ((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
+  static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n & ~7 : 256; }();
+  // persistent: one workgroup per CU (a multiple of 8 so that a workgroup's tiles stay on its XCD's contiguous range)
+  dim3 grid(persist && nt > ncu ? ncu : nt);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI>), grid, dim3(512), P8_LDS + P8_XLDS, st, p);
   return SPMM_OK;
 }
-int launch_p8(int epi, const GemmP& p, hipStream_t st) {
+int launch_p8(int epi, const GemmP& p, hipStream_t st, bool persist) {
   switch (epi) {
-    case EPI_BF16: return launch_p8_one<EPI_BF16>(p, st);
-    case EPI_GELU: return launch_p8_one<EPI_GELU>(p, st);
-    case EPI_GELU_GRAD: return launch_p8_one<EPI_GELU_GRAD>(p, st);
+    case EPI_BF16: return launch_p8_one<EPI_BF16>(p, st, persist);
+    case EPI_GELU: return launch_p8_one<EPI_GELU>(p, st, persist);
+    case EPI_GELU_GRAD: return launch_p8_one<EPI_GELU_GRAD>(p, st, persist);
+    case EPI_GELU_DERIV: return launch_p8_one<EPI_GELU_DERIV>(p, st, persist);
+    case EPI_MUL: return launch_p8_one<EPI_MUL>(p, st, persist);
     default: return -1;
   }
 }
@@ -951,6 +1055,8 @@ int launch_v3(int epi, const GemmP& p, hipStream_t st) {
     case EPI_BF16: return launch_v3_one<EPI_BF16>(p, st);
     case EPI_GELU: return launch_v3_one<EPI_GELU>(p, st);
     case EPI_GELU_GRAD: return launch_v3_one<EPI_GELU_GRAD>(p, st);
+    case EPI_GELU_DERIV: return launch_v3_one<EPI_GELU_DERIV>(p, st);
+    case EPI_MUL: return launch_v3_one<EPI_MUL>(p, st);
     default: return -1;
   }
 }
@@ -969,6 +1075,8 @@ int launch_v2(int epi, const GemmP& p, hipStream_t st) {
     case EPI_GELU: return launch_v2_one<EPI_GELU>(p, st);
     case EPI_F32: return launch_v2_one<EPI_F32>(p, st);
     case EPI_GELU_GRAD: return launch_v2_one<EPI_GELU_GRAD>(p, st);
+    case EPI_GELU_DERIV: return launch_v2_one<EPI_GELU_DERIV>(p, st);
+    case EPI_MUL: return launch_v2_one<EPI_MUL>(p, st);
     case EPI_F32_ACC: return launch_v2_one<EPI_F32_ACC>(p, st);
     default: return -1;
   }
@@ -982,15 +1090,18 @@ int launch_v1(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
     case EPI_F32_ATOMIC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ATOMIC>), grid, dim3(256), 0, st, p); break;
     case EPI_GELU_GRAD: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU_GRAD>), grid, dim3(256), 0, st, p); break;
     case EPI_F32_ACC: hipLaunchKernelGGL((gemm_nt_kernel<EPI_F32_ACC>), grid, dim3(256), 0, st, p); break;
+    case EPI_GELU_DERIV: hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU_DERIV>), grid, dim3(256), 0, st, p); break;
+    case EPI_MUL: hipLaunchKernelGGL((gemm_nt_kernel<EPI_MUL>), grid, dim3(256), 0, st, p); break;
     default: return -1;
   }
   return SPMM_OK;
 }
 
-inline bool is_bf16_epi(int epi) { return epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_GRAD; }
-// the 8-phase kernel walks K two tiles at a time and addresses its DMA sources with 32-bit byte offsets
+inline bool is_bf16_epi(int epi) { return epi_is_bf16(epi); }
+// the 8-phase kernel walks K two tiles at a time, addresses its DMA sources with 32-bit byte offsets and stores whole 16-B
+// chunks of a row (N % 8 == 0)
 inline bool p8_ok(const GemmP& p, int epi) {
-  return is_bf16_epi(epi) && p.K % 128 == 0 && (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 32) &&
+  return is_bf16_epi(epi) && p.K % 128 == 0 && p.N % 8 == 0 && (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 32) &&
          (unsigned long)p.N * (unsigned long)p.ldw * 2ul < (1ul << 32);
 }
 
@@ -1033,11 +1144,11 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   SPMM_CHECK_SHAPE(!is_bf16_epi(epi) || (ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!G || ldg % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0),
                    "spmm_gemm_nt: bf16 outputs need 16-B aligned rows (ldc/ldr/ldg/ldc2 multiples of 8)");
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
-  SPMM_CHECK_SHAPE(epi >= EPI_BF16 && epi <= EPI_F32_ACC, "spmm_gemm_nt: unknown epilogue %d", epi);
+  SPMM_CHECK_SHAPE(epi >= EPI_BF16 && epi <= EPI_MUL, "spmm_gemm_nt: unknown epilogue %d", epi);
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
-  SPMM_CHECK_SHAPE(epi != EPI_GELU_GRAD || G != nullptr, "spmm_gemm_nt: GELU-grad epilogue needs G");
-  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad epilogues");
+  SPMM_CHECK_SHAPE((epi != EPI_GELU_GRAD && epi != EPI_MUL) || G != nullptr, "spmm_gemm_nt: the GELU-grad / multiply epilogues need G");
+  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD || epi == EPI_MUL, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad / multiply epilogues");
   int ksplit = ((K / 64 + splits - 1) / splits) * 64;
   splits = (K + ksplit - 1) / ksplit;
   GemmP p;
@@ -1057,13 +1168,13 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
     k = tile == 3 ? (p8_ok(p, epi) ? 8 : 3) : tile;
     if (k == 2 && (epi == EPI_F32_ATOMIC || M < 512)) k = 1;
   }
-  SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 8, "spmm_gemm_nt: unknown kernel selector %d", kernel);
-  SPMM_CHECK_SHAPE(k != 8 || p8_ok(p, epi), "spmm_gemm_nt: the 8-phase kernel needs a bf16-output epilogue, K %% 128 == 0 and operands < 4 GiB");
+  SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 8 || k == 9, "spmm_gemm_nt: unknown kernel selector %d", kernel);
+  SPMM_CHECK_SHAPE((k != 8 && k != 9) || p8_ok(p, epi), "spmm_gemm_nt: the 8-phase kernel needs a bf16-output epilogue, K %% 128 == 0, N %% 8 == 0 and operands < 4 GiB");
   SPMM_CHECK_SHAPE(k != 3 || is_bf16_epi(epi), "spmm_gemm_nt: the 256x256 kernel has bf16-output epilogues only");
   SPMM_CHECK_SHAPE(k != 2 || epi != EPI_F32_ATOMIC, "spmm_gemm_nt: the 256x128 kernel has no atomic epilogue");
   SPMM_CHECK_SHAPE(k == 1 || splits == 1, "spmm_gemm_nt: split-K runs on the 128x128 kernel only");
   int rc;
-  if (k == 8) rc = launch_p8(epi, p, stream);
+  if (k == 8 || k == 9) rc = launch_p8(epi, p, stream, k == 8);     // 9: one workgroup per tile (A/B of the persistent walk)
   else if (k == 3) rc = launch_v3(epi, p, stream);
   else if (k == 2) rc = launch_v2(epi, p, stream);
   else rc = launch_v1(epi, p, dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splits), stream);

@@ -321,8 +321,11 @@ class Engine:
         if has_cross:
             a, sv2 = self._attn_block_fwd(lp + "crossattention", c, a, groups, save, cross=True)
         h = self._new(M, I)
-        pre = self._new(M, I) if save else None          # the pre-activation is only needed by backward
-        ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"), epi=ops.EPI_GELU, C2=pre)
+        # backward needs only gelu'(pre-activation): the forward epilogue stores it (it shares the exponential with the erf) and the
+        # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
+        dact = self._new(M, I) if save else None
+        ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"),
+                    epi=ops.EPI_GELU_DERIV if save else ops.EPI_GELU, C2=dact)
         x = self._new(M, H)
         ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x, bias=P.w(lp + "output.dense.bias"))
         y = self._new(M, H)
@@ -331,7 +334,7 @@ class Engine:
         salt = self._next_salt()
         ops.ln_fwd(x, a, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
                    mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
-        sv = dict(att=sv1, cross=sv2, a=a, h=h, pre=pre, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
+        sv = dict(att=sv1, cross=sv2, a=a, h=h, dact=dact, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
         return y, sv
 
     def _layer_bwd(self, lp, c, sv, dY, groups, dkv_acc):
@@ -344,7 +347,7 @@ class Engine:
                    seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"))
         self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
-        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_GELU_GRAD, G=sv["pre"],
+        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_MUL, G=sv["dact"],
                     colsum=P.g(lp + "intermediate.dense.bias"))
         self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"))
         da = self._new(M, H)

@@ -6,7 +6,7 @@ import torch
 
 from ._lib import lib
 
-EPI_BF16, EPI_GELU, EPI_F32, EPI_F32_ATOMIC, EPI_GELU_GRAD, EPI_F32_ACC = range(6)
+EPI_BF16, EPI_GELU, EPI_F32, EPI_F32_ATOMIC, EPI_GELU_GRAD, EPI_F32_ACC, EPI_GELU_DERIV, EPI_MUL = range(8)
 BF16 = torch.bfloat16
 
 
@@ -52,7 +52,7 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
     N = W.shape[0]
     K = Ka if K is None else K
     assert A.dtype == BF16 and W.dtype == BF16 and W.shape[1] >= K and C.shape[0] >= M and C.shape[1] >= N
-    if epi in (EPI_BF16, EPI_GELU, EPI_GELU_GRAD):
+    if epi in (EPI_BF16, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_DERIV, EPI_MUL):
         assert C.dtype == BF16
     else:
         assert C.dtype == torch.float32

@@ -47,9 +47,10 @@ static int check_one(int kernel, int epi, int M, int N, int K) {
   CK(hipMemcpy(R.d, hR.data(), R.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(G.d, hG.data(), G.bytes, hipMemcpyHostToDevice));
   CK(hipMemcpy(bias.d, hb.data(), bias.bytes, hipMemcpyHostToDevice));
   CK(hipMemset(C.d, 0x7f, C.bytes)); CK(hipMemset(C2.d, 0x7f, C2.bytes)); CK(hipMemset(cs.d, 0, cs.bytes));
-  const bool use_r = epi == SPMM_EPI_BF16, use_cs = epi != SPMM_EPI_GELU;
-  int rc = run(kernel, epi, A, W, M, N, K, (const float*)bias.d, use_r ? &R : nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C,
-               epi == SPMM_EPI_GELU ? &C2 : nullptr, use_cs ? (float*)cs.d : nullptr, 0);
+  const bool two = epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV, needs_g = epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL;
+  const bool use_r = epi == SPMM_EPI_BF16, use_cs = !two;
+  int rc = run(kernel, epi, A, W, M, N, K, (const float*)bias.d, use_r ? &R : nullptr, needs_g ? &G : nullptr, C,
+               two ? &C2 : nullptr, use_cs ? (float*)cs.d : nullptr, 0);
   if (rc) { printf("  kernel %d epi %d %dx%dx%d: rc=%d %s\n", kernel, epi, M, N, K, rc, spmm_last_error()); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> hC((size_t)M * N), hC2((size_t)M * N);
@@ -72,6 +73,8 @@ static int check_one(int kernel, int epi, int M, int N, int K) {
       if (epi == SPMM_EPI_BF16) ref = (double)bf2f(f2bf((float)acc)) + bf2f(hR[(size_t)m * N + n]);   // the kernel rounds to bf16 before adding R
       else if (epi == SPMM_EPI_GELU) { ref = gelu(acc); ref2 = acc; has2 = true; }
       else if (epi == SPMM_EPI_GELU_GRAD) ref = acc * gelu_grad((double)bf2f(hG[(size_t)m * N + n]));
+      else if (epi == SPMM_EPI_GELU_DERIV) { ref = gelu(acc); ref2 = gelu_grad(acc); has2 = true; }
+      else if (epi == SPMM_EPI_MUL) ref = (double)bf2f(f2bf((float)acc)) * bf2f(hG[(size_t)m * N + n]);
       const double got = bf2f(hC[(size_t)m * N + n]);
       double err = fabs(got - ref), tol = 2e-2 + 1e-2 * fabs(ref);
       if (has2) { const double e2 = fabs(bf2f(hC2[(size_t)m * N + n]) - ref2); if (e2 > 2e-2 + 1e-2 * fabs(ref2)) { ++bad; } if (e2 > maxerr) maxerr = e2; }
@@ -97,9 +100,9 @@ static int check_one(int kernel, int epi, int M, int N, int K) {
 static int cmd_check() {
   int fails = 0;
   const int shapes[][3] = {{256, 256, 128}, {512, 768, 768}, {1000, 2304, 128}, {216, 304, 256}, {513, 520, 3072}, {6912, 768, 768}, {3000, 3072, 768}};
-  for (int kernel : {8, 3, 2, 1})
+  for (int kernel : {8, 9, 3, 2, 1})
     for (auto& s : shapes)
-      for (int epi : {SPMM_EPI_BF16, SPMM_EPI_GELU, SPMM_EPI_GELU_GRAD}) fails += check_one(kernel, epi, s[0], s[1], s[2]);
+      for (int epi : {SPMM_EPI_BF16, SPMM_EPI_GELU, SPMM_EPI_GELU_GRAD, SPMM_EPI_GELU_DERIV, SPMM_EPI_MUL}) fails += check_one(kernel, epi, s[0], s[1], s[2]);
   // repeated launches of one shape must agree bit for bit (a racy schedule shows up as run-to-run differences)
   {
     const int M = 8192, N = 3072, K = 768;
@@ -133,15 +136,16 @@ static int cmd_time(int M, int N, int K, int epi, int rounds) {
   { auto hG = rand_bf16((size_t)M * N, 1.0f); CK(hipMemcpy(G.d, hG.data(), G.bytes, hipMemcpyHostToDevice)); }
   CK(hipMemset(bias.d, 0, bias.bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int kernels[] = {3, 8};
-  std::vector<float> best(2, 1e30f), med[2];
+  const int kernels[] = {3, 9, 8};     // 256x256 one barrier per k-step | 8-phase, one workgroup per tile | 8-phase persistent
+  const int NKER = 3;
+  std::vector<float> best(NKER, 1e30f), med[NKER];
   const int iters = 10;
   for (int r = 0; r < rounds; ++r)
-    for (int ki = 0; ki < 2; ++ki) {
-      for (int w = 0; w < 2; ++w) run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C, epi == SPMM_EPI_GELU ? &C2 : nullptr, nullptr, 0);
+    for (int ki = 0; ki < NKER; ++ki) {
+      for (int w = 0; w < 2; ++w) run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C, (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0);
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < iters; ++i) {
-        int rc = run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, epi == SPMM_EPI_GELU_GRAD ? &G : nullptr, C, epi == SPMM_EPI_GELU ? &C2 : nullptr, nullptr, 0);
+        int rc = run(kernels[ki], epi, A, W, M, N, K, (const float*)bias.d, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C, (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0);
         if (rc) { printf("rc=%d %s\n", rc, spmm_last_error()); return 1; }
       }
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -150,7 +154,7 @@ static int cmd_time(int M, int N, int K, int epi, int rounds) {
     }
   const double fl = 2.0 * M * N * K;
   printf("%6d x %5d x %5d epi %d :", M, N, K, epi);
-  for (int ki = 0; ki < 2; ++ki) {
+  for (int ki = 0; ki < NKER; ++ki) {
     std::sort(med[ki].begin(), med[ki].end());
     const float m = med[ki][med[ki].size() / 2];
     printf("  k%d %8.1f us %7.1f TF (best %7.1f)", kernels[ki], m * 1e3, fl / (m * 1e-3) / 1e12, fl / (best[ki] * 1e-3) / 1e12);
@@ -166,6 +170,8 @@ int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "step")) {   // the training step's dominant shapes (B=128, Lt=128: ~84k fusion tokens)
     int rc = 0;
     const int M = 84000;
+    rc |= cmd_time(M, 3072, 768, SPMM_EPI_GELU_DERIV, 5);
+    rc |= cmd_time(M, 3072, 768, SPMM_EPI_MUL, 5);
     rc |= cmd_time(M, 3072, 768, SPMM_EPI_GELU, 5);
     rc |= cmd_time(M, 3072, 768, SPMM_EPI_GELU_GRAD, 5);
     rc |= cmd_time(M, 3072, 768, SPMM_EPI_BF16, 5);
@@ -178,6 +184,36 @@ int main(int argc, char** argv) {
     rc |= cmd_time(8192, 8192, 8192, SPMM_EPI_BF16, 3);
     return rc;
   }
-  fprintf(stderr, "usage: gemm_bench check | time M N K [epi] [rounds] | step\n");
+  if (argc >= 5 && !strcmp(argv[1], "prof")) {    // needs the -DP8_PROFILE build (build/gemm_bench_prof): per-tile cycle stamps of wave 0
+    const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), epi = argc > 5 ? atoi(argv[5]) : 0;
+    auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
+    Buf A, W, C, C2, G, prof;
+    A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); C.alloc((size_t)M * N * 2); C2.alloc((size_t)M * N * 2); G.alloc((size_t)M * N * 2);
+    prof.alloc(256 * 16 * 8 * 8);
+    CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
+    CK(hipMemset(G.d, 0, G.bytes));
+    for (int it = 0; it < 3; ++it) {
+      CK(hipMemset(prof.d, 0, prof.bytes));
+      int rc = spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? G.d : nullptr, N, C.d, N,
+                            (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? C2.d : nullptr, N, epi, (float*)prof.d, 8, 0);
+      if (rc) { printf("rc=%d %s\n", rc, spmm_last_error()); return 1; }
+      CK(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> h(256 * 16 * 8);
+    CK(hipMemcpy(h.data(), prof.d, prof.bytes, hipMemcpyDeviceToHost));
+    // averages over every recorded (workgroup, tile): stamp 0 = tile start, 2 = main loop done, 4 = epilogue done
+    double main_s = 0, epi_s = 0, tot = 0; long cnt = 0, cnt_tot = 0;
+    for (int wg = 0; wg < 256; ++wg)
+      for (int i = 0; i < 16; ++i) {
+        const unsigned long long* t = &h[((size_t)wg * 16 + i) * 8];
+        if (!t[0] || !t[4]) continue;
+        main_s += (double)(t[2] - t[0]); epi_s += (double)(t[4] - t[2]);
+        ++cnt;
+        if (i < 15 && t[8]) { tot += (double)(t[8] - t[0]); ++cnt_tot; }
+      }
+    printf("avg over %ld tiles: mainloop %.0f  epilogue %.0f  | tile period %.0f (ticks)\n", cnt, main_s / cnt, epi_s / cnt, tot / (cnt_tot ? cnt_tot : 1));
+    return 0;
+  }
+  fprintf(stderr, "usage: gemm_bench check | time M N K [epi] [rounds] | step | prof M N K [epi]\n");
   return 2;
 }

@@ -5,6 +5,8 @@
 // pattern 1: wave instruction = 8 rows x 128 B, row stride 6 KiB      (the GEMM epilogue: N = 3072 bf16)
 // pattern 2: wave instruction = 16 rows x 64 B, row stride 6 KiB      (direct-from-accumulator stores after a permlane swap)
 // pattern 3: 8 B per lane, 16 rows x 32 B                             (raw 16x16 MFMA accumulator layout)
+// pattern 4: 8 full rows per instruction like pattern 1, but a row's 8 lanes are scattered: lane (m = l & 15, g = l >> 4) writes
+//            row m & ~1 (+1 in the second instruction), chunk (m & 1) * 4 + {0,2,1,3}[g]   (transpose-free MFMA epilogue)
 // policy 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,6 +51,10 @@ __global__ __launch_bounds__(512) void store_kernel(char* out, long ld, int tile
     } else if constexpr (PAT == 2) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) st16<POL>(wt + (long)((i >> 1) * 16 + (lane & 15)) * ld + (i & 1) * 64 + (lane >> 4) * 16, v);
+    } else if constexpr (PAT == 4) {
+      const int m = lane & 15, g = lane >> 4, chunk = (m & 1) * 4 + ((g & 1) << 1 | (g >> 1));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st16<POL>(wt + (long)((i >> 1) * 16 + (m & ~1) + (i & 1)) * ld + chunk * 16, v);
     } else {
       f32x2 w = {v[0], v[1]};
 #pragma unroll
@@ -85,5 +91,6 @@ int main(int argc, char** argv) {
   run<1, 0>(buf, ncu, tiles, ld); run<1, 1>(buf, ncu, tiles, ld); run<1, 2>(buf, ncu, tiles, ld);
   run<2, 0>(buf, ncu, tiles, ld); run<2, 1>(buf, ncu, tiles, ld);
   run<3, 0>(buf, ncu, tiles, ld); run<3, 1>(buf, ncu, tiles, ld);
+  run<4, 0>(buf, ncu, tiles, ld);
   return 0;
 }
