@@ -1,6 +1,7 @@
 """Headline benchmark: SPMM pretraining step throughput (molecules/s) on N MI355X, one process per GPU over RCCL.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py                      (1 GPU, 50 timed steps after 10 warm-up steps: SURVEY.md section 8d protocol)
+  python bench.py --gpus N             (starts `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` as a child)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = zero_grad + SPMM.forward (12 encoder passes, 4 losses) + backward + [gradient all-reduce + feature all-gather]
@@ -81,6 +82,21 @@ def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):
     return nseq * (4 * H * H * Lq + 4 * H * H * Lkv + 4 * Lq * Lkv * H)
 
 
+def cross_attn_executed_flops(groups, q_rows, H=768):
+    """FLOPs the build executes for one cross-attention block: Q and output projections on the rows actually present (packed),
+    K/V projections once per unique source row, the attention core per (query sequence, its key/value source)."""
+    kv_rows, seen, core = 0, set(), 0.0
+    for g in groups:
+        if g.src is not None:                      # shared source: unique rows, counted once however many groups attend it
+            if id(g.src) not in seen:
+                seen.add(id(g.src))
+                kv_rows += g.src.kv.shape[0]
+        else:
+            kv_rows += g.kv.shape[0] if g.kv is not None else g.nseq * g.Lkv
+        core += 4.0 * g.nseq * g.L * g.Lkv * H     # upper bound for packed groups (q_len <= L)
+    return 4.0 * H * H * q_rows + 4.0 * H * H * kv_rows + core
+
+
 def cpu_baseline(B, Lt, seconds_budget=45.0):
     """The oracle (a plain-PyTorch fp32 port of the reference's step) timed on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -108,8 +124,8 @@ def cpu_baseline(B, Lt, seconds_budget=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--layers", type=str, default="12,6,6", help="text layers, fusion layer, PV layers")
@@ -120,9 +136,19 @@ def main():
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one as a CHILD process (never exec from a process that may touch the GPU) and pass its
+        # exit code on.  Nothing in this process has initialised HIP yet.
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("SPMM_DIST_BACKEND", "nccl")          # "gloo" lets two ranks share one GPU in tests
@@ -176,9 +202,12 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread, no extra syncs
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         losses = one_step(args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -189,6 +218,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    spread = {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
+              "p90": round(per_step[int(0.9 * (len(per_step) - 1) + 0.5)], 3), "note": "GPU-side interval between consecutive steps' last kernels (this rank)"}
     final_losses = [float(x) for x in losses.cpu()]
 
     # ---- per-kernel timing with HIP events on the launch stream: same step, every GEMM / cross-attention launch bracketed.
@@ -240,7 +272,7 @@ def main():
             r = orig_blk(pfx, c, X, groups, save, cross)
             e1.record(stream)
             fl = sum(cross_attn_unit_flops(g.nseq, g.L, g.Lkv) for g in groups)
-            ev["xattn"].append((e0, e1, fl))
+            ev["xattn"].append((e0, e1, (fl, cross_attn_executed_flops(groups, X.shape[0]))))
             return r
 
         eng._attn_block_fwd = blk
@@ -250,17 +282,22 @@ def main():
         eng._attn_block_fwd = orig_blk
         model.engine.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
         x_ms = sum(a.elapsed_time(b) for a, b, _ in ev["xattn"])
-        x_fl = sum(fl for _, _, fl in ev["xattn"])
-        x_ach = x_fl / (x_ms * 1e-3) / 1e12
-        xattn = {"unit": "cross-attention block forward (Q,K,V projections + core + out-proj + residual LN), S6 batch and momentum S5",
-                 "achieved_tflops": round(x_ach, 1), "mfma_util": round(x_ach / PEAK_BF16_TFLOPS, 4),
+        x_alg = sum(fl[0] for _, _, fl in ev["xattn"])
+        x_exe = sum(fl[1] for _, _, fl in ev["xattn"])
+        xattn = {"unit": "cross-attention block forward (Q, K, V projections + softmax(QK^T/8 + mask)V + output projection + residual LN), "
+                         "the 12 calls of a step (S6 student batch and S5 momentum batch)",
+                 "algorithmic_tflops": round(x_alg / (x_ms * 1e-3) / 1e12, 1),
+                 "executed_tflops": round(x_exe / (x_ms * 1e-3) / 1e12, 1),
+                 "executed_frac_of_bf16_peak": round(x_exe / (x_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                  "calls_per_step": len(ev["xattn"]) // nsteps, "ms_per_step": round(x_ms / nsteps, 3),
-                 "note": "algorithmic FLOPs nseq*(4H^2 Lq + 4H^2 Lkv + 4 Lq Lkv H), padded-tile waste excluded; not yet a single fused kernel"}
+                 "note": "algorithmic = the reference's work, nseq*(4H^2 Lq + 4H^2 Lkv + 4 Lq Lkv H) per query sequence; executed = what runs here "
+                         "(K/V projected once per unique key/value source, packed rows); padded-tile waste excluded from both"}
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in ev["gemm"])
         tot_fl = sum(fl for _, _, fl in ev["gemm"])
         n_launch = len(ev["gemm"])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16, all launches of the step)", "achieved": round(ach, 1),
+        roof = {"bound": "mfma", "kernel": "NT GEMM family, all launches of the step: gemm_nt_p8_kernel (persistent 256x256 8-phase, bf16 MFMA "
+                                           "16x16x32) for the large shapes, gemm_nt_v2/v1 for fp32 outputs and small problems", "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "launches_per_step": n_launch // nsteps, "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
                 "flops_per_step": tot_fl / nsteps, "gemm_ms_per_step": round(tot_ms / nsteps, 3),
@@ -268,19 +305,19 @@ def main():
                 "measured": f"HIP events around every launch, {nsteps} instrumented single-stream steps after the timed region"}
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_nt_gemm.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_nt_gemm.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc["workload"] == {"batch": B, "seq_len": Lt, "layers": nt, "queue": args.queue}:
                 roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
-                roof["traffic_note"] = ("bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_nt_gemm.json "
+                roof["traffic_note"] = ("bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r02_pmc_nt_gemm.json "
                                         "(L2<->fabric requests, Infinity-Cache hits included)")
 
     flops = step_flops(B, Lt, n_text=nt, fusion=f, n_pv=npv, Q=args.queue)
     value = world * B / (dt / args.steps)
     out = {"metric": "pretrain molecules/sec", "value": round(value, 2), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16", "data": "synthetic",
+           "dtype": "bf16", "data": "synthetic", "step_ms": spread,
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}"},

@@ -181,9 +181,11 @@ int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, 
 int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
                   int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
                   float* dw, float* db, int do_bwd, spmm_stream_t stream);
-/* _dequeue_and_enqueue SPMM_models.py:272-286 (+ the bf16 GEMM shadows of the queue). */
+/* _dequeue_and_enqueue SPMM_models.py:272-286 (+ the bf16 GEMM shadows of the queue).  skip_flag (optional, device int): when
+ * non-zero neither the queue nor the pointer is touched -- the reference's NaN guard returns before the enqueue
+ * (SPMM_models.py:132-134 vs :208), so a non-finite momentum feature never enters the queue. */
 int spmm_enqueue(const float* feats, int n, int E, float* queue, int Q, void* w3, void* qT, long ldt, int Bloc, long* ptr,
-                 int advance, spmm_stream_t stream);
+                 int advance, const int* skip_flag, spmm_stream_t stream);
 int spmm_queue_shadow(const float* queue, int E, int Q, void* w3, void* qT, long ldt, int Bloc, spmm_stream_t stream);
 /* temp.clamp_(0.01, 0.5) SPMM_models.py:80-81 */
 int spmm_clamp_scalar(float* p, float lo, float hi, spmm_stream_t stream);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const float inv = 1.f / sum;
   if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
   if (p.drop_thresh16) {
-    const uint32_t rowkey = drop_rowkey(*p.seed_ptr ^ p.seed_salt, ((uint64_t)seq * p.nH + h) * p.Lq + q);
+    const uint32_t rowkey = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
 
   const bool causal = seq >= p.causal_from;
   const bool drop = p.drop_thresh16 != 0;
-  const uint64_t seed = drop ? (*p.seed_ptr ^ p.seed_salt) : 0;
+  const uint64_t seed = drop ? seed_mix(p.seed_ptr, p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
   if (drop && tid < 128) rk[tid] = drop_rowkey(seed, headbase + tid);
   const int NTq = (Lq + 31) >> 5;

@@ -48,6 +48,16 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32" finalis
 // One finaliser round over (index xor seed): lowbias32 is built to decorrelate consecutive integers, which is all a
 // dropout mask needs; a second round doubled the integer work of the attention kernels for no measurable change in
 // the mask statistics (tests/test_kernels_gpu.py::test_attention_dropout_consistency, ::test_layernorm_dropout_masks_match).
+// Effective seed of a call site: the per-step seed (a counter that advances by 1) and the per-call-site salt go through two
+// splitmix64 rounds BEFORE they meet the element index, so consecutive steps / layers get unrelated masks (xor-ing a counter
+// straight into the index would make mask_{n+1}(i) = mask_n(i ^ d)).  Once per thread, not per element.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t seed_mix(const uint64_t* seed_ptr, uint64_t salt) { return splitmix64(splitmix64(*seed_ptr) + salt); }
 __device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
   uint32_t lo = (uint32_t)pair_idx, hi = (uint32_t)(pair_idx >> 32);
   uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);

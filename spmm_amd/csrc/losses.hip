@@ -140,7 +140,7 @@ __global__ void sample_neg_kernel(const float* __restrict__ S, long ldj, int B, 
   float tot = 0.f;
   for (int j = lane; j < B; j += 64) tot += (j == row) ? 0.f : __expf(s[j] - mx);
   tot = wave_sum(tot);
-  const float target = rng_uniform(*seed_ptr ^ salt, (uint64_t)row) * tot;
+  const float target = rng_uniform(seed_mix(seed_ptr, salt), (uint64_t)row) * tot;
   // sequential scan in chunks of 64 with a wave prefix sum
   float run = 0.f;
   int pick = -1;
@@ -318,7 +318,9 @@ __global__ void mpm_head_kernel(const bf16* __restrict__ h, int Lp, int H, const
 // w3 [B + Q, 3E] bf16 split rows (sim-GEMM W operand; queue column j lives at row B + j),
 // qT [E, ldt] bf16 (dfeat-GEMM W operand; queue column j lives at column B + j).  ptr advances by n mod Q.
 __global__ void enqueue_kernel(const float* __restrict__ feats, int n, int E, float* __restrict__ queue, int Q,
-                               bf16* __restrict__ w3, bf16* __restrict__ qT, long ldt, int Bloc, long* __restrict__ ptr, int advance) {
+                               bf16* __restrict__ w3, bf16* __restrict__ qT, long ldt, int Bloc, long* __restrict__ ptr,
+                               const int* __restrict__ skip) {
+  if (skip && *skip) return;                 // NaN step: the reference returns before _dequeue_and_enqueue (SPMM_models.py:132-134, :208)
   const long p0 = *ptr;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const long col = (p0 + i) % Q;
@@ -332,9 +334,11 @@ __global__ void enqueue_kernel(const float* __restrict__ feats, int n, int E, fl
       qT[(long)c * ldt + Bloc + col] = hi;
     }
   }
-  (void)advance;
 }
-__global__ void advance_ptr_kernel(long* ptr, int n, int Q) { *ptr = (*ptr + n) % Q; }
+__global__ void advance_ptr_kernel(long* ptr, int n, int Q, const int* skip) {
+  if (skip && *skip) return;
+  *ptr = (*ptr + n) % Q;
+}
 
 // rebuild the bf16 shadows of the whole queue from the fp32 master (after load_state_dict)
 __global__ void queue_shadow_kernel(const float* __restrict__ queue, int E, int Q, bf16* __restrict__ w3, bf16* __restrict__ qT,
@@ -418,10 +422,10 @@ extern "C" int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const
   return SPMM_OK;
 }
 extern "C" int spmm_enqueue(const float* feats, int n, int E, float* queue, int Q, void* w3, void* qT, long ldt, int Bloc, long* ptr,
-                            int advance, hipStream_t stream) {
+                            int advance, const int* skip_flag, hipStream_t stream) {
   SPMM_CHECK_SHAPE(n > 0 && E > 0 && Q % n == 0, "spmm_enqueue: queue_size %d %% batch %d != 0 (SPMM_models.py:279)", Q, n);
-  hipLaunchKernelGGL(enqueue_kernel, dim3(n < 256 ? n : 256), dim3(256), 0, stream, feats, n, E, queue, Q, (bf16*)w3, (bf16*)qT, ldt, Bloc, ptr, advance);
-  if (advance) hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, stream, ptr, n, Q);
+  hipLaunchKernelGGL(enqueue_kernel, dim3(n < 256 ? n : 256), dim3(256), 0, stream, feats, n, E, queue, Q, (bf16*)w3, (bf16*)qT, ldt, Bloc, ptr, skip_flag);
+  if (advance) hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, stream, ptr, n, Q, skip_flag);
   SPMM_LAUNCH_CHECK("spmm_enqueue");
   return SPMM_OK;
 }

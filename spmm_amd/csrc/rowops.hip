@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   RowVec z, r, o;
   load_row_bf16(x + row * H, H, lane, z);
   if (thresh16) {
-    const uint64_t seed = *seed_ptr ^ salt;
+    const uint64_t seed = seed_mix(seed_ptr, salt);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (lane + 64 * i) * 4;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
   for (int i = 0; i < NC; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) gsum[i][j] = bsum[i][j] = xsum[i][j] = 0.f;
-  const uint64_t seed = thresh16 ? (*seed_ptr ^ salt) : 0;
+  const uint64_t seed = thresh16 ? seed_mix(seed_ptr, salt) : 0;
   const long stride = (long)gridDim.x * 4;
   long row = (long)blockIdx.x * 4 + wave;
   RawRow<NC> ng, ng2, nz;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(EmbedP p) {
   float mean, rstd;
   ln_apply(z, p.H, lane, p.gamma, p.beta, p.eps, mean, rstd, o);
   if (p.thresh16) {
-    const uint64_t seed = *p.seed_ptr ^ p.salt;
+    const uint64_t seed = seed_mix(p.seed_ptr, p.salt);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (lane + 64 * i) * 4;

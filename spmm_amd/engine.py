@@ -107,7 +107,10 @@ class Engine:
         self.gscale = torch.ones(4, **f32)                 # d(total)/d(loss_k), order (mlm, mpm, ita, itm)
         self.losses = torch.zeros(8, **f32)
         self.loss_scratch = torch.zeros(8, **f32)
-        self.seed = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+        # dropout / negative-sampling seed: a device counter advanced once per training-mode forward (step.py), different on every
+        # data-parallel rank, saved and restored with the checkpoint (model.py)
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        self.seed = torch.full((1,), (0x5DEECE66D + rank * 0x9E3779B97F4A7C15) % (1 << 62), dtype=torch.int64, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)

@@ -197,16 +197,42 @@ class SPMM(nn.Module):
     # ---- checkpoints in the reference's Lightning layout (SPMM_pretrain.py:24-37; consumers d_pv2smiles_batched.py:133-146,
     #      d_regression.py:153-162, SPMM_models_rxn.py:16-27) ----------------------------------------------------------------
     def save_checkpoint(self, path: str, **extra):
+        """Lightning-layout dict: 'state_dict' (what every reference consumer reads) plus what a resumed run needs to continue
+        bit-for-bit -- Adam moments and step count, the schedule position / lr, the dropout seed (Lightning's ckpt_path resume,
+        SPMM_pretrain.py:37, restores optimizer and scheduler state too)."""
         sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
-        torch.save(dict(state_dict=sd, epoch=self.current_epoch, **extra), path)
+        ck = dict(state_dict=sd, epoch=self.current_epoch, global_step=getattr(self, "global_step", 0), rng_seed=int(self.engine.seed.item()))
+        if self._optimizer is not None:
+            o = self._optimizer
+            ck["optimizer_states"] = [dict(adam_m=self.store.adam_m.detach().cpu().clone(), adam_v=self.store.adam_v.detach().cpu().clone(),
+                                           step_count=int(o.step_count.item()), param_groups=[dict(g) for g in o.param_groups])]
+        ck.update(extra)
+        torch.save(ck, path)
 
     def load_checkpoint(self, path_or_dict, strict: bool = False):
         """Accepts the Lightning dict ('state_dict'), the legacy 'model' key, or a bare state_dict; applies the legacy
-        `_unk -> _mask` rename and drops nothing the arena knows.  strict=False mirrors SPMM_pretrain.py:26."""
+        `_unk -> _mask` rename and drops nothing the arena knows.  strict=False mirrors SPMM_pretrain.py:26.  Optimizer state,
+        epoch / global step and the dropout seed are restored when the checkpoint carries them."""
         ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
         sd = ck.get("state_dict", ck.get("model", ck))
         sd = {k.replace("_unk", "_mask"): v for k, v in sd.items()}
-        return self.load_state_dict(sd, strict=strict)
+        res = self.load_state_dict(sd, strict=strict)
+        if isinstance(ck, dict):
+            if "rng_seed" in ck:
+                self.engine.seed.fill_(int(ck["rng_seed"]))
+            if "epoch" in ck and isinstance(ck["epoch"], int):
+                self.current_epoch = ck["epoch"]
+            if "global_step" in ck:
+                self.global_step = int(ck["global_step"])
+            st = ck.get("optimizer_states")
+            if st and not self.no_train and "adam_m" in st[0]:
+                o = self.optimizers()
+                self.store.adam_m.copy_(st[0]["adam_m"])
+                self.store.adam_v.copy_(st[0]["adam_v"])
+                o.step_count.fill_(int(st[0]["step_count"]))
+                for g, saved in zip(o.param_groups, st[0]["param_groups"]):
+                    g.update(saved)
+        return res
 
     @property
     def queue_ptr(self):
@@ -261,7 +287,6 @@ class SPMM(nn.Module):
         eng, opt = self.engine, self.optimizers()
         eng.train_mode = self.training
         eng.alpha.fill_(float(alpha))
-        eng.seed.add_(1)
         eng.gscale.fill_(1.0)
         self.store.grad.zero_()
         dev = self.device_

@@ -208,10 +208,10 @@ def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None,
                _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), _st())
 
 
-def enqueue(feats, queue, w3, qT, ptr, *, Bloc, advance=True):
+def enqueue(feats, queue, w3, qT, ptr, *, Bloc, advance=True, skip_flag=None):
     n, E = feats.shape
     _call("spmm_enqueue", _p(feats), n, E, _p(queue), queue.shape[1], _p(w3), _p(qT), _row_stride(qT), Bloc, _p(ptr),
-               int(advance), _st())
+               int(advance), _p(skip_flag), _st())
 
 
 def queue_shadow(queue, w3, qT, *, Bloc):

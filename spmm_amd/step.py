@@ -38,6 +38,8 @@ class PretrainStep(Engine):
         if B % 4 or cfg.queue_size % 4:
             raise ValueError("batch size and queue size must be multiples of 4")
         self._salt = 0
+        if self.train_mode:
+            self.seed.add_(1)               # new dropout masks / negative draws every step; backward re-reads the same value
         self.losses.zero_()
         self.dtemp_ita.zero_()
         self.nan_flag.zero_()
@@ -195,10 +197,15 @@ class PretrainStep(Engine):
         # ---- queue (:208, :272-286)
         feat_pm, feat_tm = feats["property_proj_m"][0], feats["text_proj_m"][0]
         if gather is not None:
-            feat_pm, feat_tm = gather(feat_pm), gather(feat_tm)
+            # ONE all-gather per step (SPMM_models.py:273-274 issues two): [prop_feat_m | text_feat_m | NaN flag].  The flag column
+            # makes the NaN decision (skip enqueue + optimiser step) identical on every rank, so the replicas cannot diverge.
+            g = gather(torch.cat([feat_pm, feat_tm, self.nan_flag.to(torch.float32).expand(B, 1)], 1))
+            feat_pm, feat_tm = g[:, :E].contiguous(), g[:, E:2 * E].contiguous()
+            self.nan_flag.copy_((g[:, 2 * E].abs().sum() > 0).to(torch.int32).view(1))
         ptr = P.buffers["queue_ptr"]
-        ops.enqueue(feat_pm, P.buffers["prop_queue"], *bank["prop"], ptr, Bloc=B, advance=False)
-        ops.enqueue(feat_tm, P.buffers["text_queue"], *bank["text"], ptr, Bloc=B, advance=True)
+        # NaN step: the reference returns at :132-134, before the enqueue at :208 -- queue and pointer stay untouched
+        ops.enqueue(feat_pm, P.buffers["prop_queue"], *bank["prop"], ptr, Bloc=B, advance=False, skip_flag=self.nan_flag)
+        ops.enqueue(feat_tm, P.buffers["text_queue"], *bank["text"], ptr, Bloc=B, advance=True, skip_flag=self.nan_flag)
 
         # ---- LM loss (:211-238)
         self._join(side5)

@@ -47,4 +47,4 @@ def test_bad_shape_is_reported_without_touching_the_gpu(built):
     with pytest.raises(RuntimeError, match=r"must be in \[1,128\]"):
         L.call("spmm_attn_fwd", None, 64, None, 64, None, 64, None, None, None, None, None, None, None, 64, None, 1, 1, 300, 54, 1, 0, 0.0, None, 0, 0, 0, None)
     with pytest.raises(RuntimeError, match="SPMM_models.py:279"):
-        L.call("spmm_enqueue", None, 5, 64, None, 16, None, None, 64, 4, None, 1, None)
+        L.call("spmm_enqueue", None, 5, 64, None, 16, None, None, 64, 4, None, 1, None, None)

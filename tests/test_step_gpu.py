@@ -278,6 +278,85 @@ def test_train_mode_dropout_runs_and_is_seeded(env):
     assert (outs[0] - outs[2]).abs().max().item() > 1e-4          # different seed, different masks
 
 
+def _tiny_train_model(env, dropout=True):
+    O, SPMM, tiny_config, *_ = env
+    cfg = tiny_config()
+    if not dropout:
+        for c in (cfg.text, cfg.prop):
+            c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sched = {'sched': 'cosine', 'lr': 1e-3, 'epochs': 4, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 1e-4,
+             'warmup_epochs': 2, 'cooldown_epochs': 0}
+    tc = {'embed_dim': 64, 'temp': 0.07, 'queue_size': 16, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
+          'optimizer': {'opt': 'adamW', 'lr': 1e-3, 'weight_decay': 0.02}}
+    m = SPMM(config=tc, spmm_config=cfg, loader_len=10)
+    m.load_state_dict(O.closed_form_state_dict(O.tiny_cfg()))
+    return m.train()
+
+
+def test_forward_api_draws_new_masks_every_call(env):
+    """The reference-style `model(...)` API in train mode: every call must use fresh dropout masks and negative draws
+    (the seed is a device counter advanced by the engine's forward, not only by fused_step)."""
+    O = env[0]
+    m = _tiny_train_model(env)
+    prop, ids, mask = O.synthetic_batch(4, 16, seed=7)
+    mpm = torch.zeros(4, 53).cuda()
+    neg = tuple(_cuda(torch.arange(4).roll(1), torch.arange(4).roll(2)))
+    s0 = int(m.engine.seed)
+    with torch.no_grad():
+        a = torch.stack(m(prop, ids, mask, alpha=0.4, mpm_mask=mpm, neg_idx=neg)).cpu()
+        m.load_state_dict(O.closed_form_state_dict(O.tiny_cfg()))
+        b = torch.stack(m(prop, ids, mask, alpha=0.4, mpm_mask=mpm, neg_idx=neg)).cpu()
+    assert int(m.engine.seed) == s0 + 2
+    assert (a - b).abs().max().item() > 1e-4            # same weights, same batch, different masks
+    m.eval()
+    with torch.no_grad():
+        m(prop, ids, mask, alpha=0.4, mpm_mask=mpm, neg_idx=neg)
+    assert int(m.engine.seed) == s0 + 2                  # eval forwards draw nothing
+
+
+def test_nan_step_leaves_queue_and_pointer_untouched(env):
+    """SPMM_models.py:132-134 returns before _dequeue_and_enqueue (:208): a non-finite momentum feature must not enter the
+    queue (it would poison every similarity until its slot is overwritten) and the optimiser step is skipped."""
+    O = env[0]
+    m = _tiny_train_model(env, dropout=False)
+    prop, ids, mask = O.synthetic_batch(4, 16, seed=7)
+    m.fused_step(prop, ids, mask, 0.4)                   # a healthy step first
+    q0, t0, p0 = m.store.buffers["prop_queue"].clone(), m.store.buffers["text_queue"].clone(), int(m.queue_ptr)
+    w0 = m.store.flat.clone()
+    m.store.w("text_proj_m.bias")[0] = float("nan")      # momentum text feature -> NaN similarities
+    losses = m.fused_step(prop, ids, mask, 0.4).cpu()
+    assert int(m.engine.nan_flag) == 1
+    assert torch.equal(m.store.buffers["prop_queue"], q0) and torch.equal(m.store.buffers["text_queue"], t0)
+    assert int(m.queue_ptr) == p0
+    assert torch.equal(m.store.flat, w0)                 # AdamW skipped on the device
+    assert torch.isfinite(m.store.buffers["prop_queue"]).all()
+    del losses
+
+
+def test_checkpoint_resume_continues_the_run(env, tmp_path):
+    """save_checkpoint / load_checkpoint carry the Adam moments, step count, lr and the dropout seed: a resumed run takes the
+    same next step as the uninterrupted one (dropout on)."""
+    O = env[0]
+    batches = [O.synthetic_batch(4, 16, seed=20 + i) for i in range(3)]
+    a = _tiny_train_model(env)
+    for i in range(2):
+        a.fused_step(*batches[i], 0.4)
+    path = str(tmp_path / "ck.pt")
+    a.current_epoch = 1
+    a.save_checkpoint(path)
+    mpm = (torch.arange(4 * 53).view(4, 53) % 3 == 0).float().cuda()   # the bernoulli draw comes from torch's global generator: pin it
+    la = a.fused_step(*batches[2], 0.4, mpm_mask=mpm).cpu()
+    b = _tiny_train_model(env)
+    b.load_checkpoint(path)
+    assert b.current_epoch == 1 and int(b.optimizers().step_count) == 2 and int(b.engine.seed) == int(a.engine.seed) - 1
+    lb = b.fused_step(*batches[2], 0.4, mpm_mask=mpm).cpu()
+    assert torch.allclose(la, lb, rtol=0, atol=5e-5), (la, lb)          # atomics-order noise only
+    da = (a.store.flat - b.store.flat).abs().max().item()
+    assert da < 5e-6, da
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck["state_dict"].keys()) == set(a.state_dict().keys())   # the reference's consumers still find their layout
+
+
 def test_on_device_negative_sampling_and_bernoulli(env):
     O, SPMM, tiny_config, *_ = env
     sd = O.closed_form_state_dict(O.tiny_cfg())
