@@ -481,18 +481,20 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   SPMM_CHECK_SHAPE((q_row0 == nullptr) == (q_len == nullptr) && (kv_row0 == nullptr) == (kv_len == nullptr),
                    "spmm_attn_bwd: row0 and len arrays come in pairs");
   SPMM_CHECK_SHAPE(d_mode == 0 || ((d_mode == 1 || d_mode == 2) && Dbuf != nullptr), "spmm_attn_bwd: d_mode=%d needs Dbuf", d_mode);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // > 64 KiB dynamic LDS needs the opt-in: once per process (function-local static: initialised exactly once, thread-safe --
+  // backward entries are called from autograd worker threads)
+  static const hipError_t attr_rc = [] {
     const void* fns[4] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
                           (const void*)attn_bwd_kernel<4>};
     for (int i = 0; i < 4; ++i) {
       hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-      if (e != hipSuccess) {
-        spmm_set_error("spmm_attn_bwd: cannot raise dynamic LDS to %d: %s", BWD_LDS, hipGetErrorString(e));
-        return SPMM_ERR_LAUNCH;
-      }
+      if (e != hipSuccess) return e;
     }
-    attr_set = true;
+    return hipSuccess;
+  }();
+  if (attr_rc != hipSuccess) {
+    spmm_set_error("spmm_attn_bwd: cannot raise dynamic LDS to %d: %s", BWD_LDS, hipGetErrorString(attr_rc));
+    return SPMM_ERR_LAUNCH;
   }
   AttnP p = {};
   p.Q = (const bf16*)Q; p.ldq = ldq; p.K = (const bf16*)K; p.ldk = ldk; p.V = (const bf16*)V; p.ldv = ldv;

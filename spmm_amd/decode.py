@@ -1,10 +1,7 @@
-"""PV -> SMILES k-beam decoding (BASELINE.json configs[3]) on the sub-module facades.
-
-Restates `generate` (d_pv2smiles_single.py:26-51, deterministic top-k branch) and the beam bookkeeping of `evaluate`
-(d_pv2smiles_batched.py:18-59) with the reference's semantics: every step re-runs the 12-layer causal text encoder with
-cross-attention to the PV embeddings on the whole prefix of all k beams (no KV cache -- that, and batching several
-molecules per launch, is the planned optimisation).  Works with anything exposing the reference's module API
-(`property_embed`, `property_cls`, `property_encoder`, `text_encoder`), so tests drive it with the CPU oracle as well."""
+"""PV -> SMILES k-beam decoding (BASELINE.json configs[3]): N molecules x k beams per launch with
+a key/value cache, returning per molecule the hypotheses the reference's one-molecule, whole-prefix-per-step search
+(`generate`, d_pv2smiles_single.py:26-51; `evaluate`, d_pv2smiles_batched.py:18-59) returns.  That sequential search is
+restated in oracle/decode_oracle.py -- test infrastructure, the yard-stick of tests/ -- not here."""
 from __future__ import annotations
 
 from typing import List, Tuple
@@ -26,19 +23,6 @@ def _pick(p: torch.Tensor, k: int, stochastic: bool, generator=None) -> Tuple[to
 
 
 @torch.no_grad()
-def next_token_topk(model, prop_embeds: torch.Tensor, text: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """d_pv2smiles_single.generate with stochastic=False, k given: log of the top-k next-token probabilities and their ids.
-    text: [beams, t] ids (0 = PAD), prop_embeds: [1 or beams, 54, H]."""
-    text_atts = torch.where(text == 0, 0, 1)
-    prop_att_mask = torch.ones(prop_embeds.shape[:-1], dtype=torch.long, device=prop_embeds.device)
-    logits = model.text_encoder(text, attention_mask=text_atts, encoder_hidden_states=prop_embeds,
-                                encoder_attention_mask=prop_att_mask, return_dict=True, is_decoder=True, return_logits=True)[:, -1, :]
-    p = torch.softmax(logits.float(), dim=-1)
-    top = torch.topk(p, k=k, dim=-1)
-    return torch.log(top.values), top.indices
-
-
-@torch.no_grad()
 def encode_properties(model, prop: torch.Tensor, prop_mask: torch.Tensor | None = None) -> torch.Tensor:
     """d_pv2smiles_batched.py:24-27: PV [B,53] -> prop_embeds [B,54,H].  prop_mask ([53] or [B,53], 1 = property unknown)
     substitutes the learned mask token for those entries, as conditional generation on a subset of properties does
@@ -53,39 +37,11 @@ def encode_properties(model, prop: torch.Tensor, prop_mask: torch.Tensor | None 
     return model.property_encoder(inputs_embeds=properties, return_dict=True).last_hidden_state
 
 
-@torch.no_grad()
-def beam_search(model, prop: torch.Tensor, k: int = 5, max_steps: int = 100) -> List[Tuple[float, List[int]]]:
-    """One molecule (prop: [53]).  Returns up to k finished hypotheses (log-prob, token ids incl. CLS and SEP), best first."""
-    prop_embeds = encode_properties(model, prop.reshape(1, -1))
-    dev = prop_embeds.device
-    product_input = torch.full((1, 1), CLS_ID, dtype=torch.long, device=dev)
-    values, indices = next_token_topk(model, prop_embeds, product_input, k)
-    product_input = torch.cat([torch.full((k, 1), CLS_ID, dtype=torch.long, device=dev), indices.squeeze(0).unsqueeze(-1)], dim=-1)
-    current_p = values.squeeze(0)
-    final: List[Tuple[float, torch.Tensor]] = []
-    for _ in range(max_steps):
-        values, indices = next_token_topk(model, prop_embeds, product_input, k)
-        k2_p = current_p[:, None] + values
-        product_input_k2 = torch.cat([product_input.unsqueeze(1).repeat(1, k, 1), indices.unsqueeze(-1)], dim=-1)
-        ends = (indices == SEP_ID).nonzero(as_tuple=False)
-        if ends.numel():
-            for e in ends:
-                final.append((float(k2_p[e[0], e[1]]), product_input_k2[e[0], e[1]].clone()))
-                k2_p[e[0], e[1]] = -1e5
-            if len(final) >= k:
-                break
-        current_p, flat = torch.topk(k2_p.flatten(), k)
-        rows, cols = flat // k, flat % k
-        product_input = product_input_k2[rows, cols]
-    final = sorted(final, key=lambda x: x[0], reverse=True)[:k]
-    return [(p, s.tolist()) for p, s in final]
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # Batched decoding: N molecules x k beams per launch, key/value cache, no host round trips inside the loop.
 # ------------------------------------------------------------------------------------------------------------------
 class BeamBook:
-    """The beam bookkeeping of `beam_search` above for N independent molecules at once, as tensor ops (no `.item()`):
+    """The beam bookkeeping of the reference's search for N independent molecules at once, as tensor ops (no `.item()`):
     per molecule it makes exactly the decisions d_pv2smiles_batched.py:29-57 makes -- candidates ending in [SEP] are moved to
     `final` in row-major order and struck out with -1e5, the molecule stops once it holds >= k finals, the k best of the
     k*k candidates survive."""
@@ -304,7 +260,8 @@ class CachedDecoder:
 def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
                         sync_every: int = 4, prop_mask: torch.Tensor | None = None, stochastic: bool = False,
                         generator=None, graph: bool = False) -> List[List[Tuple[float, List[int]]]]:
-    """`beam_search` for N molecules at once (props [N,53]); result[n] is what beam_search(model, props[n]) returns.
+    """The reference's beam search for N molecules at once (props [N,53]); result[n] is what the one-molecule search
+    (oracle/decode_oracle.py::beam_search) returns for props[n].
     cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
     through the module API (any model exposing it, e.g. the CPU oracle).  prop_mask: properties to leave unspecified
     (encode_properties).  stochastic=True draws the k candidates of every beam from the next-token distribution instead of

@@ -16,6 +16,12 @@ from torch import nn
 
 from . import ops
 from .config import SPMMConfig, is_buffer, student_of
+
+try:                                    # the reference subclasses pl.LightningModule (SPMM_models.py:16); keep that when it is importable
+    import pytorch_lightning as _pl
+    _Base, _HAS_PL = _pl.LightningModule, True
+except Exception:                       # not installed on the target image: the members SPMM_models.py:345-386 uses are provided below
+    _Base, _HAS_PL = nn.Module, False
 from .params import ParamStore
 from .step import PretrainStep
 
@@ -89,7 +95,7 @@ class _StepFn(torch.autograd.Function):
         return (None, None, None, None, None) + grads
 
 
-class SPMM(nn.Module):
+class SPMM(_Base):
     def __init__(self, tokenizer=None, config=None, loader_len=0, no_train=False, device=None, spmm_config: Optional[SPMMConfig] = None):
         super().__init__()
         if not torch.cuda.is_available() and not ops._DRY_RUN:
@@ -134,8 +140,10 @@ class SPMM(nn.Module):
         for nm in ("property_proj", "text_proj", "itm_head", "property_embed", "property_proj_m", "text_proj_m"):
             object.__setattr__(self, nm, LinearFacade(self, nm))
         object.__setattr__(self, "property_mtr_head", MtrHeadFacade(self))
-        self.current_epoch = 0
-        self.global_rank = 0
+        if not _HAS_PL:                     # read-only trainer-backed properties under Lightning
+            self.current_epoch = 0
+            self.global_rank = 0
+        self.global_step_ = 0
         self._optimizer = None
         self._scheduler = None
         self.logged = {}
@@ -190,9 +198,35 @@ class SPMM(nn.Module):
     def temp(self):
         return self._parameters["temp"]
 
-    @property
-    def device(self):
-        return self.device_
+    if not _HAS_PL:
+        @property
+        def device(self):
+            return self.device_
+
+        @property
+        def global_step(self):
+            return self.global_step_
+
+        @global_step.setter
+        def global_step(self, v):
+            self.global_step_ = int(v)
+
+        def log(self, name, value, prog_bar=False, **kw):        # self.log(...) of SPMM_models.py:365-370
+            self.logged[name] = value
+
+        def manual_backward(self, loss):                         # SPMM_models.py:360
+            loss.backward()
+
+    def lr_scheduler_step(self, scheduler, *args):               # SPMM_models.py:345: manual stepping only
+        pass
+
+    def on_train_epoch_end(self):
+        """SPMM_models.py:382-386: mean of the last (up to) 1000 steps' losses, printed by rank 0."""
+        if self.training_step_outputs:
+            tmp = torch.stack(self.training_step_outputs[-1000:]).float().mean(dim=0).tolist()
+            if self.global_rank == 0:
+                print(f"\n mean loss: {tmp[0]:.4f}, {tmp[1]:.4f}, {tmp[2]:.4f}, {tmp[3]:.4f}")
+        self.training_step_outputs.clear()
 
     # ---- checkpoints in the reference's Lightning layout (SPMM_pretrain.py:24-37; consumers d_pv2smiles_batched.py:133-146,
     #      d_regression.py:153-162, SPMM_models_rxn.py:16-27) ----------------------------------------------------------------
@@ -201,7 +235,7 @@ class SPMM(nn.Module):
         bit-for-bit -- Adam moments and step count, the schedule position / lr, the dropout seed (Lightning's ckpt_path resume,
         SPMM_pretrain.py:37, restores optimizer and scheduler state too)."""
         sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
-        ck = dict(state_dict=sd, epoch=self.current_epoch, global_step=getattr(self, "global_step", 0), rng_seed=int(self.engine.seed.item()))
+        ck = dict(state_dict=sd, epoch=int(self.current_epoch), global_step=int(self.global_step_), rng_seed=int(self.engine.seed.item()))
         if self._optimizer is not None:
             o = self._optimizer
             ck["optimizer_states"] = [dict(adam_m=self.store.adam_m.detach().cpu().clone(), adam_v=self.store.adam_v.detach().cpu().clone(),
@@ -220,10 +254,10 @@ class SPMM(nn.Module):
         if isinstance(ck, dict):
             if "rng_seed" in ck:
                 self.engine.seed.fill_(int(ck["rng_seed"]))
-            if "epoch" in ck and isinstance(ck["epoch"], int):
+            if "epoch" in ck and isinstance(ck["epoch"], int) and not _HAS_PL:
                 self.current_epoch = ck["epoch"]
             if "global_step" in ck:
-                self.global_step = int(ck["global_step"])
+                self.global_step_ = int(ck["global_step"])
             st = ck.get("optimizer_states")
             if st and not self.no_train and "adam_m" in st[0]:
                 o = self.optimizers()
@@ -308,7 +342,8 @@ class SPMM(nn.Module):
 
     def training_step(self, train_batch, batch_idx):
         """SPMM_models.py:348-380 (tokenisation :353 is the caller's job when `text` is already a tensor pair)."""
-        prop, text = train_batch
+        prop, text = train_batch[0], train_batch[1]
+        draws = train_batch[2] if len(train_batch) > 2 else {}
         if isinstance(text, (tuple, list)) and torch.is_tensor(text[0]):
             ids, mask = text
         else:
@@ -319,14 +354,18 @@ class SPMM(nn.Module):
         from .parallel import grad_sync_fn
         if self._grad_sync is None:
             self._grad_sync = grad_sync_fn(self.store) or False
-        losses = self.fused_step(prop, ids, mask, alpha, grad_sync=self._grad_sync or None)
+        losses = self.fused_step(prop, ids, mask, alpha, grad_sync=self._grad_sync or None, mpm_mask=draws.get("mpm_mask"),
+                                 neg_idx=draws.get("neg_idx"))
         if self.global_rank == 0:
-            self.logged = {"lr": opt.param_groups[0]["lr"], "losses": losses}
+            self.logged = {"lr": opt.param_groups[0]["lr"], "losses": losses}      # device tensor: no host read per step
         step_size, warm = 100, self.warmup_steps
         if self.current_epoch > 0 and batch_idx == 0:
             opt.param_groups[0]["lr"] = sch.lr_at(self.current_epoch + warm)
         elif self.current_epoch == 0 and batch_idx % step_size == 0 and batch_idx <= warm * step_size:
             opt.param_groups[0]["lr"] = sch.lr_at(batch_idx // step_size)
-        out = losses.detach().clone()
+        out = losses[:4].detach().clone()
         self.training_step_outputs.append(out)
+        if len(self.training_step_outputs) > 1000:         # only the last 1000 feed on_train_epoch_end (:383)
+            del self.training_step_outputs[:-1000]
+        self.global_step_ += 1
         return out

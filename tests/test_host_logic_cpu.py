@@ -174,7 +174,8 @@ def test_batched_beam_bookkeeping_matches_sequential_search():
     d_pv2smiles_batched.py:29-57 -- same hypotheses, same order, same scores -- including molecules that stop early, ones
     that never finish and ones with several [SEP] candidates in one step."""
     import torch
-    from spmm_amd.decode import beam_search, beam_search_batched
+    from spmm_amd.decode import beam_search_batched
+    from decode_oracle import beam_search                 # oracle/: the reference's sequential one-molecule search
     m = _HashLM()
     props = torch.randn(12, 53, generator=torch.Generator().manual_seed(1))
     for k, steps in ((3, 10), (5, 6), (2, 1)):

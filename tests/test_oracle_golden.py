@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import decode_oracle                      # oracle/decode_oracle.py (tests/conftest.py puts oracle/ on sys.path)
+
 import spmm_oracle as O
 
 
@@ -128,9 +130,9 @@ def test_oracle_module_api_runs_beam_decode():
     prop = torch.randn(53, generator=torch.Generator().manual_seed(9))
     pe = decode.encode_properties(om, prop.reshape(1, -1))
     assert pe.shape == (1, 54, 128)
-    v, i = decode.next_token_topk(om, pe, torch.full((1, 1), decode.CLS_ID, dtype=torch.long), 4)
+    v, i = decode_oracle.next_token_topk(om, pe, torch.full((1, 1), decode.CLS_ID, dtype=torch.long), 4)
     assert v.shape == (1, 4) and (v[0, :-1] >= v[0, 1:]).all() and i.max() < 300
-    hyps = decode.beam_search(om, prop, k=3, max_steps=8)
+    hyps = decode_oracle.beam_search(om, prop, k=3, max_steps=8)
     assert all(s[0] == decode.CLS_ID and s[-1] == decode.SEP_ID for _, s in hyps)
     assert [p for p, _ in hyps] == sorted([p for p, _ in hyps], reverse=True)
 

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import decode_oracle                      # oracle/decode_oracle.py (tests/conftest.py puts oracle/ on sys.path)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -357,6 +359,49 @@ def test_checkpoint_resume_continues_the_run(env, tmp_path):
     assert set(ck["state_dict"].keys()) == set(a.state_dict().keys())   # the reference's consumers still find their layout
 
 
+def test_trainer_runs_the_reference_schedule_and_resumes(env, golden_dir, tmp_path):
+    """The driver's pieces on the tiny config, batch 4.  (a) `training_step` -- the hook a trainer calls -- replays the first
+    three steps of the REAL reference's recorded run (tests/golden/train_tiny_b4_l16.npz: losses, lr cadence of
+    SPMM_models.py:372-378, queue pointer).  (b) spmm_amd.trainer.Trainer (what pretrain.py builds) runs 64 steps on synthetic
+    batches with finite losses, writes Lightning-layout checkpoints and resumes from one."""
+    O = env[0]
+    from spmm_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, "train_tiny_b4_l16.npz"))
+    B, Lt, seed = int(g["B"]), int(g["Lt"]), int(g["seed"])
+    m = _tiny_train_model(env, dropout=False)
+    m.loader_len = int(g["loader_len"])
+    for s, (epoch, bidx) in enumerate(g["plan"][:3]):
+        prop, ids, mask = O.synthetic_batch(B, Lt, seed=seed + s)
+        m.current_epoch = int(epoch)
+        draws = dict(mpm_mask=torch.from_numpy(g["mpm_mask"][s]).cuda(),
+                     neg_idx=tuple(_cuda(torch.from_numpy(g["prop_neg_idx"][s]), torch.from_numpy(g["text_neg_idx"][s]))))
+        out = m.training_step((prop.cuda(), (ids.cuda(), mask.cuda()), draws), int(bidx))
+        np.testing.assert_allclose(out.cpu().numpy(), g["losses"][s], rtol=0, atol=[2e-2, 6e-2, 0.15][s])
+        assert abs(m.optimizers().param_groups[0]["lr"] - g["lr_next"][s]) < 1e-12
+        assert int(m.queue_ptr) == int(g["ptr"][s])
+
+    class Loader:
+        def __len__(self):
+            return 64
+
+        def __iter__(self):
+            for s in range(64):
+                prop, ids, mask = O.synthetic_batch(B, Lt, seed=1000 + s)
+                yield prop.cuda(), (ids.cuda(), mask.cuda())
+
+    m = _tiny_train_model(env, dropout=True)
+    tr = Trainer(max_epochs=1, output_dir=str(tmp_path), every_n_train_steps=32, log_every_n_steps=8, quiet=True)
+    tr.fit(m, Loader())
+    assert tr.global_step == 64 and len(tr.history) == 8
+    assert all(np.isfinite(h[2]).all() for h in tr.history) and tr.history[-1][3] > 0
+    ck = torch.load(tmp_path / "checkpoint_epoch=0.ckpt", map_location="cpu")
+    assert ck["global_step"] == 64 and ck["optimizer_states"][0]["step_count"] == 64 and len(ck["state_dict"]) == len(m.state_dict())
+    m2 = _tiny_train_model(env, dropout=True)
+    tr2 = Trainer(max_epochs=2, output_dir=str(tmp_path / "r"), every_n_train_steps=0, log_every_n_steps=64, max_steps=66, quiet=True)
+    tr2.fit(m2, Loader(), ckpt_path=str(tmp_path / "checkpoint_epoch=0.ckpt"))      # epoch 0 is complete: continues with epoch 1
+    assert tr2.global_step == 66 and int(m2.optimizers().step_count) == 66 and m2.current_epoch == 1
+
+
 def test_on_device_negative_sampling_and_bernoulli(env):
     O, SPMM, tiny_config, *_ = env
     sd = O.closed_form_state_dict(O.tiny_cfg())
@@ -414,12 +459,12 @@ def test_beam_decode_matches_oracle_teacher_forced(env):
     pe_h = decode.encode_properties(m, prop.reshape(1, -1))
     assert (pe_h.cpu() - pe_o).abs().max().item() < 6e-2
     text = torch.full((1, 1), decode.CLS_ID, dtype=torch.long)
-    vo, io = decode.next_token_topk(om, pe_o, text, k)
+    vo, io = decode_oracle.next_token_topk(om, pe_o, text, k)
     text = torch.cat([torch.full((k, 1), decode.CLS_ID, dtype=torch.long), io.squeeze(0).unsqueeze(-1)], dim=-1)
     cur = vo.squeeze(0)
     for step in range(6):
-        vo, io = decode.next_token_topk(om, pe_o, text, k)
-        vh, ih = decode.next_token_topk(m, pe_h, text.cuda(), k)
+        vo, io = decode_oracle.next_token_topk(om, pe_o, text, k)
+        vh, ih = decode_oracle.next_token_topk(m, pe_h, text.cuda(), k)
         assert (vh.cpu() - vo).abs().max().item() < 3e-2, step
         gap = (vo[:, :-1] - vo[:, 1:]).min(dim=1).values              # margin between consecutive candidates
         for b in range(k):
@@ -429,7 +474,7 @@ def test_beam_decode_matches_oracle_teacher_forced(env):
         cur, flat = torch.topk(k2.flatten(), k)
         text = torch.cat([text.unsqueeze(1).repeat(1, k, 1), io.unsqueeze(-1)], dim=-1)[flat // k, flat % k]
     # and the free-running search returns well-formed hypotheses
-    hyps = decode.beam_search(m, prop, k=k, max_steps=12)
+    hyps = decode_oracle.beam_search(m, prop, k=k, max_steps=12)
     for p, seq in hyps:
         assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and p <= 0.0
 

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spmm_amd.model import SPMM
 from spmm_amd import decode
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import decode_oracle                      # the reference's sequential search: the baseline this tool times the batched decoder against
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--molecules", type=int, default=200)
@@ -35,10 +37,10 @@ out["cached_batched_molecules_per_s"] = round(a.molecules / dt, 2)
 out["cached_batched_ms_per_position"] = round(dt / (a.steps + 1) / ((a.molecules + a.chunk - 1) // a.chunk) * 1e3, 3)
 out["finished_hypotheses"] = nfin
 if a.uncached > 0:
-    decode.beam_search(m, props[0], k=a.k, max_steps=3)
+    decode_oracle.beam_search(m, props[0], k=a.k, max_steps=3)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(a.uncached):
-        decode.beam_search(m, props[i], k=a.k, max_steps=a.steps)
+        decode_oracle.beam_search(m, props[i], k=a.k, max_steps=a.steps)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     out["per_molecule_recompute_molecules_per_s"] = round(a.uncached / dt, 2)
 print(json.dumps(out))
