@@ -66,9 +66,11 @@ int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N,
  * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
  * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
 long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
-int spmm_gemm_tn_splits(int M, int N, int K);
+/* kernel (per call): 0 = chosen from the shape; 1 = 128x128 tiles; 8 = 256x256 tiles on the 8-phase schedule (N, K % 8 == 0).
+ * spmm_gemm_tn_splits returns the split count that fills the chip for that choice (pass the same `kernel` to both). */
+int spmm_gemm_tn_splits(int M, int N, int K, int kernel);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
-                 long ldc, float* workspace, spmm_stream_t stream);
+                 long ldc, float* workspace, int kernel, spmm_stream_t stream);
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.

@@ -206,6 +206,234 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// p8: the weight-gradient GEMM on the 8-phase schedule of gemm.hip's NT kernel (same LDS ring, same phases, same counted
+// waits; cdna_hip_programming.md "The 256^2 8-phase template").  Output tile 256 (n) x 256 (k) per 512-thread workgroup,
+// 8 waves as 2 (n) x 4 (k); the reduction runs over the memory ROW index m in steps of 64 rows.
+//  * A step stages FOUR 16-KiB half-tiles -- columns [0,128) and [128,256) of the A (dY) and of the B (X) row block, i.e. one
+//    whole 256-B piece of every row -- one per phase, by LDS-DMA; the three newest stay in flight across the raw barriers.
+//  * Wave (wr, wc) owns n-columns h*128 + wr*64 + [0,64) and k-columns h*128 + wc*32 + [0,32) of half h = 0, 1: its four
+//    quadrants (hn, hk) are 64 x 32 outputs = 8 accumulators of v_mfma_f32_16x16x32_bf16, 16 MFMA per quadrant per step.
+//  * Fragments come from ds_read_b64_tr_b16 (inline asm): lane i of a 16-lane group addresses 4 contiguous bf16 of row
+//    mb + (i >> 2), columns cb + 4*(i & 3), and receives column cb + i of the four rows -- two reads = the 8 reduction values
+//    of its k-slot.  LDS rows are 256 B; the 16-B chunk index is XOR-ed with ((row & 3) << 2) ^ (((row >> 3) & 1) << 1): the
+//    32 lanes of a service group (rows mb..mb+3 and mb+8..mb+11 of one 16-column block) then touch all 64 banks once.
+//  * Every split covers a multiple of 128 rows (an even number of steps); the launcher gives the < 128 leftover rows of M to the
+//    128x128 kernel (LDS-DMA cannot zero-fill a ragged last step).
+// Output: D[k][n] per MFMA, a lane owns 4 consecutive k of one n -> 16-B fp32 stores into the split's slab (or += C).
+constexpr int TP_HT = 64 * 128 * 2;               // half-tile: 64 rows x 128 columns = 16 KiB
+constexpr int TP_BUF = 4 * TP_HT;                 // one step: A-h0 | A-h1 | B-h0 | B-h1 = 64 KiB
+constexpr int TP_LDS = 2 * TP_BUF;                // 128 KiB
+
+template <int OFF>
+__device__ __forceinline__ void tp_tr(bf16x4& d, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <bool SLAB>
+__global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tp[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
+  const int tile = blockIdx.x;
+  const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
+  const int mbeg = blockIdx.z * p.rsplit;
+  const int mend = min(p.M, mbeg + p.rsplit);
+  const int nk = (mend - mbeg) / 64;                   // steps of 64 rows: even and >= 2 (the launcher hands out multiples of 128 rows)
+  (void)ntn;
+
+  f32x4 acc[2][4][4];                                  // [n half][n block mi][k half * 2 + k block]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- LDS-DMA sources.  DMA instruction i (0/1) of a half-tile: chunk id = i*512 + tid -> row id >> 4 (0..63), physical chunk
+  // id & 15, logical chunk (8 columns) = physical ^ swizzle(row).  32-bit byte offsets from (operand + step * 64 rows); chunks
+  // wholly past the last column re-read the last valid chunk (they feed outputs that are never stored).
+  uint32_t offA[2][2], offB[2][2];                     // [half][instruction]
+  {
+    const int pc = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + (tid >> 4);
+      const int lc = pc ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int ca = n0 + h * 128 + lc * 8, cb = k0 + h * 128 + lc * 8;
+        ca = ca + 8 <= p.N ? ca : ((p.N - 8) & ~7);
+        cb = cb + 8 <= p.K ? cb : ((p.K - 8) & ~7);
+        offA[h][i] = (uint32_t)(mbeg + row) * (uint32_t)(p.lda * 2) + (uint32_t)(ca * 2);
+        offB[h][i] = (uint32_t)(mbeg + row) * (uint32_t)(p.ldb * 2) + (uint32_t)(cb * 2);
+      }
+    }
+  }
+  const char* gA = (const char*)p.A;
+  const char* gB = (const char*)p.B;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem_tp;
+  // LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form (inline asm: the builtin materialises a 64-bit address per load -- 16
+  // VGPRs of loop-invariant pointers here -- and its loads are tracked by the compiler's waitcnt pass, which this schedule
+  // counts by hand anyway).  M0 = wave-uniform LDS destination; one wait state between the M0 write and its use.
+#define TP_STG(GB, O, SLOT)                                                                                               \
+  do {                                                                                                                    \
+    const uint32_t d_ = lds0 + (SLOT) + wave * 1024;                                                                      \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((O)[0]), "s"(GB), "s"(d_) : "memory", "m0");          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((O)[1]), "s"(GB), "s"(d_ + 8192) : "memory", "m0");   \
+  } while (0)
+#define TP_STG_A(H, BUF, KT) TP_STG((const char*)(gA + (size_t)(KT) * 128 * p.lda), offA[H], (BUF) * TP_BUF + (H) * TP_HT)
+#define TP_STG_B(H, BUF, KT) TP_STG((const char*)(gB + (size_t)(KT) * 128 * p.ldb), offB[H], (BUF) * TP_BUF + (2 + (H)) * TP_HT)
+
+  // ---- fragment addresses.  16x16x32 operand: lane l -> column (l & 15) of the block, reduction rows kk*32 + (l >> 4)*8 .. +7,
+  // fetched as two transpose reads of 4 rows.  This lane SUPPLIES the address of row mb + 4*rh + (i >> 2), columns cb + 4*(i & 3).
+  uint32_t aad[2][2];                                  // [kk][row half]: byte address inside an A half-tile for column block 0 of the wave
+  {
+    const int i16 = lane & 15, j = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const int row = kk * 32 + j * 8 + rh * 4 + (i16 >> 2);
+        const int sw = ((row & 3) << 2) ^ (((row >> 3) & 1) << 1);
+        const int ca = wr * 64 + (i16 & 3) * 4;        // column inside the half-tile (block f adds 16)
+        aad[kk][rh] = lds0 + (uint32_t)(row * 256 + (((ca >> 3) ^ sw) << 4) + (ca & 7) * 2);
+      }
+  }
+  // the B address of the same lane differs only in the wave's base chunk (wc*4 instead of wr*8): a wave-uniform XOR
+  const uint32_t bxor = (uint32_t)(((wr * 8) ^ (wc * 4)) << 4);
+  // column block f of the wave's run: +16 columns = chunk index + 2f; the wave's base chunk is a multiple of 4 (B) / 8 (A) and the
+  // swizzle touches bits 1-3, so the block index enters the address as XOR (f << 5), not as an immediate
+  // (`opq` is an always-zero value the compiler cannot see through, refreshed before every group of reads: without it the 48
+  // XOR-ed addresses of both buffers are hoisted out of the loop and spill)
+  uint32_t opq = 0;
+  bf16x4 ta[4][2][2], tb0[2][2][2], tb1[2][2][2];     // [block][kk][row half]
+#define TP_RD_A(BUF, H)                                                                                              \
+  do {                                                                                                               \
+    asm volatile("" : "+v"(opq));                                                                                    \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_) {                                                            \
+      _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                                                               \
+      _Pragma("unroll") for (int rh_ = 0; rh_ < 2; ++rh_)                                                            \
+        tp_tr<(H) * TP_HT>(ta[f_][kk_][rh_], ((aad[kk_][rh_] ^ (uint32_t)(f_ << 5)) ^ opq) + (BUF) * TP_BUF);       \
+      __builtin_amdgcn_sched_barrier(0);           /* at most 8 address temporaries alive at a time */               \
+    }                                                                                                                \
+  } while (0)
+#define TP_RD_B(BUF, H, TB)                                                                                          \
+  do {                                                                                                               \
+    asm volatile("" : "+v"(opq));                                                                                    \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                              \
+    _Pragma("unroll") for (int f_ = 0; f_ < 2; ++f_)                                                                 \
+    _Pragma("unroll") for (int rh_ = 0; rh_ < 2; ++rh_)                                                              \
+      tp_tr<(2 + (H)) * TP_HT>(TB[f_][kk_][rh_], ((aad[kk_][rh_] ^ bxor ^ (uint32_t)(f_ << 5)) ^ opq) + (BUF) * TP_BUF); \
+  } while (0)
+#define TP_MM(H, KH, TB)                                                                                             \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                              \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                              \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                                              \
+      acc[H][mi_][(KH) * 2 + ni_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                        \
+          tn_join(TB[ni_][kk_][0], TB[ni_][kk_][1]), tn_join(ta[mi_][kk_][0], ta[mi_][kk_][1]), acc[H][mi_][(KH) * 2 + ni_], 0, 0, 0); \
+  } while (0)
+#define TP_BAR() __builtin_amdgcn_s_barrier()
+#define TP_SB() __builtin_amdgcn_sched_barrier(0)
+#define TP_COMPUTE(H, KH, TB)                              \
+  do {                                                     \
+    TP_BAR();                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    TP_SB();                                               \
+    __builtin_amdgcn_s_setprio(1);                         \
+    TP_MM(H, KH, TB);                                      \
+    __builtin_amdgcn_s_setprio(0);                         \
+    TP_SB();                                               \
+    TP_BAR();                                              \
+    TP_SB();                                               \
+  } while (0)
+
+  // ---- prologue: step 0 complete, the first three half-tiles of step 1 in flight
+  TP_STG_A(0, 0, 0); TP_STG_B(0, 0, 0); TP_STG_B(1, 0, 0); TP_STG_A(1, 0, 0);
+  TP_STG_B(0, 1, 1); TP_STG_A(0, 1, 1); TP_STG_B(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  TP_BAR();
+  TP_SB();
+  if (wr == 1) TP_BAR();                               // the second wave row runs one barrier behind the first
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    const bool more = kt + 2 < nk;
+    // ---------------- step kt (buffer 0).  Hazards exactly as in gemm_nt_p8_kernel: B-h0 (8 reads, issued first, retired by the
+    // lgkmcnt before the first barrier) is restaged one phase later, everything else two phases after its last read.
+    TP_RD_B(0, 0, tb0); TP_SB(); TP_RD_A(0, 0);                                   // phase 1: 8 + 16 transpose reads
+    TP_STG_A(1, 1, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");                           // 24 issued, <= 15 pending: the 8 B-h0 reads are back
+    TP_COMPUTE(0, 0, tb0);
+    TP_RD_B(0, 1, tb1);                                                           // phase 2
+    if (more) TP_STG_B(0, 0, kt + 2);
+    TP_COMPUTE(0, 1, tb1);
+    TP_RD_A(0, 1);                                                                // phase 3
+    if (more) TP_STG_A(0, 0, kt + 2);
+    TP_COMPUTE(1, 1, tb1);
+    if (more) {                                                                   // phase 4
+      TP_STG_B(1, 0, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TP_COMPUTE(1, 0, tb0);
+    // ---------------- step kt+1 (buffer 1)
+    TP_RD_B(1, 0, tb0); TP_SB(); TP_RD_A(1, 0);                                   // phase 5
+    if (more) TP_STG_A(1, 0, kt + 2);
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    TP_COMPUTE(0, 0, tb0);
+    TP_RD_B(1, 1, tb1);                                                           // phase 6
+    if (more) TP_STG_B(0, 1, kt + 3);
+    TP_COMPUTE(0, 1, tb1);
+    TP_RD_A(1, 1);                                                                // phase 7
+    if (more) TP_STG_A(0, 1, kt + 3);
+    TP_COMPUTE(1, 1, tb1);
+    if (more) {                                                                   // phase 8
+      TP_STG_B(1, 1, kt + 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    TP_COMPUTE(1, 0, tb0);
+  }
+  if (wr == 0) TP_BAR();
+#undef TP_STG
+#undef TP_STG_A
+#undef TP_STG_B
+#undef TP_RD_A
+#undef TP_RD_B
+#undef TP_MM
+#undef TP_COMPUTE
+#undef TP_BAR
+#undef TP_SB
+
+  // ---- epilogue: acc[h][mi][kh*2+ni][j] = D[k][n], n = n0 + h*128 + wr*64 + mi*16 + (lane & 15),
+  //      k = k0 + kh*128 + wc*32 + ni*16 + 4*(lane >> 4) + j
+  float* out = SLAB ? p.slab + (long)blockIdx.z * p.N * p.K : p.C;
+  const long ldo = SLAB ? p.K : p.ldc;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int n = n0 + h * 128 + wr * 64 + mi * 16 + (lane & 15);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + (q >> 1) * 128 + wc * 32 + (q & 1) * 16 + 4 * (lane >> 4);
+        if (k >= p.K) continue;
+        f32x4* dst = (f32x4*)(out + (long)n * ldo + k);
+        f32x4 v = acc[h][mi][q];
+        v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+        if constexpr (!SLAB) {
+          const f32x4 o = *dst;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        *dst = v;
+      }
+    }
+}
+
 // C[n*ldc + k] += sum_z slab[z][n][k]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int N, int K4, float* __restrict__ C,
                                                           long ldc) {
@@ -269,11 +497,28 @@ extern "C" long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits) {
   return splits > 1 ? (long)splits * N * K * 4 : 0;
 }
 
-// target number of workgroups (tiles x splits): ~2 full rounds of the 2 x 256 resident workgroups (measured: 640 -> 1000 =
-// +20..45 % on the training step's shapes)
+// target number of workgroups (tiles x splits) of the 128x128 kernel: ~2 full rounds of the 2 x 256 resident workgroups (measured:
+// 640 -> 1000 = +20..45 % on the training step's shapes)
 constexpr int TN_TARGET_WGS = 1000;
 
-extern "C" int spmm_gemm_tn_splits(int M, int N, int K) {
+// kernel: 0 = chosen from the shape, 1 = 128x128 tiles (two workgroups per CU), 8 = 256x256 tiles on the 8-phase schedule (one
+// workgroup per CU; long reductions, N and K multiples of 8)
+static int tn_pick(int M, int N, int K, int kernel) {
+  if (kernel == 1 || kernel == 8) return kernel;
+  const bool ok8 = N % 8 == 0 && K % 8 == 0 && N >= 256 && K >= 256;
+  const long tiles8 = (long)((N + 255) / 256) * ((K + 255) / 256);
+  // the big tile needs >= ~1000 reduction rows per workgroup to amortise its 256-KiB fp32 tile store and 14-load prologue
+  return (ok8 && M >= 4096 && (long)M * tiles8 >= 256L * 1024) ? 8 : 1;
+}
+
+extern "C" int spmm_gemm_tn_splits(int M, int N, int K, int kernel) {
+  if (tn_pick(M, N, K, kernel) == 8) {
+    const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    int s = 256 / tiles;                              // one workgroup per CU
+    const int maxs = M / 1024 > 0 ? M / 1024 : 1;     // >= 16 steps per split
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : s;
+  }
   const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
   int s = (TN_TARGET_WGS + tiles / 2) / tiles;
   const int maxs = (M / BR) / 16 > 0 ? (M / BR) / 16 : 1;   // at least 16 reduction steps per split
@@ -282,26 +527,64 @@ extern "C" int spmm_gemm_tn_splits(int M, int N, int K) {
 }
 
 extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha,
-                            float* C, long ldc, float* workspace, spmm_stream_t stream) {
+                            float* C, long ldc, float* workspace, int kernel, spmm_stream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(N % 4 == 0 && K % 4 == 0 && ldc % 4 == 0, "spmm_gemm_tn: N=%d K=%d ldc=%ld must be multiples of 4", N, K, ldc);
   SPMM_CHECK_SHAPE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((N + 7) & ~7) && ldb >= ((K + 7) & ~7),
                    "spmm_gemm_tn: lda=%ld / ldb=%ld must be multiples of 8 covering the 8-column chunks of N=%d / K=%d", lda, ldb, N, K);
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "spmm_gemm_tn: A/B must be 16-B aligned");
+  SPMM_CHECK_SHAPE(kernel == 0 || kernel == 1 || kernel == 8, "spmm_gemm_tn: unknown kernel selector %d", kernel);
+  SPMM_CHECK_SHAPE(kernel != 8 || (N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8), "spmm_gemm_tn: the 8-phase kernel needs N %% 8 == 0 and K %% 8 == 0");
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || workspace != nullptr, "spmm_gemm_tn: split reduction needs a workspace");
+  const int k8 = tn_pick(M, N, K, kernel) == 8 && M >= 128;
+  SPMM_CHECK_SHAPE(!k8 || ((unsigned long)M * (unsigned long)lda * 2ul < (1ul << 32) && (unsigned long)M * (unsigned long)ldb * 2ul < (1ul << 32)),
+                   "spmm_gemm_tn: the 8-phase kernel addresses its operands with 32-bit byte offsets (< 4 GiB)");
+  TnP p;
+  p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha;
+  auto reduce = [&](int nsplit) {
+    long blocks = ((long)N * (K / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, nsplit, N, K / 4, C, ldc);
+  };
+  if (k8) {
+    static const hipError_t attr_rc = [] {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS);
+      if (e != hipSuccess) return e;
+      return hipFuncSetAttribute((const void*)gemm_tn_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS);
+    }();
+    if (attr_rc != hipSuccess) {
+      spmm_set_error("spmm_gemm_tn: cannot raise dynamic LDS to %d: %s", TP_LDS, hipGetErrorString(attr_rc));
+      return SPMM_ERR_LAUNCH;
+    }
+    const int M8 = M & ~127;                            // rows the 8-phase kernel takes: whole pairs of 64-row steps
+    int rs = (((M8 / 128) + splits - 1) / splits) * 128;
+    const int ns = (M8 + rs - 1) / rs;
+    p.M = M8; p.rsplit = rs;
+    dim3 grid(((N + 255) / 256) * ((K + 255) / 256), 1, ns);
+    if (ns > 1) {
+      hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
+      reduce(ns);
+    } else {
+      hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, grid, dim3(512), TP_LDS, stream, p);
+    }
+    if (M8 < M) {                                       // the < 128 leftover rows: one pass of the 128x128 kernel, accumulated into C
+      TnP q = p;
+      q.A = (const bf16*)A + (long)M8 * lda; q.B = (const bf16*)B + (long)M8 * ldb; q.M = M - M8; q.rsplit = ((M - M8 + BR - 1) / BR) * BR;
+      hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(((N + BT - 1) / BT) * ((K + BT - 1) / BT), 1, 1), dim3(256), 0, stream, q);
+    }
+    SPMM_LAUNCH_CHECK("spmm_gemm_tn(8-phase)");
+    return SPMM_OK;
+  }
   int rsplit = (((M + BR - 1) / BR + splits - 1) / splits) * BR;
   splits = (M + rsplit - 1) / rsplit;
-  TnP p;
-  p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.rsplit = rsplit;
-  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha;
+  p.rsplit = rsplit;
   const int tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
   dim3 grid(tiles, 1, splits);
   if (splits > 1) {
     hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, stream, p);
-    long blocks = ((long)N * (K / 4) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, splits, N, K / 4, C, ldc);
+    reduce(splits);
   } else {
     hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, stream, p);
   }

@@ -62,15 +62,17 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
     return C
 
 
-def gemm_tn(A, B, C, *, alpha=1.0, splits=None):
-    """C[N,K] (fp32) += alpha * A[M,N]^T @ B[M,K]  -- weight gradients straight from token-major activations."""
+def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0):
+    """C[N,K] (fp32) += alpha * A[M,N]^T @ B[M,K]  -- weight gradients straight from token-major activations.
+    kernel: 0 = chosen from the shape, 1 = 128x128 tiles, 8 = 256x256 8-phase (N, K multiples of 8)."""
     M, N = A.shape
     K = B.shape[1]
     assert A.dtype == BF16 and B.dtype == BF16 and C.dtype == torch.float32 and B.shape[0] == M and tuple(C.shape) == (N, K)
     if splits is None:
-        splits = 1 if _DRY_RUN else lib().cdll.spmm_gemm_tn_splits(M, N, K)
+        splits = 1 if _DRY_RUN else lib().cdll.spmm_gemm_tn_splits(M, N, K, int(kernel))
     ws = torch.empty(splits * N * K, dtype=torch.float32, device=C.device) if splits > 1 else None
-    _call("spmm_gemm_tn", _p(A), _row_stride(A), _p(B), _row_stride(B), M, N, K, splits, float(alpha), _p(C), _row_stride(C), _p(ws), _st())
+    _call("spmm_gemm_tn", _p(A), _row_stride(A), _p(B), _row_stride(B), M, N, K, splits, float(alpha), _p(C), _row_stride(C), _p(ws),
+          int(kernel), _st())
     return C
 
 

@@ -153,18 +153,34 @@ def test_gemm_f32_epilogues_and_splitk(ops):
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (216, 128, 256, 1), (216, 128, 256, 3), (6912, 768, 768, None),
                                           (4096, 2304, 768, None), (1000, 300, 128, 2), (130, 64, 192, 1), (8192, 768, 3072, None),
                                           (2100, 300, 520, 2), (13824, 768, 768, None)])
-def test_gemm_tn_weight_gradient(ops, M, N, K, splits):
+@pytest.mark.parametrize("kernel", [1, 8])      # 128x128 tiles | 256x256 tiles on the 8-phase schedule (+ the 128x128 kernel for M % 128 rows)
+def test_gemm_tn_weight_gradient(ops, M, N, K, splits, kernel):
+    if kernel == 8 and (N % 8 or K % 8):
+        pytest.skip("the 8-phase weight-gradient kernel reads whole 16-B chunks: N, K % 8 == 0")
     lda = (N + 7) // 8 * 8 + 16
     Abig = rnd(M, lda, seed=14)
     A = Abig[:, :N]                            # strided dY (e.g. dlogits[:, :V] inside a padded buffer)
     B = rnd(M, K, scale=0.5, seed=15)
     C = torch.full((N, K), 3.0, device="cuda")
-    ops.gemm_tn(A, B, C, alpha=0.5, splits=splits)
+    ops.gemm_tn(A, B, C, alpha=0.5, splits=splits, kernel=kernel)
     ref = 3.0 + 0.5 * (A.float().t() @ B.float())
-    close(C, ref, 2e-3 * math.sqrt(M), 1e-4, "gemm_tn")
+    close(C, ref, 2e-3 * math.sqrt(M), 1e-4, f"gemm_tn kernel {kernel}")
     cs = torch.ones(N, device="cuda")
     ops.colsum_bf16(A, cs) if N % 4 == 0 else None
     close(cs, 1.0 + A.float().sum(0), 1e-3 * math.sqrt(M), 1e-5, "colsum")
+
+
+def test_gemm_tn_default_choice_matches_both_kernels(ops):
+    """The shape-based choice (the training step's path) against both forced kernels at a step-like shape with a ragged row count."""
+    M, N, K = 33000, 768, 3072
+    A, B = rnd(M, N, seed=16), rnd(M, K, scale=0.5, seed=17)
+    out = []
+    for kernel in (0, 1, 8):
+        C = torch.zeros(N, K, device="cuda")
+        ops.gemm_tn(A, B, C, kernel=kernel)
+        out.append(C)
+    close(out[0], out[1], 2e-3 * math.sqrt(M), 1e-4, "default vs 128x128")
+    close(out[2], out[1], 2e-3 * math.sqrt(M), 1e-4, "8-phase vs 128x128")
 
 
 def test_gemm_rejects_bad_shapes(ops):

@@ -22,6 +22,29 @@ def env():
     return O, SPMM, tiny_config, SPMMConfig, BertConfig
 
 
+# Per-loss absolute bounds |hip - reference| in the order (loss_mlm, 5*loss_mpm, loss_ita, loss_itm).  north_star asks for 1e-3:
+# that is asserted wherever the bf16 pipeline meets it; elsewhere the bound is 1.5x the deviation measured on MI355X (DESIGN.md
+# section 5 has the table and the reason: activations are stored in bf16, 8 mantissa bits, so a hidden state of magnitude 2-4
+# carries 4e-3 .. 1.6e-2 of rounding per store whatever the accumulation precision).
+LOSS_ATOL = {
+    "tiny_golden":   [1e-3, 2.6e-3, 1.5e-3, 1.5e-3],    # measured 1.7e-4 / 1.7e-3 / 9.4e-4 / 9.7e-4  (vs the REAL reference)
+    "tiny_golden_2": [1e-3, 5.4e-3, 4.2e-3, 1.5e-3],    # the second forward, from the state the first one left (queue, EMA): 1.7e-4 / 3.6e-3 / 2.8e-3 / 6.9e-4
+    "h768_2layer":   [1e-3, 1.7e-2, 1.4e-3, 1.7e-3],    # measured 2.1e-4 / 1.1e-2 / 9.2e-4 / 1.1e-3
+    "full_depth_b8": [1e-3, 4.9e-3, 6.2e-3, 3.8e-3],    # measured 6.4e-5 / 3.2e-3 / 4.1e-3 / 2.5e-3
+    "bench_shape":   [1e-3, 1.4e-2, 5.5e-3, 2e-3],      # measured 6.4e-4 / 9.2e-3 / 3.6e-3 / 1.3e-3  (B=32, Lt=128, Q=36864, 12+6 layers)
+    "edge_shapes":   [1e-3, 3e-3, 3.1e-3, 2.3e-3],      # worst over the five cases: 4.4e-4 / 1.9e-3 / 2.1e-3 / 1.5e-3
+    "lt160":         [1e-3, 1.3e-3, 4.4e-3, 1e-3],      # measured 2.0e-4 / 8.6e-4 / 2.9e-3 / 1.2e-4
+    "wide_golden":   [1e-3, 4.4e-3, 2e-2, 7.7e-3],      # measured 5.4e-4 / 2.9e-3 / 1.33e-2 / 5.1e-3 (closed-form weights ~0.08: sims up to 40)
+    "grad_tiny":     [1e-3, 2.9e-3, 1.3e-3, 1e-3],      # measured 2.5e-4 / 1.9e-3 / 8.2e-4 / 4.0e-4
+}
+
+
+def assert_losses(got, ref, key, what=""):
+    got, ref, tol = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64), np.asarray(LOSS_ATOL[key])
+    d = np.abs(got - ref)
+    assert (d <= tol).all(), f"{what or key}: |hip - reference| = {d} exceeds {tol} (hip {got}, reference {ref})"
+
+
 def _mk(SPMM, cfg, sd, train_cfg=None):
     m = SPMM(config=train_cfg, spmm_config=cfg)
     m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
@@ -45,8 +68,7 @@ def test_forward_matches_reference_golden(env, golden_dir):
                        neg_idx=tuple(_cuda(torch.from_numpy(g["prop_neg_idx"]), torch.from_numpy(g["text_neg_idx"]))), aux=aux)
         got = np.array([float(x) for x in losses])
         print(name, "hip", got, "reference", g["losses"], "diff", np.abs(got - g["losses"]))
-        # bf16 path vs fp32 reference: stated tolerance 2e-2 absolute on each loss at this toy scale (weights ~0.08)
-        np.testing.assert_allclose(got, g["losses"], rtol=0, atol=2e-2)
+        assert_losses(got, g["losses"], "tiny_golden", name)
         # state mutations: queue block, pointer, EMA'd momentum weights, clamped temp
         sdo = m.state_dict()
         np.testing.assert_allclose(sdo["prop_queue"].cpu().numpy(), g["prop_queue"], atol=2e-2)
@@ -61,7 +83,7 @@ def test_forward_matches_reference_golden(env, golden_dir):
         with torch.no_grad():
             l2 = m(prop2, ids2, mask2, alpha=0.0, mpm_mask=torch.from_numpy(g["mpm_mask2"]).cuda(),
                    neg_idx=tuple(_cuda(torch.from_numpy(g["prop_neg_idx2"]), torch.from_numpy(g["text_neg_idx2"]))))
-        np.testing.assert_allclose([float(x) for x in l2], g["losses2"], rtol=0, atol=2e-2)
+        assert_losses([float(x) for x in l2], g["losses2"], "tiny_golden_2", name + " second forward")
         assert int(m.queue_ptr) == int(g["queue_ptr2"][0])
 
 
@@ -131,8 +153,7 @@ def test_forward_matches_oracle_h768(env):
         ref = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, aux=oaux)
     got, ref = np.array([float(x) for x in losses]), np.array([float(x) for x in ref])
     print("hip", got, "oracle", ref, "diff", np.abs(got - ref))
-    loss_tol = 2e-2
-    np.testing.assert_allclose(got, ref, rtol=0, atol=loss_tol)        # losses (bf16 pipeline), tightened below per loss
+    assert_losses(got, ref, "h768_2layer")
     Lp = 54
     for key, shape, tol in (("prop_embeds", (B, Lp, 768), 6e-2), ("text_embeds", (B, Lt, 768), 6e-2),
                             ("prop_feat", (B, 256), 4e-3), ("text_feat", (B, 256), 4e-3), ("prop_feat_m", (B, 256), 4e-3),
@@ -165,9 +186,32 @@ def test_full_depth_forward_matches_oracle(env):
     for key in ("prop_embeds", "text_embeds", "prop_feat", "text_feat", "sim_i2t", "vl_output", "mlm_output", "pred"):
         a = aux[key].float().cpu().reshape(oaux[key].shape)
         print(f"  {key}: max|diff| {(a - oaux[key]).abs().max().item():.4g} (ref max {oaux[key].abs().max().item():.3g})")
-    # stated tolerance for the bf16 path at full depth: 5e-3 relative on every loss (fp32 accumulation everywhere,
-    # bf16 storage of activations through 18 encoder layers); the loss values are O(1..10)
-    np.testing.assert_allclose(got, ref, rtol=5e-3, atol=0)
+    assert_losses(got, ref, "full_depth_b8")
+
+
+def test_benchmark_shape_forward_matches_oracle(env):
+    """BASELINE configs[1]'s real shape -- 12+6 layers, H=768, Lt=128, queue 36 864 (the 36 992-wide softmax at temperature
+    0.07 that nothing smaller exercises) -- at B=32, forward only, recorded draws, dropout off, vs the fp32 CPU oracle."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env, layers=(12, 6, 6), Q=36864)
+    sd = O.init_state_dict(ocfg, seed=13)
+    m = _mk(SPMM, cfg, sd).eval()
+    B, Lt = 32, 128
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=42)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(6))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(7))
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    aux, oaux = {}, {}
+    with torch.no_grad():
+        losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)), aux=aux)
+        ref = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, aux=oaux)
+    got, ref = np.array([float(x) for x in losses]), np.array([float(x) for x in ref])
+    print("benchmark shape: hip", got, "oracle", ref, "diff", np.abs(got - ref), "rel", np.abs(got - ref) / np.abs(ref))
+    for key in ("prop_feat", "text_feat", "sim_i2t", "sim_t2i", "vl_output", "mlm_output", "pred"):
+        a = aux[key].float().cpu().reshape(oaux[key].shape)
+        print(f"  {key}: max|diff| {(a - oaux[key]).abs().max().item():.4g} (ref max {oaux[key].abs().max().item():.3g})")
+    assert_losses(got, ref, "bench_shape")
+    assert int(m.queue_ptr) == B
 
 
 def test_gradients_match_oracle(env):
@@ -194,6 +238,7 @@ def test_gradients_match_oracle(env):
     ref_losses = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.3, mpm_mask=mpm, neg_idx=neg, train=True)
     sum(ref_losses).backward()
     print("losses hip", [float(x) for x in losses], "oracle", [float(x) for x in ref_losses])
+    assert_losses([float(x) for x in losses], [float(x) for x in ref_losses], "grad_tiny")
     total_r = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
     worst, err2 = [], 0.0
     for n in names:
@@ -710,7 +755,7 @@ def test_edge_shapes_match_oracle(env, case):
         ref = np.array([float(x) for x in O.spmm_forward(sd, ocfg, prop, ids, mask, 0.25, mpm_mask=mpm, neg_idx=neg, train=True)])
     print(case, "hip", got, "oracle", ref)
     assert np.isfinite(got).all() and torch.isfinite(m.store.grad).all()
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
+    assert_losses(got, ref, "edge_shapes", case)
 
 
 def test_long_sequences_forward_backward_match_oracle(env):
@@ -739,8 +784,8 @@ def test_long_sequences_forward_backward_match_oracle(env):
     gn_ref = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
     gn = m.store.grad.double().norm().item()
     print("Lt=160 hip", got, "oracle", ref, "grad norm", gn, gn_ref)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
-    assert abs(gn - gn_ref) / gn_ref < 2e-2
+    assert_losses(got, ref, "lt160")
+    assert abs(gn - gn_ref) / gn_ref < 2e-3                 # measured 4e-4
 
 
 def test_wide_model_matches_reference_golden(env, golden_dir):
@@ -765,7 +810,7 @@ def test_wide_model_matches_reference_golden(env, golden_dir):
     got = np.array([float(x) for x in losses])
     gn = m.store.grad.double().norm().item()
     print("wide: hip", got, "reference", g["losses"], "grad norm", gn, float(g["grad_norm"]))
-    np.testing.assert_allclose(got, g["losses"], rtol=0, atol=2e-2)
+    assert_losses(got, g["losses"], "wide_golden")
     np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=1e-2)
     for k in g.files:
         if k.startswith("gradsum::"):

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <array>
 #include <algorithm>
 #include "../include/spmm_hip.h"
 
@@ -163,8 +164,79 @@ static int cmd_time(int M, int N, int K, int epi, int rounds) {
   return 0;
 }
 
+
+// ---- TN (weight-gradient) GEMM: C[N,K] += A[M,N]^T B[M,K]
+static int tn_run(int kernel, const Buf& A, const Buf& B, int M, int N, int K, Buf& C, Buf& ws, int* splits_out = nullptr) {
+  const int splits = spmm_gemm_tn_splits(M, N, K, kernel);
+  if (splits_out) *splits_out = splits;
+  if ((size_t)spmm_gemm_tn_workspace_bytes(M, N, K, splits) > ws.bytes) { printf("workspace too small\n"); return 1; }
+  return spmm_gemm_tn(A.d, N, B.d, K, M, N, K, splits, 1.0f, (float*)C.d, K, (float*)ws.d, kernel, 0);
+}
+static int cmd_tncheck() {
+  int fails = 0;
+  const int shapes[][3] = {{4096, 768, 768}, {5000, 768, 3072}, {8320, 2304, 768}, {4224, 520, 264}, {16500, 3072, 768}, {300, 256, 256}};
+  for (auto& sh : shapes) {
+    const int M = sh[0], N = sh[1], K = sh[2];
+    auto hA = rand_bf16((size_t)M * N, 1.0f), hB = rand_bf16((size_t)M * K, 1.0f);
+    Buf A, B, C1, C8, ws; A.alloc(hA.size() * 2); B.alloc(hB.size() * 2); C1.alloc((size_t)N * K * 4); C8.alloc((size_t)N * K * 4); ws.alloc((size_t)64 * N * K * 4);
+    CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(B.d, hB.data(), B.bytes, hipMemcpyHostToDevice));
+    std::vector<float> init((size_t)N * K);
+    for (auto& x : init) x = urand();
+    CK(hipMemcpy(C1.d, init.data(), C1.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(C8.d, init.data(), C8.bytes, hipMemcpyHostToDevice));
+    int s1 = 0, s8 = 0;
+    int rc = tn_run(1, A, B, M, N, K, C1, ws, &s1); CK(hipDeviceSynchronize());
+    rc |= tn_run(8, A, B, M, N, K, C8, ws, &s8); CK(hipDeviceSynchronize());
+    if (rc) { printf("  tn %dx%dx%d rc=%d %s\n", M, N, K, rc, spmm_last_error()); ++fails; continue; }
+    std::vector<float> h1((size_t)N * K), h8((size_t)N * K);
+    CK(hipMemcpy(h1.data(), C1.d, C1.bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(h8.data(), C8.d, C8.bytes, hipMemcpyDeviceToHost));
+    double maxd = 0, maxref = 0; long bad = 0;
+    for (size_t i = 0; i < h1.size(); ++i) { const double d = fabs((double)h1[i] - h8[i]); if (d > maxd) maxd = d; if (d > 2e-3 * sqrt((double)M) + 1e-4 * fabs(h1[i])) ++bad; }
+    for (int t = 0; t < 400; ++t) {                     // fp64 reference on sampled outputs (incl. the last row / column)
+      const int n = t < 8 ? N - 1 - t : (int)(fabsf(urand()) * (N - 1)), k = t < 8 ? K - 1 - 7 * t % K : (int)(fabsf(urand()) * (K - 1));
+      double acc = init[(size_t)n * K + k];
+      for (int m = 0; m < M; ++m) acc += (double)bf2f(hA[(size_t)m * N + n]) * (double)bf2f(hB[(size_t)m * K + k]);
+      const double d = fabs(acc - h8[(size_t)n * K + k]);
+      if (d > maxref) maxref = d;
+      if (d > 2e-3 * sqrt((double)M) + 1e-4 * fabs(acc)) ++bad;
+    }
+    printf("  tn %6d x %5d x %5d: splits k1 %d k8 %d  max|k8 - k1| %.3g  max|k8 - fp64| %.3g  %s\n", M, N, K, s1, s8, maxd, maxref, bad ? "FAIL" : "ok");
+    fails += bad != 0;
+  }
+  printf("%s\n", fails ? "TN CHECK FAILED" : "TN CHECK OK");
+  return fails ? 1 : 0;
+}
+static int cmd_tntime(int M, int N, int K, int rounds) {
+  auto hA = rand_bf16((size_t)M * N, 1.0f), hB = rand_bf16((size_t)M * K, 1.0f);
+  Buf A, B, C, ws; A.alloc(hA.size() * 2); B.alloc(hB.size() * 2); C.alloc((size_t)N * K * 4); ws.alloc((size_t)64 * N * K * 4);
+  CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(B.d, hB.data(), B.bytes, hipMemcpyHostToDevice));
+  CK(hipMemset(C.d, 0, C.bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int kernels[] = {1, 8};
+  std::vector<float> med[2];
+  for (int r = 0; r < rounds; ++r)
+    for (int ki = 0; ki < 2; ++ki) {
+      for (int w = 0; w < 2; ++w) tn_run(kernels[ki], A, B, M, N, K, C, ws);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 10; ++i) if (tn_run(kernels[ki], A, B, M, N, K, C, ws)) { printf("%s\n", spmm_last_error()); return 1; }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); med[ki].push_back(ms / 10);
+    }
+  printf("tn %6d : %5d x %5d :", M, N, K);
+  for (int ki = 0; ki < 2; ++ki) { std::sort(med[ki].begin(), med[ki].end()); const float m = med[ki][med[ki].size() / 2]; printf("  k%d %8.1f us %7.1f TF", kernels[ki], m * 1e3, 2.0 * M * N * K / (m * 1e-3) / 1e12); }
+  printf("\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "check")) return cmd_check();
+  if (argc >= 2 && !strcmp(argv[1], "tncheck")) return cmd_tncheck();
+  if (argc >= 5 && !strcmp(argv[1], "tntime")) return cmd_tntime(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 5);
+  if (argc >= 2 && !strcmp(argv[1], "tnstep")) {
+    int rc = 0;
+    for (auto& sh : std::vector<std::array<int, 3>>{{84256, 3072, 768}, {84256, 768, 768}, {84256, 768, 3072}, {84256, 2304, 768}, {28304, 768, 3072}, {13824, 3072, 768}, {13824, 768, 768}})
+      rc |= cmd_tntime(sh[0], sh[1], sh[2], 5);
+    return rc;
+  }
   if (argc >= 5 && !strcmp(argv[1], "time"))
     return cmd_time(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 5);
   if (argc >= 2 && !strcmp(argv[1], "step")) {   // the training step's dominant shapes (B=128, Lt=128: ~84k fusion tokens)
