@@ -816,14 +816,18 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   } while (0)
   const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem8;
+  // LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form (inline asm: the builtin materialises a 64-bit VGPR address per load --
+  // 16 VGPRs of loop-invariant pointers plus three VALU per load -- and this schedule counts its DMA by hand anyway).
+  // M0 = wave-uniform LDS destination; one wait state between the M0 write and its use.
 #define P8_STG(GB, O, SLOT)                                                                                               \
   do {                                                                                                                    \
-    char* d_ = smem8 + (SLOT) + wave * 1024;                                                                              \
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((GB) + (O)[0]), (LDS_AS void*)d_, 16, 0, 0);                 \
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((GB) + (O)[1]), (LDS_AS void*)(d_ + 8192), 16, 0, 0);        \
+    const uint32_t d_ = lds0 + (SLOT) + wave * 1024;                                                                      \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((O)[0]), "s"(GB), "s"(d_) : "memory", "m0");          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((O)[1]), "s"(GB), "s"(d_ + 8192) : "memory", "m0");   \
   } while (0)
-#define P8_STG_A(H, BUF, KT) P8_STG(gA + (size_t)(KT) * (BK * 2), offA[H], (BUF) * P8_BUF + (H) * P8_HT)
-#define P8_STG_W(H, BUF, KT) P8_STG(gW + (size_t)(KT) * (BK * 2), offW[H], (BUF) * P8_BUF + (2 + (H)) * P8_HT)
+#define P8_STG_A(H, BUF, KT) P8_STG((const char*)(gA + (size_t)(KT) * (BK * 2)), offA[H], (BUF) * P8_BUF + (H) * P8_HT)
+#define P8_STG_W(H, BUF, KT) P8_STG((const char*)(gW + (size_t)(KT) * (BK * 2)), offW[H], (BUF) * P8_BUF + (2 + (H)) * P8_HT)
   // K-tile 0 complete + the first three half-tiles of K-tile 1: what the main loop expects to find in flight
 #define P8_PROLOGUE()                                                                        \
   do {                                                                                       \
@@ -832,7 +836,6 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   } while (0)
 
   // ---- fragment read addresses (16x16x32 operand: lane -> row lane & 15, k-slot kk*4 + (lane >> 4))
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem8;
   uint32_t aad[2][2], wad[2][2];                     // [buffer][kk]
   {
     const uint32_t sw = (uint32_t)((lane >> 1) & 7), r16 = (uint32_t)(lane & 15), q = (uint32_t)(lane >> 4);
