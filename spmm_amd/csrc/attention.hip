@@ -108,6 +108,29 @@ __device__ __forceinline__ void ld_tr2(const char* tile, int rb, int lane, bf16x
   out[1] = join8(r2, r3);
   __builtin_amdgcn_sched_barrier(0);
 }
+// the same for TWO 16-row k-blocks (rb, rb + 16) with a single wait: eight transpose reads in flight instead of four
+__device__ __forceinline__ void ld_tr2x2(const char* tile, int rb, int lane, bf16x8 (&o0)[2], bf16x8 (&o1)[2]) {
+  const int i16 = lane & 15, j = lane >> 4;
+  const int row0 = rb + 4 * (j >> 1) + (i16 >> 2);
+  const int col = (j & 1) * 16 + (i16 & 3) * 4;
+  unsigned a[8];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    a[b * 4 + 0] = (unsigned)(size_t)(tile + swz(row0 + 16 * b, col >> 3) + (col & 7) * 2);
+    a[b * 4 + 1] = (unsigned)(size_t)(tile + swz(row0 + 16 * b + 8, col >> 3) + (col & 7) * 2);
+    a[b * 4 + 2] = (unsigned)(size_t)(tile + swz(row0 + 16 * b, (col + 32) >> 3) + (col & 7) * 2);
+    a[b * 4 + 3] = (unsigned)(size_t)(tile + swz(row0 + 16 * b + 8, (col + 32) >> 3) + (col & 7) * 2);
+  }
+  bf16x4 r[8];
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+               "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+  o0[0] = join8(r[0], r[1]); o0[1] = join8(r[2], r[3]);
+  o1[0] = join8(r[4], r[5]); o1[1] = join8(r[6], r[7]);
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int hf) {
   bf16x8 r;
 #pragma unroll
@@ -128,9 +151,11 @@ constexpr int FWD_LDS = 2 * TILE + 128 * 4;
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // only the NT 32-row tiles in use are allocated (a 54-key head holds 16 KiB + the mask vector, not 33 KiB: the two-wave
+  // workgroups of the PV-query calls were held to 4 per CU by LDS alone)
   char* Ks = smem;
-  char* Vs = smem + TILE;
-  float* mb = (float*)(smem + 2 * TILE);   // mask value per kv (1/0), -1 = padding
+  char* Vs = smem + NT * 32 * ROWB;
+  float* mb = (float*)(smem + 2 * NT * 32 * ROWB);   // mask value per kv (1/0), -1 = padding
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
@@ -142,8 +167,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
   stage_head(Kg, p.ldk, Lkv, Ks, tid, nthreads, NT * 32);
   stage_head(Vg, p.ldv, Lkv, Vs, tid, nthreads, NT * 32);
+  // additive score bias per key: 0 (attend), mask_neg (masked: (1 - m) * -10000 resp. finfo.min), -inf (tile padding past Lkv)
   for (int j = tid; j < 128; j += nthreads)
-    mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
+    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : p.mask_neg) : -INFINITY;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
   const int q = wave * 32 + (lane & 31);
   const int qc = q < Lq ? q : Lq - 1;
@@ -160,16 +186,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
   }
+  // registers 4*gq .. 4*gq+3 of tile t hold the 4 consecutive keys t*32 + 8*gq + 4*g + {0..3}: one 16-B read of the bias vector
   float mx = -INFINITY;
+  const int qpos = q + p.q_off - p.kv_off;          // causal: key kv is visible iff kv <= qpos
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      const float mv = mb[kv];
-      const float s = mv < 0.f ? -INFINITY : st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
-      st[t][r] = s;
-      mx = fmaxf(mx, s);
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kv0 = t * 32 + 8 * gq + 4 * g;
+      f32x4 b = *(const f32x4*)(mb + kv0);
+      if (causal) {                                 // workgroup-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], p.mask_neg) : b[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = st[t][gq * 4 + j] * 0.125f + b[j];
+        st[t][gq * 4 + j] = sc;
+        mx = fmaxf(mx, sc);
+      }
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
@@ -201,15 +236,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
   f32x16 ot[2] = {zero16(), zero16()};
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const bf16x8 pf = pack8(st[t], hf);
-      bf16x8 vf[2];
-      ld_tr2(Vs, t * 32 + hf * 16, lane, vf);
-      ot[0] = MFMA32(vf[0], pf, ot[0]);
-      ot[1] = MFMA32(vf[1], pf, ot[1]);
-    }
+  for (int t = 0; t < NT; ++t) {
+    const bf16x8 pf0 = pack8(st[t], 0), pf1 = pack8(st[t], 1);
+    bf16x8 vf0[2], vf1[2];
+    ld_tr2x2(Vs, t * 32, lane, vf0, vf1);
+    ot[0] = MFMA32(vf0[0], pf0, ot[0]);
+    ot[1] = MFMA32(vf0[1], pf0, ot[1]);
+    ot[0] = MFMA32(vf1[0], pf1, ot[0]);
+    ot[1] = MFMA32(vf1[1], pf1, ot[1]);
+  }
   if (q < Lq) {
     bf16* Og = p.O + (qrow + q) * p.ldo + h * HD;
 #pragma unroll
@@ -224,22 +259,54 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward
-constexpr int BWD_LDS = 4 * TILE + 4 * 128 * 4;
+// LDS: region X | Q | dO | small vectors.  X holds K and V during phase A, then the probabilities P~ (dropout applied) and
+// then dS, as [q][kv] bf16 tiles with 256-B rows: the transposed layout phase B needs is produced by ONE pass over the
+// scores (phase A) instead of recomputing S and dP per key tile.
+__host__ __device__ constexpr int bwd_xbytes(int nt_kv, int nt_q) {
+  return 2 * nt_kv * 32 * 128 > nt_q * 32 * 256 ? 2 * nt_kv * 32 * 128 : nt_q * 32 * 256;
+}
+constexpr int BWD_LDS = bwd_xbytes(4, 4) + 2 * TILE + 3 * 128 * 4;
+
+// [q][kv] bf16 tile, 256-B rows, 8-B slots (4 consecutive kv).  Slot index XOR ((q & 3) << 3 | ((q >> 2) & 3) << 1):
+//  * the 16 lanes of a write group (16 consecutive q, one slot) land on 16 distinct slots;
+//  * the 4 rows x 8 slots of a 32-lane transpose-read group land on 4 distinct 64-B spans.
+__device__ __forceinline__ int xoff(int q, int slot) { return q * 256 + ((slot ^ (((q & 3) << 3) | (((q >> 2) & 3) << 1))) << 3); }
+
+// B-operand fragment of the [q][kv] tile for MFMA 32x32x16: lane (kv = cb + (lane & 31), g = lane >> 5) receives
+// X[rb + 4g + {0..3, 8..11}][kv] -- the k-slot order of ld_tr2's A operands.
+__device__ __forceinline__ bf16x8 ld_xt(const char* X, int rb, int cb, int lane) {
+  const int i16 = lane & 15, j = lane >> 4;
+  const int row0 = rb + 4 * (j >> 1) + (i16 >> 2);
+  const int slot = (cb + (j & 1) * 16 + (i16 & 3) * 4) >> 2;
+  const unsigned a0 = (unsigned)(size_t)(X + xoff(row0, slot));
+  const unsigned a1 = (unsigned)(size_t)(X + xoff(row0 + 8, slot));
+  bf16x4 r0, r1;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return join8(r0, r1);
+}
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float up_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float up_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: ceil(max Lq / 32) tiles): a 54 x 54 head takes 34 KiB
-  // instead of 66, and with the 160-VGPR budget of the NT <= 2 instances three workgroups share a CU instead of two.
-  const int kvb = NT * 32 * 128, qb = ((p.Lq + 31) >> 5) * 32 * 128;
-  char* Ks = smem;
-  char* Vs = smem + kvb;
-  char* Qs = smem + 2 * kvb;
+  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: ceil(max Lq / 32) tiles)
+  const int ntq_max = (p.Lq + 31) >> 5;
+  const int kvb = NT * 32 * 128, qb = ntq_max * 32 * 128, xb = bwd_xbytes(NT, ntq_max);
+  char* X = smem;
+  char* Ks = X;
+  char* Vs = X + kvb;
+  char* Qs = X + xb;
   char* dOs = Qs + qb;
   float* mb = (float*)(dOs + qb);
   float* lse = mb + 128;
-  float* Dq = lse + 128;
-  uint32_t* rk = (uint32_t*)(Dq + 128);      // dropout row keys of the 128 query rows
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
@@ -260,7 +327,6 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
     const int j = tid;
     mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
     lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] : 0.f;
-    Dq[j] = 0.f;
   }
   __syncthreads();
 
@@ -268,14 +334,15 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   const bool drop = p.drop_thresh16 != 0;
   const uint64_t seed = drop ? seed_mix(p.seed_ptr, p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
-  if (drop && tid < 128) rk[tid] = drop_rowkey(seed, headbase + tid);
   const int NTq = (Lq + 31) >> 5;
 
-  // ---- phase A: wave owns query tile `wave` -> D[q] = sum_kv P dP (fp32, exactly consistent with ds) and dQ.
+  // ---- phase A: wave owns query tile `wave`: ONE pass over the scores gives D[q] = sum_kv P dP (fp32, exactly consistent with
+  // ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and dS = P (dP - D).
   // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
   // ds = P (dP - D) is a small difference of large numbers that such a D would swamp.
+  uint32_t ppk[NT][8], dpk[NT][8];                   // packed bf16 pairs: registers (2i, 2i+1) of tile t
+  const int q = wave * 32 + (lane & 31);
   if (wave < NTq) {
-    const int q = wave * 32 + (lane & 31);
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -284,45 +351,49 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
     }
     const float lq = lse[q];
     const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) : 0u;
-    f32x16 st[NT], dp[NT];
+    f32x16 dp[NT];
+    uint32_t keepbits[NT];
     float dloc = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      st[t] = zero16();
+      f32x16 st = zero16();
       dp[t] = zero16();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
+        st = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st);
         dp[t] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[t]);
       }
-      uint32_t keepbits = 0xffffu;                     // bit r: probability (q, kv(r)) survived dropout in forward
+      uint32_t kb = 0xffffu;                           // bit r: probability (q, kv(r)) survived dropout in forward
       if (drop) {
-        keepbits = 0;
+        kb = 0;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const uint32_t pr2 = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
           const uint32_t r0 = drop_pair(rowkey, pr2), r1 = drop_pair(rowkey, pr2 + 1);
-          keepbits |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
-          keepbits |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
-          keepbits |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);
-          keepbits |= ((r1 >> 16) >= p.drop_thresh16 ? 8u : 0u) << (gq * 4);
+          kb |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
+          kb |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
+          kb |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);
+          kb |= ((r1 >> 16) >= p.drop_thresh16 ? 8u : 0u) << (gq * 4);
         }
       }
+      keepbits[t] = kb;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float mv = mb[kv];
         float pr = 0.f, dpr = 0.f;
         if (mv >= 0.f && q < Lq) {
-          const float s = st[t][r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
+          const float s = st[r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
           pr = __expf(s - lq);
           dpr = dp[t][r];
-          if (drop) dpr = ((keepbits >> r) & 1u) ? dpr * p.drop_scale : 0.f;
+          if (drop) dpr = ((kb >> r) & 1u) ? dpr * p.drop_scale : 0.f;
         }
-        st[t][r] = pr;
+        st[r] = pr;
         dp[t][r] = dpr;
         dloc += pr * dpr;
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ppk[t][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
     }
     dloc += __shfl_xor(dloc, 32, 64);
     if (p.d_mode == 1) {
@@ -330,85 +401,88 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
     } else if (p.d_mode == 2) {
       dloc = q < Lq ? p.Dbuf[headbase + q] : 0.f;
     }
-    if (g == 0) Dq[q] = dloc;
-    f32x16 dq[2] = {zero16(), zero16()};
+    if (p.d_mode != 1) {
+      f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t kb = keepbits[t];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dp[t][r] - dloc);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 dsf = pack8(st[t], hf);
-        bf16x8 kf[2];
-        ld_tr2(Ks, t * 32 + hf * 16, lane, kf);
-        dq[0] = MFMA32(kf[0], dsf, dq[0]);
-        dq[1] = MFMA32(kf[1], dsf, dq[1]);
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = up_lo(ppk[t][i]), p1 = up_hi(ppk[t][i]);
+          dpk[t][i] = pk2(p0 * (dp[t][2 * i] - dloc), p1 * (dp[t][2 * i + 1] - dloc));
+          ppk[t][i] = pk2(((kb >> (2 * i)) & 1u) ? p0 * p.drop_scale : 0.f, ((kb >> (2 * i + 1)) & 1u) ? p1 * p.drop_scale : 0.f);
+        }
+        {
+          const u32x4 w0 = {dpk[t][0], dpk[t][1], dpk[t][2], dpk[t][3]}, w1 = {dpk[t][4], dpk[t][5], dpk[t][6], dpk[t][7]};
+          const bf16x8 ds0 = __builtin_bit_cast(bf16x8, w0), ds1 = __builtin_bit_cast(bf16x8, w1);
+          bf16x8 kf0[2], kf1[2];
+          ld_tr2x2(Ks, t * 32, lane, kf0, kf1);
+          dq[0] = MFMA32(kf0[0], ds0, dq[0]);
+          dq[1] = MFMA32(kf0[1], ds0, dq[1]);
+          dq[0] = MFMA32(kf1[0], ds1, dq[0]);
+          dq[1] = MFMA32(kf1[1], ds1, dq[1]);
+        }
       }
-    }
-    if (q < Lq && p.d_mode != 1) {
-      bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD;
+      if (q < Lq) {
+        bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          *(bf16x4*)(dQg + dt * 32 + 8 * gq + 4 * g) =
-              to_bf16x4(dq[dt][gq * 4] * 0.125f, dq[dt][gq * 4 + 1] * 0.125f, dq[dt][gq * 4 + 2] * 0.125f,
-                        dq[dt][gq * 4 + 3] * 0.125f);
+          for (int gq = 0; gq < 4; ++gq)
+            *(bf16x4*)(dQg + dt * 32 + 8 * gq + 4 * g) =
+                to_bf16x4(dq[dt][gq * 4] * 0.125f, dq[dt][gq * 4 + 1] * 0.125f, dq[dt][gq * 4 + 2] * 0.125f,
+                          dq[dt][gq * 4 + 3] * 0.125f);
+      }
     }
   }
   if (p.d_mode == 1) return;   // partial-D pass: nothing else is written
-  __syncthreads();   // D[q] of every query tile is in LDS
 
-  // ---- phase B: wave owns kv tile `wave` -> dK, dV   (S[q][kv]: lane = kv column, registers = q rows)
+  // ---- phase B: wave owns kv tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
+  __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
+  if (wave < NTq) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)(X + xoff(q, t * 8 + 2 * gq + g)) = u32x2{ppk[t][2 * gq], ppk[t][2 * gq + 1]};
+      }
+  }
+  __syncthreads();
+  const int kv = wave * 32 + (lane & 31);
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   if (wave < NT) {
-    const int kv = wave * 32 + (lane & 31);
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      kf[kk] = ld_rm(Ks, kv, kk * 2 + g);
-      vf[kk] = ld_rm(Vs, kv, kk * 2 + g);
-    }
-    const float mv = mb[kv];
-    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    for (int qt = 0; qt < NTq; ++qt) {
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        s = MFMA32(ld_rm(Qs, qt * 32 + (lane & 31), kk * 2 + g), kf[kk], s);
-        dp = MFMA32(ld_rm(dOs, qt * 32 + (lane & 31), kk * 2 + g), vf[kk], dp);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        float pd = 0.f, ds = 0.f;
-        if (mv >= 0.f && q < Lq) {
-          const float sc = s[r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
-          const float pr = __expf(sc - lse[q]);
-          float dpr = dp[r];
-          pd = pr;
-          if (drop) {
-            const uint32_t rr = drop_pair(rk[q], (uint32_t)kv >> 1);
-            const bool keep = ((kv & 1) ? (rr >> 16) : (rr & 0xffffu)) >= p.drop_thresh16;
-            pd = keep ? pr * p.drop_scale : 0.f;
-            dpr = keep ? dpr * p.drop_scale : 0.f;
-          }
-          ds = pr * (dpr - Dq[q]);
-        }
-        s[r] = pd;
-        dp[r] = ds;
-      }
+    for (int qt = 0; qt < NTq; ++qt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack8(s, hf), dsf = pack8(dp, hf);
-        bf16x8 dof[2], qf[2];
+        const bf16x8 pf = ld_xt(X, qt * 32 + hf * 16, wave * 32, lane);
+        bf16x8 dof[2];
         ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
-        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
         dv[0] = MFMA32(dof[0], pf, dv[0]);
         dv[1] = MFMA32(dof[1], pf, dv[1]);
+      }
+  }
+  __syncthreads();             // P~ consumed: region X becomes the dS tile
+  if (wave < NTq) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)(X + xoff(q, t * 8 + 2 * gq + g)) = u32x2{dpk[t][2 * gq], dpk[t][2 * gq + 1]};
+      }
+  }
+  __syncthreads();
+  if (wave < NT) {
+    for (int qt = 0; qt < NTq; ++qt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 dsf = ld_xt(X, qt * 32 + hf * 16, wave * 32, lane);
+        bf16x8 qf[2];
+        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
         dk[0] = MFMA32(qf[0], dsf, dk[0]);
         dk[1] = MFMA32(qf[1], dsf, dk[1]);
       }
-    }
     if (kv < Lkv) {
       bf16* dKg = p.dK + (dkvrow + kv) * p.lddk + h * HD;
       bf16* dVg = p.dV + (dkvrow + kv) * p.lddv + h * HD;
@@ -457,7 +531,7 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
   const int nt = (Lkv + 31) / 32, nw = (Lq + 31) / 32;
-  const size_t lds = FWD_LDS;
+  const size_t lds = (size_t)2 * (nt > 4 ? 4 : nt) * 32 * ROWB + 128 * 4;
   dim3 grid(nH, nseq), block(64 * nw);
   switch (nt) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, stream, p); break;
@@ -509,7 +583,7 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
   const int nt_b = (Lkv + 31) / 32 > 4 ? 4 : (Lkv + 31) / 32;
-  const size_t lds_b = (size_t)2 * nt_b * 32 * 128 + (size_t)2 * ((Lq + 31) / 32) * 32 * 128 + 4 * 128 * 4;
+  const size_t lds_b = (size_t)bwd_xbytes(nt_b, (Lq + 31) / 32) + (size_t)2 * ((Lq + 31) / 32) * 32 * 128 + 3 * 128 * 4;
   switch ((Lkv + 31) / 32) {
     case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
     case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
