@@ -76,9 +76,11 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
   uint32_t u = (idx & 1) ? (r >> 16) : (r & 0xffffu);
   return u >= thresh16;
 }
-// four consecutive elements starting at idx (idx % 4 == 0)
-__device__ __forceinline__ void drop_keep4(uint64_t seed, uint64_t idx, uint32_t thresh16, bool k[4]) {
-  uint32_t r0 = rng_pair(seed, idx >> 1), r1 = rng_pair(seed, (idx >> 1) + 1);
+// Row-kernel dropout (LayerNorm / embedding kernels): element (row, col) uses half (col & 1) of drop_pair(rowkey, col >> 1) with
+// rowkey = drop_rowkey(seed, row) hashed once per row: two 32-bit multiplies per PAIR of elements (v_mul_lo_u32 is a
+// quarter-rate instruction; the 64-bit counter form made the LayerNorm kernels VALU-co-limited).  c % 4 == 0.
+__device__ __forceinline__ void drop_keep4(uint32_t rowkey, int c, uint32_t thresh16, bool k[4]) {
+  const uint32_t r0 = drop_pair(rowkey, (uint32_t)c >> 1), r1 = drop_pair(rowkey, ((uint32_t)c >> 1) + 1);
   k[0] = (r0 & 0xffffu) >= thresh16; k[1] = (r0 >> 16) >= thresh16;
   k[2] = (r1 & 0xffffu) >= thresh16; k[3] = (r1 >> 16) >= thresh16;
 }
@@ -93,6 +95,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// The same sums without the LDS crossbar: four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), one ds_swizzle for the xor-16 step, v_readlane for the two halves.  Every lane of the (half-)wave must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_sum(float v) {   // over each group of 32 lanes, result in all of them
+  v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {   // over the wave, result wave-uniform (scalar registers)
+  v = half_sum(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

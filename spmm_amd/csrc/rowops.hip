@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   RowVec z, r, o;
   load_row_bf16(x + row * H, H, lane, z);
   if (thresh16) {
-    const uint64_t seed = seed_mix(seed_ptr, salt);
+    const uint32_t rowkey = drop_rowkey(seed_mix(seed_ptr, salt), (uint64_t)row);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
         bool k[4];
-        drop_keep4(seed, (uint64_t)row * H + c, thresh16, k);
+        drop_keep4(rowkey, c, thresh16, k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) z.v[i][j] = k[j] ? z.v[i][j] * dscale : 0.f;
       }
@@ -120,6 +120,87 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// The same for H == 256 * NC (768, 1024, ...): a row is owned by HALF a wave (32 lanes x NC chunks of 16 bytes), so a wave
+// normalises two rows at once, every access is a full 16-byte lane access and there are no column guards.
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ res,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16* __restrict__ y, bf16* __restrict__ zout, float* __restrict__ mean_o,
+                                                       float* __restrict__ rstd_o, long rows, float eps, uint32_t thresh16,
+                                                       float dscale, const uint64_t* seed_ptr, uint64_t salt) {
+  constexpr int H = 256 * NC;
+  const int l32 = threadIdx.x & 31;
+  long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool live = row < rows;
+  if (!live) row = rows - 1;                       // the partner half-wave still needs every lane for the reductions
+  const long base = row * H + l32 * 8;
+  bf16x8 xv[NC], rv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) xv[i] = *(const bf16x8*)(x + base + i * 256);
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) rv[i] = *(const bf16x8*)(res + base + i * 256);
+  }
+  float z[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[i][j] = (float)xv[i][j];
+  if (thresh16) {
+    const uint32_t rowkey = drop_rowkey(seed_mix(seed_ptr, salt), (uint64_t)row);
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bool k[4];
+        drop_keep4(rowkey, l32 * 8 + i * 256 + h * 4, thresh16, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[i][h * 4 + j] = k[j] ? z[i][h * 4 + j] * dscale : 0.f;
+      }
+  }
+  float s = 0.f;
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[i][j] += (float)rv[i][j];
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += z[i][j];
+  const float mean = half_sum(s) * (1.f / H);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = z[i][j] - mean; ss += d * d; }
+  const float var = half_sum(ss) * (1.f / H);
+  float rstd = rsqrtf(var + eps);
+  if (!(var + eps > 0.f)) rstd = 0.f;
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = l32 * 8 + i * 256;
+    const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (bf16)((z[i][j] - mean) * rstd * g0[j] + b0[j]);
+      o[4 + j] = (bf16)((z[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+    }
+    *(bf16x8*)(y + base + i * 256) = o;
+    if (zout) {
+      bf16x8 zb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) zb[j] = (bf16)z[i][j];
+      *(bf16x8*)(zout + base + i * 256) = zb;
+    }
+  }
+  if (mean_o && l32 == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
 // ---------------------------------------------------------------- LN backward
 // dz = rstd * (dy*g - mean_H(dy*g) - xhat * mean_H(dy*g*xhat));  dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
 // dx (optional) = dropout-mask(dz).  Per-column partial sums are kept in registers over the block's rows,
@@ -130,17 +211,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 template <int NC>
 struct RawRow { bf16x4 v[NC]; };
 
-template <int NC>
+template <int NC, bool EXACT>
 __device__ __forceinline__ void load_raw(const bf16* __restrict__ p, int H, int lane, RawRow<NC>& r) {
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < H) r.v[i] = *(const bf16x4*)(p + c);
+    if (EXACT || c < H) r.v[i] = *(const bf16x4*)(p + c);
     else r.v[i] = to_bf16x4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
-template <int NC>
+// EXACT: H == 256 * NC, no column guards.  HOT: the combination every encoder layer of a training step uses (one incoming
+// gradient, dropout on x, dx + dgamma + dbeta + dxsum all wanted) with the run-time switches folded away.
+template <int NC, bool EXACT, bool HOT>
 __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2,
                                                      const bf16* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
@@ -155,15 +238,17 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
   for (int i = 0; i < NC; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) gsum[i][j] = bsum[i][j] = xsum[i][j] = 0.f;
-  const uint64_t seed = thresh16 ? seed_mix(seed_ptr, salt) : 0;
+  if (HOT) { dy2 = nullptr; drop_on_dy = 0; }
+  const bool has2 = !HOT && dy2 != nullptr, has_dx = HOT || dx_o != nullptr, has_xs = HOT || dxsum != nullptr, drop = HOT || thresh16 != 0;
+  const uint64_t seed = drop ? seed_mix(seed_ptr, salt) : 0;
   const long stride = (long)gridDim.x * 4;
   long row = (long)blockIdx.x * 4 + wave;
   RawRow<NC> ng, ng2, nz;
   float nmean = 0.f, nrstd = 0.f;
   if (row < rows) {
-    load_raw<NC>(dy + row * H, H, lane, ng);
-    if (dy2) load_raw<NC>(dy2 + row * H, H, lane, ng2);
-    load_raw<NC>(z + row * H, H, lane, nz);
+    load_raw<NC, EXACT>(dy + row * H, H, lane, ng);
+    if (has2) load_raw<NC, EXACT>(dy2 + row * H, H, lane, ng2);
+    load_raw<NC, EXACT>(z + row * H, H, lane, nz);
     nmean = mean_i[row]; nrstd = rstd_i[row];
   }
   for (; row < rows; row += stride) {
@@ -171,23 +256,24 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
     const float mean = nmean, rstd = nrstd;
     const long nrow = row + stride;
     if (nrow < rows) {
-      load_raw<NC>(dy + nrow * H, H, lane, ng);
-      if (dy2) load_raw<NC>(dy2 + nrow * H, H, lane, ng2);
-      load_raw<NC>(z + nrow * H, H, lane, nz);
+      load_raw<NC, EXACT>(dy + nrow * H, H, lane, ng);
+      if (has2) load_raw<NC, EXACT>(dy2 + nrow * H, H, lane, ng2);
+      load_raw<NC, EXACT>(z + nrow * H, H, lane, nz);
       nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
     }
     float g[NC][4], xh[NC][4];
+    const uint32_t rowkey = drop ? drop_rowkey(seed, (uint64_t)row) : 0u;
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[i][j] = (float)cg.v[i][j] + (dy2 ? (float)cg2.v[i][j] : 0.f);
-    if (thresh16 && drop_on_dy) {   // y_out = dropout(LN(z)) (BertEmbeddings): mask the incoming gradient
+      for (int j = 0; j < 4; ++j) g[i][j] = (float)cg.v[i][j] + (has2 ? (float)cg2.v[i][j] : 0.f);
+    if (drop && drop_on_dy) {   // y_out = dropout(LN(z)) (BertEmbeddings): mask the incoming gradient
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (c < H) {
+        if (EXACT || c < H) {
           bool k[4];
-          drop_keep4(seed, (uint64_t)row * H + c, thresh16, k);
+          drop_keep4(rowkey, c, thresh16, k);
 #pragma unroll
           for (int j = 0; j < 4; ++j) g[i][j] = k[j] ? g[i][j] * dscale : 0.f;
         }
@@ -197,7 +283,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < H) {
+      if (EXACT || c < H) {
         const f32x4 gm = *(const f32x4*)(gamma + c);      // L1-resident; keeping it in registers costs occupancy
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -215,43 +301,43 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
         for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
       }
     }
-    s1 = wave_sum(s1) / H;
-    s2 = wave_sum(s2) / H;
-    const bool mask_dx = dx_o && thresh16 && !drop_on_dy;
+    s1 = wave_sum_dpp(s1) / H;
+    s2 = wave_sum_dpp(s2) / H;
+    const bool mask_dx = has_dx && drop && !drop_on_dy;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < H) {
+      if (EXACT || c < H) {
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
         const bf16x4 ob = to_bf16x4(o[0], o[1], o[2], o[3]);
         *(bf16x4*)(dz_o + row * H + c) = ob;
-        if (dx_o) {
+        if (has_dx) {
           bf16x4 xb = ob;
           if (mask_dx) {
             bool k[4];
-            drop_keep4(seed, (uint64_t)row * H + c, thresh16, k);
+            drop_keep4(rowkey, c, thresh16, k);
             xb = to_bf16x4(k[0] ? o[0] * dscale : 0.f, k[1] ? o[1] * dscale : 0.f, k[2] ? o[2] * dscale : 0.f, k[3] ? o[3] * dscale : 0.f);
           }
           *(bf16x4*)(dx_o + row * H + c) = xb;
-          if (dxsum) {
+          if (has_xs) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) xsum[i][j] += (float)xb[j];
           }
-        } else if (dxsum) {
+        } else if (has_xs) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xsum[i][j] += (float)ob[j];
         }
       }
     }
   }
-  if (dgamma == nullptr && dxsum == nullptr) return;
+  if (!HOT && dgamma == nullptr && dxsum == nullptr) return;
   // three block reductions through one LDS buffer: dgamma, dbeta, dxsum
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
     float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dxsum;
-    if (dst == nullptr) continue;
+    if (!HOT && dst == nullptr) continue;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NC; ++i)
@@ -324,13 +410,13 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(EmbedP p) {
   float mean, rstd;
   ln_apply(z, p.H, lane, p.gamma, p.beta, p.eps, mean, rstd, o);
   if (p.thresh16) {
-    const uint64_t seed = seed_mix(p.seed_ptr, p.salt);
+    const uint32_t rowkey = drop_rowkey(seed_mix(p.seed_ptr, p.salt), (uint64_t)row);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < p.H) {
         bool k[4];
-        drop_keep4(seed, (uint64_t)row * p.H + c, p.thresh16, k);
+        drop_keep4(rowkey, c, p.thresh16, k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o.v[i][j] = k[j] ? o.v[i][j] * p.dscale : 0.f;
       }
@@ -525,9 +611,19 @@ extern "C" int spmm_ln_fwd(const void* x, const void* res, const float* gamma, c
                            const uint64_t* seed_ptr, uint64_t salt, hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_fwd: rows=%ld H=%d (need H%%4==0, H<=1024)", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_fwd: dropout needs a device seed");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta,
-                     (bf16*)y, (bf16*)zout, mean, rstd, rows, H, eps, (uint32_t)(dropout_p * 65536.f + 0.5f),
-                     1.f / (1.f - dropout_p), seed_ptr, salt);
+  const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
+  const float ds = 1.f / (1.f - dropout_p);
+#define LN_FWD16(NC)                                                                                                          \
+  hipLaunchKernelGGL(ln_fwd16_kernel<NC>, dim3((rows + 7) / 8), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, gamma, \
+                     beta, (bf16*)y, (bf16*)zout, mean, rstd, rows, eps, th, ds, seed_ptr, salt)
+  if (H == 768) LN_FWD16(3);
+  else if (H == 1024) LN_FWD16(4);
+  else if (H == 512) LN_FWD16(2);
+  else if (H == 256) LN_FWD16(1);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta,
+                       (bf16*)y, (bf16*)zout, mean, rstd, rows, H, eps, th, ds, seed_ptr, salt);
+#undef LN_FWD16
   SPMM_LAUNCH_CHECK("spmm_ln_fwd");
   return SPMM_OK;
 }
@@ -542,12 +638,14 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   if (g > gmax) g = gmax;
   const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
   const float ds = 1.f / (1.f - dropout_p);
-  if (H <= 768)
-    hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
-                       gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, mean, rstd,
-                       gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum);
+  const bool hot = !dy2 && dx && dgamma && dbeta && dxsum && th && !drop_on_dy;
+#define LN_BWD_LAUNCH(NC, EX, HOT)                                                                                                \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX, HOT>), dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, \
+                     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum)
+  if (H == 768 && hot) LN_BWD_LAUNCH(3, true, true);
+  else if (H <= 768) LN_BWD_LAUNCH(3, false, false);
+  else LN_BWD_LAUNCH(4, false, false);
+#undef LN_BWD_LAUNCH
   SPMM_LAUNCH_CHECK("spmm_ln_bwd");
   return SPMM_OK;
 }

@@ -458,7 +458,7 @@ def test_attention_dropout_consistency(ops):
 
 
 # ------------------------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("rows,H", [(7, 128), (1000, 768), (333, 256), (64, 1024)])
+@pytest.mark.parametrize("rows,H", [(7, 128), (1000, 768), (1003, 768), (333, 256), (64, 1024), (61, 512), (5, 1000)])
 def test_layernorm_fwd_bwd(ops, rows, H):
     x, res = rnd(rows, H, seed=50), rnd(rows, H, seed=51)
     gamma = (1 + 0.1 * torch.randn(H)).cuda()
@@ -507,6 +507,49 @@ def test_layernorm_dropout_masks_match(ops):
     close(dxs, dx.float().sum(0), 2e-2, 1e-3, "dxsum with dropout")
     assert ((dx.float() != 0) & ~keep).sum().item() == 0            # dropped inputs get no gradient
     close(dx.float()[keep], dz.float()[keep] / (1 - p), 1e-2, 1e-2, "dropout dx")
+
+
+def test_layernorm_backward_fast_path_equals_general_path(ops):
+    """The all-outputs training combination has its own instantiation (rowops.hip ln_bwd_kernel<3, true, true>); a zero second
+    gradient forces the general one: same masks, same values, same column sums."""
+    rows, H, p = 1237, 768, 0.1
+    x, res = rnd(rows, H, seed=60), rnd(rows, H, seed=61)
+    gamma, beta = (1 + 0.1 * torch.randn(H)).cuda(), (0.1 * torch.randn(H)).cuda()
+    seed = torch.tensor([7], dtype=torch.int64, device="cuda")
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.ln_fwd(x, res, gamma, beta, y, zout=z, mean=mean, rstd=rstd, dropout_p=p, seed=seed, salt=9)
+    dy = rnd(rows, H, seed=62)
+    out = []
+    for dy2 in (None, torch.zeros_like(dy)):
+        dz, dx = torch.empty_like(x), torch.empty_like(x)
+        dg, db, dxs = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        ops.ln_bwd(dy, z, mean, rstd, gamma, dz, dy2=dy2, dx=dx, dgamma=dg, dbeta=db, dropout_p=p, seed=seed, salt=9, dxsum=dxs)
+        out.append((dz, dx, dg, db, dxs))
+    for a, b, nm in zip(out[0], out[1], ("dz", "dx", "dgamma", "dbeta", "dxsum")):
+        close(a, b, 2e-3, 1e-2 if nm in ("dz", "dx") else 1e-3, "fast vs general " + nm)   # dz / dx: one bf16 ulp (fma contraction differs)
+    assert torch.equal(out[0][1] != 0, out[1][1] != 0)
+    # the forward's mask: dropped elements of x have z == res exactly
+    dropped = (out[0][1].float() == 0) & (out[0][0].float() != 0)
+    assert abs(dropped.float().mean().item() - p) < 0.01
+    assert torch.equal(z[dropped], res[dropped])
+
+
+def test_layernorm_dropout_masks_differ_between_rows_steps_and_sites(ops):
+    rows, H, p = 512, 768, 0.5
+    x = torch.ones(rows, H, dtype=BF, device="cuda")
+    gamma, beta = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
+
+    def mask(seed, salt):
+        z, y = torch.empty_like(x), torch.empty_like(x)
+        ops.ln_fwd(x, None, gamma, beta, y, zout=z, dropout_p=p, seed=torch.tensor([seed], dtype=torch.int64, device="cuda"), salt=salt)
+        return (z.float() != 0).float()
+    m0, m1, m2 = mask(100, 3), mask(101, 3), mask(100, 4)
+    assert abs(m0.mean().item() - 0.5) < 0.01
+    for a, b in ((m0, m1), (m0, m2), (m0[:-1], m0[1:]), (m0[:, :-1], m0[:, 1:]), (m0[:, :-2], m0[:, 2:])):
+        agree = (a == b).float().mean().item()
+        assert abs(agree - 0.5) < 0.01, agree
+    assert abs(m0.mean(0) - 0.5).max().item() < 0.12 and abs(m0.mean(1) - 0.5).max().item() < 0.1
 
 
 # ------------------------------------------------------------------------------------------ embeddings

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spmm_amd import ops
-M, H = 93184, 768
+M, H = 84256, 768
 dev = "cuda"
 BF = torch.bfloat16
 x = torch.randn(M, H, device=dev).to(BF); r = torch.randn(M, H, device=dev).to(BF)
@@ -26,6 +26,7 @@ cases = [
     ("ln_fwd  x+res -> y,z (train, dropout)", lambda: ops.ln_fwd(x, r, g, b, y, zout=z, mean=mean, rstd=rstd, dropout_p=0.1, seed=seed, salt=7), 4 * row),
     ("ln_fwd  x+res -> y (eval)", lambda: ops.ln_fwd(x, r, g, b, y), 3 * row),
     ("ln_bwd  dy,z -> dz,dx (dropout, dgamma, dxsum)", lambda: ops.ln_bwd(x, z, mean, rstd, g, dz, dx=dx, dgamma=dg, dbeta=db, dropout_p=0.1, seed=seed, salt=7, dxsum=dxs), 4 * row),
+    ("ln_bwd  dy,z -> dz,dx (dropout, dgamma, dbeta, dxsum: the training combination)", lambda: ops.ln_bwd(x, z, mean, rstd, g, dz, dx=dx, dgamma=dg, dbeta=db, dropout_p=0.1, seed=seed, salt=7, dxsum=dxs), 4 * row),
     ("ln_bwd  dy,z -> dz (no dropout, dgamma)", lambda: ops.ln_bwd(x, z, mean, rstd, g, dz, dgamma=dg, dbeta=db), 3 * row),
 ]
 ops.ln_fwd(x, r, g, b, y, zout=z, mean=mean, rstd=rstd)
