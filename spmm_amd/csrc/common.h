@@ -122,11 +122,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// (v_rcp_f32 through the builtin: `__frcp_rn` and `1.f / x` expand to the ten-instruction IEEE division sequence.)
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, far below the bf16 resolution of the GELU outputs): one v_rcp,
 // one v_exp and a 5-term Horner chain instead of libm's erff in the GEMM epilogues.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float y = 1.0f - poly * __expf(-ax * ax);
   return copysignf(y, x);
@@ -141,9 +142,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // gelu(x) and gelu'(x) together: exp(-x^2/2) serves both the erf (A&S 7.1.26: erf(z) = 1 - poly(t) exp(-z^2), z = x / sqrt 2)
 // and the density term, so the derivative costs two extra FMAs in the forward epilogue and the backward epilogue becomes a
 // plain multiply (SPMM_EPI_GELU_DERIV / SPMM_EPI_MUL).
+// Two elements at a time on float2 values: every multiply / FMA becomes a v_pk_* instruction (two elements per issue slot);
+// only the reciprocal, the exponential and the sign transfer stay per element.  Same formula as gelu_erf_both.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool DERIV>
+__device__ __forceinline__ void gelu_erf_pair(f32x2 x, f32x2& g, f32x2& dg) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const f32x2 a = x * x * (-0.5f * 1.4426950408889634f);
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+  const f32x2 h = 0.5f - 0.5f * (poly * e);                       // = Phi(|x|) - 1/2  in [0, 1/2]
+  f32x2 hs;
+  hs.x = copysignf(h.x, x.x); hs.y = copysignf(h.y, x.y);
+  const f32x2 cdf = hs + 0.5f;
+  g = x * cdf;
+  if (DERIV) dg = cdf + x * (0.3989422804014327f * e);
+}
 __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
   const float az = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * az);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float e = __expf(-0.5f * x * x);
   const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));

@@ -695,9 +695,12 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if constexpr (EPI == EPI_GELU) { w[ni][j] = v[ni][j]; v[ni][j] = gelu_erf(v[ni][j]); }
-            else { const float x = v[ni][j]; gelu_erf_both(x, v[ni][j], w[ni][j]); }
+          for (int j = 0; j < 4; j += 2) {
+            const f32x2 x = {v[ni][j], v[ni][j + 1]};
+            f32x2 gg, dd = x;                                     // EPI_GELU keeps the pre-activation as its second output
+            gelu_erf_pair<EPI == EPI_GELU_DERIV>(x, gg, dd);
+            v[ni][j] = gg.x; v[ni][j + 1] = gg.y;
+            w[ni][j] = dd.x; w[ni][j + 1] = dd.y;
           }
         if (c2p) {
 #pragma unroll

@@ -452,18 +452,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-// out[c] += sum_r x[r][c]   (bias gradients).  A workgroup reduces a 256-row x 128-column strip: 16 column groups of
-// 8 bf16 (16-byte loads) x 16 row lanes, 16 rows per thread, LDS tree over the row lanes, one atomicAdd per column.
+// out[c] += sum_r x[r][c]   (bias gradients).  A workgroup reduces a CS_ROWS-row x 128-column strip: 16 column groups of
+// 8 bf16 (16-byte loads) x 16 row lanes, eight loads in flight per thread, LDS tree over the row lanes, one atomicAdd per column.
+constexpr int CS_ROWS = 1024;
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, float* __restrict__ out) {
   __shared__ float red[16][129];
   const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 128 + cg * 8;
-  const int r0 = blockIdx.y * 256;
+  const int r0 = blockIdx.y * CS_ROWS;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     const bool full = c + 8 <= C;
+    if (full && r0 + CS_ROWS <= R) {
+      const bf16* xp = x + (long)(r0 + rl) * ld + c;
+      for (int i = 0; i < CS_ROWS / 16; i += 8) {
+        bf16x8 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const bf16x8*)(xp + (long)(i + u) * 16 * ld);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
+      }
+    } else
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < CS_ROWS / 16; ++i) {
       const int r = r0 + rl + i * 16;
       if (r < R) {
         if (full) {
@@ -594,7 +607,7 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
 
 extern "C" int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream) {
   SPMM_CHECK_SHAPE(R > 0 && C > 0 && ld % 8 == 0 && ((uintptr_t)x % 16 == 0), "spmm_colsum_bf16: R=%d C=%d ld=%ld (ld %% 8, 16-B aligned)", R, C, ld);
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128, (R + 255) / 256), dim3(256), 0, stream, (const bf16*)x, ld, R, C, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128, (R + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, stream, (const bf16*)x, ld, R, C, out);
   SPMM_LAUNCH_CHECK("spmm_colsum_bf16");
   return SPMM_OK;
 }
