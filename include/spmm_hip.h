@@ -183,6 +183,11 @@ int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, 
 int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
                   int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
                   float* dw, float* db, int do_bwd, spmm_stream_t stream);
+/* Small dense heads of the inference tier: out[r,n] = act(bias[n] + sum_k x[r,k] W[n,k]) in fp32 (x fp32 or bf16; act 0 = none,
+ * 1 = erf-GELU) -- property_embed / property_proj / text_proj / itm_head / property_mtr_head called as modules on a few rows
+ * (SPMM_models.py:36-43; d_smiles2pv.py:15-25, d_pv2smiles_batched.py:25-27). */
+int spmm_rows_linear(const void* x, int x_is_bf16, long ldx, const float* W, const float* bias, float* out, long ldo, long rows,
+                     int N, int K, int act, spmm_stream_t stream);
 /* _dequeue_and_enqueue SPMM_models.py:272-286 (+ the bf16 GEMM shadows of the queue).  skip_flag (optional, device int): when
  * non-zero neither the queue nor the pointer is touched -- the reference's NaN guard returns before the enqueue
  * (SPMM_models.py:132-134 vs :208), so a non-finite momentum feature never enters the queue. */

@@ -313,6 +313,36 @@ __global__ void mpm_head_kernel(const bf16* __restrict__ h, int Lp, int H, const
   if (lane == 0 && keep) atomicAdd(db, g);
 }
 
+// ---------------------------------------------------------------- small dense heads for the inference tier
+// out[r, n] = act(bias[n] + sum_k x[r, k] W[n, k]), fp32 weights / accumulation / output, x fp32 or bf16.  One wave per row.
+// K >= 64: the lanes stride k (coalesced x and W rows) and every output is one wave reduction -- the projection, matching and
+// regression heads (N in {1, 2, 256, H}, K = H or 2H) called on a handful of pooled rows (SPMM_models.py:36-43).  K < 64: the lanes
+// stride n -- property_embed = Linear(1, H) (:36).
+template <bool XBF>
+__global__ __launch_bounds__(256) void rows_linear_kernel(const void* __restrict__ xv, long ldx, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ out, long ldo,
+                                                          long rows, int N, int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  auto X = [&](int k) -> float { return XBF ? (float)((const bf16*)xv)[r * ldx + k] : ((const float*)xv)[r * ldx + k]; };
+  auto fin = [&](float v) -> float { return act == 1 ? 0.5f * v * (1.f + erff(v * 0.70710678118654752f)) : v; };
+  if (K >= 64) {
+    for (int n = 0; n < N; ++n) {
+      float a = 0.f;
+      for (int k = lane; k < K; k += 64) a += X(k) * W[(long)n * K + k];
+      a = wave_sum(a);
+      if (lane == 0) out[r * ldo + n] = fin(a + (bias ? bias[n] : 0.f));
+    }
+  } else {
+    for (int n = lane; n < N; n += 64) {
+      float a = bias ? bias[n] : 0.f;
+      for (int k = 0; k < K; ++k) a += X(k) * W[(long)n * K + k];
+      out[r * ldo + n] = fin(a);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- queue
 // feats [n, E] fp32 (all-gathered momentum features).  queue [E, Q] fp32 (reference layout, state_dict buffer),
 // w3 [B + Q, 3E] bf16 split rows (sim-GEMM W operand; queue column j lives at row B + j),
@@ -419,6 +449,17 @@ extern "C" int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const
   hipLaunchKernelGGL(mpm_head_kernel, dim3((B * Lp + 3) / 4), dim3(256), 0, stream, (const bf16*)h, Lp, H, w, bias, target, mask, B,
                      n_keep_ws, gscale, losses, loss_slot, pred_out, (bf16*)dh, dw, db, do_bwd);
   SPMM_LAUNCH_CHECK("spmm_mpm_head");
+  return SPMM_OK;
+}
+extern "C" int spmm_rows_linear(const void* x, int x_is_bf16, long ldx, const float* W, const float* bias, float* out, long ldo,
+                                long rows, int N, int K, int act, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(rows > 0 && N > 0 && K > 0 && ldx >= K && ldo >= N, "spmm_rows_linear: rows=%ld N=%d K=%d ldx=%ld ldo=%ld", rows, N, K, ldx, ldo);
+  SPMM_CHECK_SHAPE(act == 0 || act == 1, "spmm_rows_linear: act %d (0 = none, 1 = erf-GELU)", act);
+  if (x_is_bf16)
+    hipLaunchKernelGGL(rows_linear_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, W, bias, out, ldo, rows, N, K, act);
+  else
+    hipLaunchKernelGGL(rows_linear_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, W, bias, out, ldo, rows, N, K, act);
+  SPMM_LAUNCH_CHECK("spmm_rows_linear");
   return SPMM_OK;
 }
 extern "C" int spmm_enqueue(const float* feats, int n, int E, float* queue, int Q, void* w3, void* qT, long ldt, int Bloc, long* ptr,

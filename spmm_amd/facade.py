@@ -94,7 +94,8 @@ class MaskedLMFacade:
 
 
 class LinearFacade:
-    """nn.Linear-like callable over parameters of the flat arena (fp32 math: these heads are tiny)."""
+    """nn.Linear-like callable over parameters of the flat arena: the in-tree small-head kernel (csrc/losses.hip rows_linear,
+    fp32 weights and accumulation) -- these heads see a handful of pooled rows."""
 
     def __init__(self, model, name: str):
         self._m, self.name = model, name
@@ -107,19 +108,34 @@ class LinearFacade:
     def bias(self):
         return self._m._parameters[self.name + ".bias"]
 
+    @torch.no_grad()
     def __call__(self, x):
-        return torch.nn.functional.linear(x.to(self.weight.device).float(), self.weight, self.bias)
+        W = self.weight.detach()
+        N, K = W.shape
+        x2 = x.to(W.device).float().reshape(-1, K).contiguous()
+        out = torch.empty(x2.shape[0], N, dtype=torch.float32, device=W.device)
+        ops.rows_linear(x2, W.contiguous(), self.bias.detach(), out)
+        return out.view(*x.shape[:-1], N)
 
 
 class MtrHeadFacade:
-    """property_mtr_head = Sequential(Linear, GELU, LayerNorm, Linear(H,1)) SPMM_models.py:39-42."""
+    """property_mtr_head = Sequential(Linear, GELU, LayerNorm, Linear(H,1)) SPMM_models.py:39-42 -- the kernels the training step
+    runs for it (step.py: bf16 GEMM with the erf-GELU epilogue, the LayerNorm row kernel), then the fp32 Linear(H, 1)."""
 
     def __init__(self, model):
         self._m = model
 
+    @torch.no_grad()
     def __call__(self, x):
-        P, F = self._m._parameters, torch.nn.functional
-        x = x.to(self._m.device_).float()
-        h = F.gelu(F.linear(x, P["property_mtr_head.0.weight"], P["property_mtr_head.0.bias"]))
-        h = F.layer_norm(h, (h.shape[-1],), P["property_mtr_head.2.weight"], P["property_mtr_head.2.bias"], self._m.cfg.text.layer_norm_eps)
-        return F.linear(h, P["property_mtr_head.3.weight"], P["property_mtr_head.3.bias"])
+        m = self._m
+        P, S = m._parameters, m.store
+        H = x.shape[-1]
+        x2 = x.to(m.device_).to(BF).reshape(-1, H).contiguous()
+        rows = x2.shape[0]
+        h = torch.empty(rows, H, dtype=BF, device=x2.device)
+        ops.gemm_nt(x2, S.wb("property_mtr_head.0.weight"), h, bias=S.w("property_mtr_head.0.bias"), epi=ops.EPI_GELU)
+        y = torch.empty_like(h)
+        ops.ln_fwd(h, None, S.w("property_mtr_head.2.weight"), S.w("property_mtr_head.2.bias"), y, eps=m.cfg.text.layer_norm_eps)
+        out = torch.empty(rows, 1, dtype=torch.float32, device=x2.device)
+        ops.rows_linear(y, P["property_mtr_head.3.weight"].detach().contiguous(), P["property_mtr_head.3.bias"].detach(), out)
+        return out.view(*x.shape[:-1], 1)

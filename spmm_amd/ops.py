@@ -210,6 +210,16 @@ def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None,
                _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), _st())
 
 
+def rows_linear(x, W, bias, out, *, act=0):
+    """out[r,n] = act(bias[n] + x[r,:] . W[n,:]) in fp32; x [rows, K] fp32 or bf16 (row stride free), W [N, K] fp32 contiguous."""
+    rows, K = x.shape
+    N = W.shape[0]
+    assert W.dtype == torch.float32 and W.is_contiguous() and W.shape[1] == K and out.dtype == torch.float32 and tuple(out.shape) == (rows, N)
+    assert x.dtype in (torch.float32, BF16) and x.stride(1) == 1
+    _call("spmm_rows_linear", _p(x), int(x.dtype == BF16), _row_stride(x), _p(W), _p(bias), _p(out), _row_stride(out), rows, N, K, int(act), _st())
+    return out
+
+
 def enqueue(feats, queue, w3, qT, ptr, *, Bloc, advance=True, skip_flag=None):
     n, E = feats.shape
     _call("spmm_enqueue", _p(feats), n, E, _p(queue), queue.shape[1], _p(w3), _p(qT), _row_stride(qT), Bloc, _p(ptr),

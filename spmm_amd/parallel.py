@@ -57,9 +57,11 @@ class OverlappedGradSync:
     tensors are contiguous in the flat arena, so `layer_done(prefix)` launches one asynchronous all-reduce over that slice
     (28-38 MB fp32: long messages for the point-to-point xGMI links).  RCCL runs it on its own stream behind an event on the
     compute stream while the next layers' backward kernels keep the CUs busy.  `finish()` reduces what no layer covered
-    (embeddings, heads, projections: ~2 % of the bytes) and joins the streams before the optimiser."""
+    (embeddings, heads, projections: ~2 % of the bytes) and joins the streams before the optimiser.
+    The collective is issued from the stream context the layer's backward ran in (S2's backward runs on a side stream): its
+    implicit dependency is exactly the stream that wrote the slice."""
 
-    def __init__(self, order, offset, total):
+    def __init__(self, order, offset, total, wire=None):
         self.total = int(total)
         names = list(order)
         ends = [offset[n] for n in names[1:]] + [self.total]
@@ -74,16 +76,54 @@ class OverlappedGradSync:
                 raise ValueError(f"parameters of {m.group(1)} are not contiguous in the flat arena")
             self._ranges[m.group(1)] = (lo, e)
         self._grad, self._work, self._done = None, [], []
+        # wire format of the gradient exchange: "fp32" = one all-reduce per slice on the arena itself; "bf16" = the slice is cast
+        # to bf16, reduce-scattered and all-gathered (half the bytes on every xGMI link, sums in bf16: |rel err| <= 2^-8 per element)
+        self.wire = os.environ.get("SPMM_GRAD_WIRE", "fp32") if wire is None else wire
+        if self.wire not in ("fp32", "bf16"):
+            raise ValueError(f"SPMM_GRAD_WIRE must be fp32 or bf16, not {self.wire!r}")
+        self.trace = None            # set to [] to record (lo, hi, issue event, done event) per slice (tests / timeline checks)
+        self._observer = None
 
     def begin(self, grad: torch.Tensor):
         assert grad.numel() == self.total
-        self._grad, self._work, self._done = grad, [], []
+        self._grad, self._work, self._done, self._staged = grad, [], [], []
         self._avg = dist.get_backend() == "nccl"
+        if self.trace is not None:
+            self.trace.clear()
 
     def _reduce(self, lo, hi):
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._work.append(dist.all_reduce(self._grad[lo:hi], op=op, async_op=True))
+        if hi <= lo:
+            return
+        sl = self._grad[lo:hi]
+        issue = None
+        if self.trace is not None and sl.is_cuda:
+            issue = torch.cuda.Event(enable_timing=True)
+            issue.record()                                       # on the stream that just finished writing this slice
+        if self.wire == "fp32":
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            works = [dist.all_reduce(sl, op=op, async_op=True)]
+        else:
+            ws, n = world(), hi - lo
+            npad = (n + ws - 1) // ws * ws
+            buf = torch.zeros(npad, dtype=torch.bfloat16, device=sl.device) if npad != n else torch.empty(n, dtype=torch.bfloat16, device=sl.device)
+            buf[:n].copy_(sl)
+            shard = torch.empty(npad // ws, dtype=torch.bfloat16, device=sl.device)
+            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, async_op=True)
+            if not self._avg:
+                w1.wait()                                        # gloo runs independent works concurrently: order them by hand
+            works = [w1, dist.all_gather_into_tensor(buf, shard, async_op=True)]      # RCCL: same stream, in issue order
+            self._staged.append((lo, hi, buf, shard))           # both stay alive until finish(): RCCL reads / writes them on its stream
+        self._work.extend(works)
         self._done.append((lo, hi))
+        if issue is not None:
+            if self._observer is None:
+                self._observer = torch.cuda.Stream()
+            done = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._observer):              # the observer waits for the collective; the compute stream does not
+                for w in works:
+                    w.wait()
+                done.record()
+            self.trace.append((lo, hi, issue, done))
 
     def layer_done(self, prefix: str):
         if self._grad is None or prefix not in self._ranges:
@@ -98,9 +138,11 @@ class OverlappedGradSync:
             pos = max(pos, hi)
         for w in self._work:
             w.wait()
-        if not self._avg:
+        for lo, hi, buf, _ in self._staged:
+            self._grad[lo:hi].copy_(buf[:hi - lo])
+        if not self._avg or self.wire == "bf16":
             self._grad.div_(world())
-        self._grad, self._work = None, []
+        self._grad, self._work, self._staged = None, [], []
 
 
 def grad_sync_fn(store=None):

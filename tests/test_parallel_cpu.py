@@ -74,7 +74,7 @@ def test_two_rank_gather_and_grad_average():
     assert not torch.allclose(queue[:, :8], init[:, :8]) and torch.equal(queue[:, 8:], init[:, 8:])
 
 
-def _overlap_worker(rank, world, port, q):
+def _overlap_worker(rank, world, port, q, wire="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPMM_DRY_RUN="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spmm_amd import parallel
@@ -89,7 +89,7 @@ def _overlap_worker(rank, world, port, q):
     for n in order:                                    # the arithmetic of ParamStore.__init__ (needs no device)
         offset[n] = off
         off += ((int(math.prod(shape[n])) if shape[n] else 1) + ALIGN - 1) // ALIGN * ALIGN
-    sync = parallel.OverlappedGradSync(order, offset, off)
+    sync = parallel.OverlappedGradSync(order, offset, off, wire=wire)
     g = torch.Generator().manual_seed(100 + rank)
     grad = torch.randn(off, generator=g)
     local = grad.clone()
@@ -126,3 +126,23 @@ def test_overlapped_grad_sync_two_ranks():
         assert p.exitcode == 0
     assert torch.allclose(torch.from_numpy(got), torch.from_numpy(want), atol=1e-7)
     assert 0.5 * total < covered < total and nl >= 3          # layers carry most of the bytes, the sweep the rest
+
+
+def test_overlapped_grad_sync_bf16_reduce_scatter_all_gather_two_ranks():
+    """SPMM_GRAD_WIRE=bf16: every slice travels as bf16 through reduce-scatter + all-gather (half the bytes per link).  Stated
+    tolerance against the fp32 mean: two bf16 roundings (the cast and the sum), |err| <= 2^-7 * (|g0| + |g1|) / 2 per element."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, "bf16")) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, want, covered, total, nl = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got, want = torch.from_numpy(got), torch.from_numpy(want)
+    g = [torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    bound = 2.0 ** -7 * (g[0].abs() + g[1].abs()) / 2 + 1e-6
+    assert ((got - want).abs() <= bound).all(), float(((got - want).abs() - bound).max())
+    assert (got - want).abs().max() > 1e-5                    # it really went through bf16

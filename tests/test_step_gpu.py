@@ -118,9 +118,19 @@ def test_submodule_facades_match_reference_blocks(env, golden_dir):
     cls = pe[:, 0, :]
     ref = torch.nn.functional.linear(cls.cpu(), sd["property_proj.weight"], sd["property_proj.bias"])
     assert torch.allclose(m.property_proj(cls).cpu(), ref, atol=1e-5)
-    pf = m.property_embed(torch.from_numpy(g["prop"]).unsqueeze(2))
+    F = torch.nn.functional
+    pin = torch.from_numpy(g["prop"]).unsqueeze(2)
+    pf = m.property_embed(pin)
     assert pf.shape == (B, 53, 128)
-    assert m.property_mtr_head(pe[:, :-1, :]).shape == (B, 53, 1)
+    assert torch.allclose(pf.cpu(), F.linear(pin, sd["property_embed.weight"], sd["property_embed.bias"]), atol=1e-6)
+    pair = torch.cat([cls, te[:, 0, :]], dim=-1)                             # itm_head = Linear(2H, 2) on the two CLS states (SPMM_models.py:43, :201)
+    assert torch.allclose(m.itm_head(pair).cpu(), F.linear(pair.cpu(), sd["itm_head.weight"], sd["itm_head.bias"]), atol=1e-5)
+    mt = m.property_mtr_head(pe[:, :-1, :])
+    assert mt.shape == (B, 53, 1)
+    h = F.gelu(F.linear(pe[:, :-1, :].cpu(), sd["property_mtr_head.0.weight"], sd["property_mtr_head.0.bias"]))
+    h = F.layer_norm(h, (128,), sd["property_mtr_head.2.weight"], sd["property_mtr_head.2.bias"], 1e-12)
+    ref = F.linear(h, sd["property_mtr_head.3.weight"], sd["property_mtr_head.3.bias"])
+    assert (mt.cpu() - ref).abs().max().item() < 3e-2, (mt.cpu() - ref).abs().max().item()       # bf16 GEMM + LayerNorm rows, as in the training step
     assert m.property_cls.shape == (1, 1, 128) and m.device.type == "cuda"
 
 
@@ -697,6 +707,86 @@ def test_full_depth_training_steps_match_oracle(env):
     assert int(m.queue_ptr) == (3 * B) % 64
 
 
+def test_gradient_exchange_overlaps_backward(env, monkeypatch):
+    """Timeline of the overlapped gradient exchange (spmm_amd/parallel.py OverlappedGradSync) with the collective replaced by one that
+    behaves like ProcessGroupNCCL -- it waits for the issuing stream, runs ~5 ms on its OWN stream, and `work.wait()` only makes the
+    caller's stream wait -- so the check needs no second GPU: every layer's slice is issued exactly once, the backward of the
+    NEXT layer finishes on the compute stream while this layer's (slow) reduce is still running, the compute stream joins
+    only in finish(), and the step's results are those of the run without any exchange."""
+    if os.environ.get("SPMM_OVERLAP_CHILD") != "1":
+        # HIP maps streams onto a few hardware queues (4 by default) and streams that share a queue serialise: after the ~60 streams
+        # the earlier tests of this process created, the "communication" stream below may sit behind a compute stream.  A training
+        # process has four streams (main, two side streams, RCCL's), so the timeline is checked in a fresh process.
+        import subprocess, sys
+        out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__) + "::test_gradient_exchange_overlaps_backward"],
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, SPMM_OVERLAP_CHILD="1"))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        return
+    from spmm_amd import parallel
+    O = env[0]
+    prop, ids, mask = O.synthetic_batch(4, 16, seed=7)
+    prop, ids, mask = _cuda(prop, ids, mask)
+    mpm = torch.zeros(4, 53).cuda()
+    neg = tuple(_cuda(torch.arange(4).roll(1), torch.arange(4).roll(2)))
+    ref = _tiny_train_model(env, dropout=False)
+    want = [float(x) for x in ref.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)]
+    want_flat = ref.store.flat.clone()
+
+    comm = torch.cuda.Stream()
+    issued_from = []
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    SLEEP = 20_000_000                                           # ~10 ms: several times a tiny layer's (host-bound) backward
+    torch.cuda._sleep(1000)
+    c0.record(); torch.cuda._sleep(SLEEP); c1.record()
+    torch.cuda.synchronize()
+    link_ms = c0.elapsed_time(c1)                                # what the fake collective below costs (a few ms)
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def slow_all_reduce(t, op=None, async_op=False):
+        assert async_op
+        issued_from.append(torch.cuda.current_stream().cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            torch.cuda._sleep(SLEEP)                            # "link time"
+            t.mul_(1.0)                                          # one rank: the mean is the value itself
+            done = torch.cuda.Event()
+            done.record()
+        return Work(done)
+
+    monkeypatch.setattr(parallel.dist, "all_reduce", slow_all_reduce)
+    monkeypatch.setattr(parallel.dist, "get_backend", lambda *a: "nccl")
+    m = _tiny_train_model(env, dropout=False)
+    sync = parallel.OverlappedGradSync(m.store.order, m.store.offset, m.store.total, wire="fp32")
+    sync.trace = []
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    got = [float(x) for x in m.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, grad_sync=sync)]
+    t1.record()
+    torch.cuda.synchronize()
+    trace = list(sync.trace)
+    nl = m.cfg.text.num_hidden_layers + m.cfg.prop.num_hidden_layers
+    layer_slices = trace[:nl]                                    # per-layer slices come first, the sweep of the rest follows
+    assert len(trace) > nl and len(issued_from) == len(trace)
+    covered = sorted((lo, hi) for lo, hi, _, _ in trace)
+    assert covered[0][0] == 0 and covered[-1][1] == m.store.total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))            # every element exactly once
+    for (lo, hi, issue, done), (_, _, issue_next, _) in zip(layer_slices, layer_slices[1:]):
+        assert issue.elapsed_time(done) >= 0.8 * link_ms                       # the fake collective really takes its time
+        assert issue_next.elapsed_time(done) > 0.0, "the next layer's backward did not finish before this layer's reduce ended: no overlap"
+    # all slices ran back to back on the communication stream; the compute stream joined once, at the end
+    assert t0.elapsed_time(t1) < len(trace) * link_ms * 1.5 + 200.0
+    np.testing.assert_allclose(got, want, rtol=1e-5)             # (fp32 atomic sums: two runs agree to rounding, not bit for bit)
+    assert (m.store.flat - want_flat).abs().max().item() < 2.5e-3            # one AdamW step at lr 1e-3: sign flips of ~0 gradients move a weight by <= 2 lr
+
+
 def test_rccl_code_path_single_rank(env):
     """The collective code path on real RCCL with a one-rank group (this box has one GPU): per-layer asynchronous all-reduces
     issued from the backward streams, the final sweep, the feature all-gather -- the step must produce the losses of the
@@ -706,15 +796,17 @@ def test_rccl_code_path_single_rank(env):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--seq-len", "32", "--layers", "2,1,1",
            "--queue", "64", "--no-cpu-baseline", "--no-kernel-timing", "--eval-mode"]
     outs = []
-    for force in ("1", "0"):
+    for force, wire in (("1", "fp32"), ("0", "fp32"), ("1", "bf16")):
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-        envv = dict(os.environ, SPMM_FORCE_DIST=force, MASTER_PORT=str(port))
+        envv = dict(os.environ, SPMM_FORCE_DIST=force, SPMM_GRAD_WIRE=wire, MASTER_PORT=str(port))
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=envv, cwd=root)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["losses"])
     assert all(np.isfinite(outs[0]))
     # two separate 4-step runs: fp32 atomic accumulation order (bias / LayerNorm gradients) makes them agree to ~5e-4 only
     np.testing.assert_allclose(outs[0], outs[1], rtol=3e-3, atol=0)
+    # bf16 reduce-scatter + all-gather of the gradients (RCCL, one rank): gradients rounded to bf16 before AdamW
+    np.testing.assert_allclose(outs[2], outs[1], rtol=2e-2, atol=0)
 
 
 @pytest.mark.parametrize("case", ["min_len", "full_len_128", "odd_33", "mask_holes", "one_long_rest_short"])
