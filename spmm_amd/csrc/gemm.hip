@@ -689,6 +689,10 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[ni][j] = acc[h][mi][ni][j] * scale + b[ni][j];
+      // the accumulators of this block are zeroed for the next tile HERE, in the shadow of the block's LDS round trip and store
+      // issue (a P8_ZERO after the epilogue is 128 VALU slots per wave with the MFMA pipe idle)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[h][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x4 o1, o2;
       if constexpr (GELU2) {
         float w[4][4];                                          // second output: pre-activation (GELU) or gelu'(pre) (GELU_DERIV)
@@ -750,8 +754,14 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
           }
         }
       }
+#ifdef P8_NOSTORE          // experiment (tools/Makefile gemm_bench_nostore): what the stores of the epilogue cost the NEXT tile's DMA waits
+      if (p.M < 0) {
+#endif
       if (ok1) *(u32x4*)(cp + (long)blk * 16 * p.ldc) = o1;
       if (ok2) *(u32x4*)(cp + (long)blk * 16 * p.ldc + 8 * p.ldc) = o2;
+#ifdef P8_NOSTORE
+      }
+#endif
       hook(blk);
       if (blk == 3) { P8_LOAD_EX(1); }
     }
@@ -905,6 +915,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
 #define P8_STAMP(K) do { } while (0)
 #endif
   int vb = blockIdx.x;
+  bool pre = false;
   P8_TILE(vb);
   P8_PROLOGUE();
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile 0 landed, three half-tiles of K-tile 1 in flight
@@ -919,13 +930,16 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
     const int cm0 = m0, cn0 = n0;
     const int vbn = vb + (int)gridDim.x;
     const bool has_next = vbn < nt;                  // wave-uniform
+    // an interior tile's epilogue issues AT LEAST 16 vector-memory operations per lane (the unpredicated stores of C; more with
+    // a second output, R / G loads or column-sum atomics): the next tile's first pair may leave 16 of them outstanding
+    const bool pre_next = has_next && cm0 + BM3 <= p.M && cn0 + BN3 <= p.N;
     for (int kt = 0; kt < nk; kt += 2) {
       const bool last = kt + 2 >= nk;
       const bool more = !last || has_next;
       int kn = kt + 2;                               // K-tile (of the tile whose offsets are loaded) staged from phase 2 on
       // ---------------- K-tile kt (buffer 0)
       P8_RD_W(0, 0, fw0); P8_SB(); P8_RD_A(0, 0);                                 // phase 1
-      P8_STG_A(1, 1, kt + 1);
+      if (!(pre && kt == 0)) P8_STG_A(1, 1, kt + 1);                              // (pre: staged before the previous tile's epilogue)
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                          // the four W-h0 reads: slot free for phase 2
       P8_COMPUTE(0, 0, fw0);
       if (last && has_next) { P8_TILE(vbn); kn = 0; }                             // from here on the DMA sources are the next tile's
@@ -937,7 +951,11 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       P8_COMPUTE(1, 1, fw1);
       if (more) {                                                                 // phase 4
         P8_STG_W(1, 0, kn);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          // K-tile kt+1 complete (this wave's pieces)
+        // K-tile kt+1 complete (this wave's pieces).  First pair after a boundary: its pieces were all issued BEFORE the previous
+        // tile's stores, the six loads above after them -- vmcnt counts loads and stores in issue order, so the stores may stay
+        // outstanding (waiting for them here costs the first K-tile of every tile)
+        if (pre && kt == 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -955,7 +973,12 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       P8_COMPUTE(1, 1, fw1);
       if (more) {                                                                 // phase 8
         P8_STG_W(1, 1, kn + 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          // the next K-tile for buffer 0 complete
+        if (last && pre_next) {                                                   // the fourth half-tile of the next tile's K-tile 1 too:
+          P8_STG_A(1, 1, kn + 1);                                                 // nothing of that K-tile is then issued after the stores
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        // the next K-tile for buffer 0 complete
+        }
       }
       P8_COMPUTE(1, 0, fw0);
     }
@@ -995,8 +1018,8 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
 #endif
     if (!has_next) break;
     vb = vbn;
+    pre = pre_next;
     P8_SB();
-    P8_ZERO();
   }
   if (wr == 0) P8_BAR();                             // balance the barrier count of the two wave rows
 #undef P8_ZERO

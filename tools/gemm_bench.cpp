@@ -30,7 +30,10 @@ static std::vector<uint16_t> rand_bf16(size_t n, float scale) { std::vector<uint
 
 static int run(int kernel, int epi, const Buf& A, const Buf& W, int M, int N, int K, const float* bias, const Buf* R, const Buf* G, Buf& C, Buf* C2,
                float* colsum, hipStream_t st) {
-  return spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, bias, nullptr, 1.0f, R ? R->d : nullptr, N, G ? G->d : nullptr, N, C.d, N, C2 ? C2->d : nullptr, N,
+  // GEMM_BENCH_LDA0=1: every row of A is row 0 (lda = 0): the A operand is cache-resident, what remains is the schedule itself
+  // (an upper bound for what hiding the first-touch latency of A could buy)
+  static const long lda = getenv("GEMM_BENCH_LDA0") ? 0 : -1;
+  return spmm_gemm_nt(A.d, lda < 0 ? K : lda, W.d, K, M, N, K, 1, bias, nullptr, 1.0f, R ? R->d : nullptr, N, G ? G->d : nullptr, N, C.d, N, C2 ? C2->d : nullptr, N,
                       epi, colsum, kernel, st);
 }
 
@@ -264,12 +267,18 @@ int main(int argc, char** argv) {
     prof.alloc(256 * 16 * 8 * 8);
     CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
     CK(hipMemset(G.d, 0, G.bytes));
+    const long lda = getenv("GEMM_BENCH_LDA0") ? 0 : K;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0.f;
     for (int it = 0; it < 3; ++it) {
       CK(hipMemset(prof.d, 0, prof.bytes));
-      int rc = spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? G.d : nullptr, N, C.d, N,
+      CK(hipEventRecord(e0, 0));
+      int rc = spmm_gemm_nt(A.d, lda, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? G.d : nullptr, N, C.d, N,
                             (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? C2.d : nullptr, N, epi, (float*)prof.d, 8, 0);
+      CK(hipEventRecord(e1, 0));
       if (rc) { printf("rc=%d %s\n", rc, spmm_last_error()); return 1; }
       CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ms, e0, e1));
     }
     std::vector<unsigned long long> h(256 * 16 * 8);
     CK(hipMemcpy(h.data(), prof.d, prof.bytes, hipMemcpyDeviceToHost));
@@ -283,7 +292,22 @@ int main(int argc, char** argv) {
         ++cnt;
         if (i < 15 && t[8]) { tot += (double)(t[8] - t[0]); ++cnt_tot; }
       }
+    unsigned long long first = ~0ull, last = 0, first_max = 0, last_min = ~0ull;
+    for (int wg = 0; wg < 256; ++wg) {
+      unsigned long long f = 0, l = 0;
+      for (int i = 0; i < 16; ++i) {
+        const unsigned long long* t = &h[((size_t)wg * 16 + i) * 8];
+        if (!t[0] || !t[4]) continue;
+        if (!f) f = t[0];
+        l = t[4];
+      }
+      if (!f) continue;
+      first = std::min(first, f); first_max = std::max(first_max, f); last = std::max(last, l); last_min = std::min(last_min, l);
+    }
+    const double span = (double)(last - first);
     printf("avg over %ld tiles: mainloop %.0f  epilogue %.0f  | tile period %.0f (ticks)\n", cnt, main_s / cnt, epi_s / cnt, tot / (cnt_tot ? cnt_tot : 1));
+    printf("launch %.1f us; stamps span %.0f ticks (=> >= %.0f ticks/us); first tile starts spread over %.0f ticks, last tile ends over %.0f ticks\n",
+           ms * 1e3, span, span / (ms * 1e3), (double)(first_max - first), (double)(last - last_min));
     return 0;
   }
   fprintf(stderr, "usage: gemm_bench check | time M N K [epi] [rounds] | step | prof M N K [epi]\n");
