@@ -133,8 +133,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (NOT the benchmark configuration)")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (E4M3) FFN forward GEMMs (BASELINE configs[4] tier; NOT the headline configuration)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
     args = ap.parse_args()
+    if args.fp8:
+        os.environ["SPMM_FP8"] = "1"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: start one as a CHILD process (never exec from a process that may touch the GPU) and pass its
@@ -317,7 +320,7 @@ def main():
     value = world * B / (dt / args.steps)
     out = {"metric": "pretrain molecules/sec", "value": round(value, 2), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16", "data": "synthetic", "step_ms": spread,
+           "dtype": "fp8 (E4M3 FFN forward GEMMs) + bf16" if args.fp8 else "bf16", "data": "synthetic", "step_ms": spread,
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}"},

@@ -210,6 +210,26 @@ def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None,
                _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), _st())
 
 
+def quant_rows_fp8(x, q=None, scale=None):
+    """Per-row E4M3 quantisation: returns (q uint8 [rows, K], scale fp32 [rows]) with x ~ q * scale[:, None]."""
+    rows, K = x.shape
+    assert x.dtype in (BF16, torch.float32) and x.stride(1) == 1
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
+    _call("spmm_quant_rows_fp8", _p(x), int(x.dtype == torch.float32), _row_stride(x), rows, K, _p(q), _row_stride(q), _p(scale), _st())
+    return q, scale
+
+
+def gemm_nt_f8(A8, sa, W8, sw, C, *, bias=None, epi=EPI_BF16, R=None, C2=None):
+    """C[M,N] (bf16) = epi((A8 @ W8^T) * sa[:, None] * sw[None, :] + bias): fp8 (E4M3) operands as uint8, fp32 accumulation."""
+    M, K = A8.shape
+    N = W8.shape[0]
+    assert A8.dtype == torch.uint8 and W8.dtype == torch.uint8 and W8.shape[1] == K and C.dtype == BF16
+    _call("spmm_gemm_nt_f8", _p(A8), _row_stride(A8), _p(sa), _p(W8), _row_stride(W8), _p(sw), M, N, K, _p(bias), _p(R),
+          0 if R is None else _row_stride(R), _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), int(epi), _st())
+    return C
+
+
 def rows_linear(x, W, bias, out, *, act=0):
     """out[r,n] = act(bias[n] + x[r,:] . W[n,:]) in fp32; x [rows, K] fp32 or bf16 (row stride free), W [N, K] fp32 contiguous."""
     rows, K = x.shape

@@ -68,6 +68,7 @@ class ParamStore:
             elif k == "ptr":
                 self.buffers[n] = torch.zeros(1, dtype=torch.long, device=device)
         self._wT: Dict[str, torch.Tensor] = {}     # transposed bf16 shadows for dgrad, keyed by (fused) name
+        self._w8: Dict[str, tuple] = {}            # fp8 tier: name -> (fp32 master view, E4M3 bytes, per-row scales)
 
     # ---- views -----------------------------------------------------------------------------------------------
     def _resolve(self, name: str):
@@ -127,6 +128,16 @@ class ParamStore:
             ops.cast_transpose(src, None, self._wT[key])
         return self._wT[key]
 
+    def w8(self, name: str):
+        """(fp8 E4M3 bytes [out,in], per-output-row scale [out]) of a weight for the fp8 tier (spmm_gemm_nt_f8); quantised from the
+        fp32 master (student or momentum twin) on first use and again by refresh_shadows()."""
+        if name not in self._w8:
+            src = self.w(name)
+            self._w8[name] = (src, torch.empty(src.shape, dtype=torch.uint8, device=self.device),
+                              torch.empty(src.shape[0], dtype=torch.float32, device=self.device))
+            ops.quant_rows_fp8(src, self._w8[name][1], self._w8[name][2])
+        return self._w8[name][1], self._w8[name][2]
+
     # ---- maintenance -----------------------------------------------------------------------------------------
     def refresh_shadows(self, transposed_only: bool = False):
         """bf16 shadows <- fp32 masters (after load_state_dict / optimiser step).  AdamW and the EMA kernels already
@@ -134,6 +145,8 @@ class ParamStore:
         if not transposed_only:
             ops.cast_f32_bf16(self.flat, self.shadow)
             ops.cast_f32_bf16(self.flat_m, self.shadow_m)
+        for src, q, sc in self._w8.values():
+            ops.quant_rows_fp8(src, q, sc)
         srcs = getattr(self, "_wT_src", {})
         if not srcs:
             return

@@ -175,6 +175,45 @@ def test_forward_matches_oracle_h768(env):
         assert err < tol, key
 
 
+def test_fp8_ffn_forward_tracks_the_bf16_pipeline(env):
+    """fp8 tier (BASELINE configs[4], SPMM_FP8=1): the FFN GEMMs of every forward read E4M3 operands (per-token / per-output-channel
+    scales, fp32 accumulation).  Full depth (12+6 layers, H=768), B=8, Lt=32, dropout off, recorded draws: the four losses against
+    the bf16 pipeline on the same weights and against the fp32 oracle, and two training steps that must still reduce the loss.
+    Stated tolerance vs bf16 (1.5 x the measured 6.8e-4 / 9.7e-2 / 1.8e-2 / 4.2e-3; E4M3 carries 3 mantissa bits and the
+    property-regression loss is an MSE x 5 on O(1) predictions): 5e-3 (mlm), 0.15 (5 mpm), 3e-2 (ita), 1e-2 (itm)."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env, layers=(12, 6, 6), Q=1024)
+    sd = O.init_state_dict(ocfg, seed=11)
+    B, Lt = 8, 32
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=42)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(4))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(3))
+    out = {}
+    for mode in ("bf16", "fp8"):
+        m = _mk(SPMM, cfg, sd).eval()
+        m.engine.fp8 = mode == "fp8"
+        with torch.no_grad():
+            out[mode] = np.array([float(x) for x in m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))])
+    d = np.abs(out["fp8"] - out["bf16"])
+    print("bf16", out["bf16"], "fp8", out["fp8"], "diff", d)
+    assert np.all(np.isfinite(out["fp8"])) and np.all(d < np.array([5e-3, 0.15, 3e-2, 1e-2])), d
+    assert d.max() > 0                                           # the fp8 path really ran
+    # training: fused steps with the fp8 forward (bf16 backward on the saved activations) still descend
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20, 'cooldown_epochs': 0}
+    tc = {'embed_dim': 256, 'temp': 0.07, 'queue_size': 1024, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
+          'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
+    m = _mk(SPMM, cfg, sd, train_cfg=tc).train()
+    m.engine.fp8 = True
+    first = last = None
+    for it in range(6):
+        l = [float(x) for x in m.fused_step(*_cuda(prop, ids, mask), 0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))]
+        assert all(np.isfinite(l)), l
+        first = sum(l) if first is None else first
+        last = sum(l)
+    print("fp8-forward training: total loss", first, "->", last)
+    assert last < first
+
+
 def test_full_depth_forward_matches_oracle(env):
     """The published architecture (12 text layers with 6 fusion + 6 PV layers, H=768), random-init weights, B=8, Lt=32,
     queue 1024: bf16 pipeline vs the fp32 CPU oracle.  This is the depth at which bf16 rounding has accumulated most."""

@@ -63,10 +63,12 @@ for nm, nseq, Lq, Lkv, cross in (("self PV", 512, 54, 54, False), ("self text", 
 def gemm(Mg, N, K, epi=ops.EPI_BF16, two=False):
     A = torch.randn(Mg, K, device=dev).to(BF); W = torch.randn(N, K, device=dev).to(BF); bias = torch.zeros(N, device=dev)
     C = torch.empty(Mg, N, device=dev, dtype=BF); C2 = torch.empty(Mg, N, device=dev, dtype=BF) if two else None
-    G = torch.randn(Mg, N, device=dev).to(BF) if epi == ops.EPI_GELU_GRAD else None
+    G = torch.randn(Mg, N, device=dev).to(BF) if epi in (ops.EPI_GELU_GRAD, ops.EPI_MUL) else None
     by = (Mg * K + N * K + Mg * N * (2 if two else 1) + (Mg * N if G is not None else 0)) * 2
-    add(f"gemm_nt epi={epi}{' +pre' if two else ''}", f"{Mg}x{N}x{K}", lambda: ops.gemm_nt(A, W, C, bias=None if G is not None else bias, epi=epi, C2=C2, G=G), by, 2.0 * Mg * N * K)
-gemm(M, H, H); gemm(M, 3 * H, H); gemm(M, I, H, ops.EPI_GELU, True); gemm(M, H, I); gemm(M, I, H, ops.EPI_GELU_GRAD)
+    nm = {ops.EPI_BF16: "plain", ops.EPI_GELU: "erf-GELU (+pre-activation)", ops.EPI_GELU_DERIV: "erf-GELU + gelu' (FFN forward)",
+          ops.EPI_MUL: "x G (FFN backward)", ops.EPI_GELU_GRAD: "x gelu'(G) (LM-head transform backward)"}[epi]
+    add(f"gemm_nt {nm}", f"{Mg}x{N}x{K}", lambda: ops.gemm_nt(A, W, C, bias=None if G is not None else bias, epi=epi, C2=C2, G=G), by, 2.0 * Mg * N * K)
+gemm(M, H, H); gemm(M, 3 * H, H); gemm(M, I, H, ops.EPI_GELU_DERIV, True); gemm(M, H, I); gemm(M, I, H, ops.EPI_MUL); gemm(M, I, H, ops.EPI_GELU, False)
 for (N, K) in ((H, H), (I, H), (H, I)):
     A = torch.randn(M, N, device=dev).to(BF); B = torch.randn(M, K, device=dev).to(BF); C = torch.zeros(N, K, device=dev)
     add("gemm_tn (weight gradient)", f"{M}: {N}x{K}", lambda: ops.gemm_tn(A, B, C), (M * N + M * K) * 2 + N * K * 4, 2.0 * M * N * K)
@@ -91,6 +93,7 @@ add("decode_attn (K/V cache gather)", f"{R} rows x {t} keys", lambda: ops.decode
     R * 12 * t * 256)
 
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "roofline_table.md")
+rows.sort(key=lambda r: 0)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
     f.write("| kernel | shape | us / launch | GB/s | TFLOP/s | bound | fraction of peak |\n|---|---|---|---|---|---|---|\n")
