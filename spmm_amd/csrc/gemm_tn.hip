@@ -410,26 +410,43 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
 
   // ---- epilogue: acc[h][mi][kh*2+ni][j] = D[k][n], n = n0 + h*128 + wr*64 + mi*16 + (lane & 15),
   //      k = k0 + kh*128 + wc*32 + ni*16 + 4*(lane >> 4) + j
+  // Straight from the accumulators a store instruction would write 16 rows x 64 B (12 B/clk/CU, tools/store_bench: 22 k cycles
+  // for the 256-KiB tile); the ring is free now, so each quarter (64 output rows x 256 columns) is transposed through LDS
+  // (row pitch 260 floats: the 16 rows of a lane group land in disjoint banks) and leaves as whole 1-KiB rows, 8 rows per wave.
   float* out = SLAB ? p.slab + (long)blockIdx.z * p.N * p.K : p.C;
   const long ldo = SLAB ? p.K : p.ldc;
+  float* tl = (float*)smem_tp;
+  constexpr int TPITCH = 260;
+  const int kcol = k0 + lane * 4;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int n = n0 + h * 128 + wr * 64 + mi * 16 + (lane & 15);
-      if (n >= p.N) continue;
+    for (int r = 0; r < 2; ++r) {
+      __syncthreads();                                   // the ring (first pass) / the previous quarter's rows have been read
+      if (wr == r) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = k0 + (q >> 1) * 128 + wc * 32 + (q & 1) * 16 + 4 * (lane >> 4);
-        if (k >= p.K) continue;
-        f32x4* dst = (f32x4*)(out + (long)n * ldo + k);
-        f32x4 v = acc[h][mi][q];
-        v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
-        if constexpr (!SLAB) {
-          const f32x4 o = *dst;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = acc[h][mi][q];
+            v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+            *(f32x4*)(tl + (mi * 16 + (lane & 15)) * TPITCH + (q >> 1) * 128 + wc * 32 + (q & 1) * 16 + 4 * (lane >> 4)) = v;
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wave * 8 + i;                    // row of the quarter
+        const int n = n0 + h * 128 + r * 64 + row;
+        if (n < p.N && kcol < p.K) {
+          f32x4 v = *(const f32x4*)(tl + row * TPITCH + lane * 4);
+          f32x4* dst = (f32x4*)(out + (long)n * ldo + kcol);
+          if constexpr (!SLAB) {
+            const f32x4 o = *dst;
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          }
+          *dst = v;
         }
-        *dst = v;
       }
     }
 }
