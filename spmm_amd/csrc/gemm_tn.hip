@@ -34,6 +34,7 @@ struct TnP {
   float* C; long ldc;         // direct mode: C[n*ldc + k] += ...
   float* slab;                // slab mode: slab[z][n][k] (dense N*K)
   float alpha;
+  int nsplit;                 // 8-phase kernel: > 0 = 1-D grid of tiles x nsplit workgroups in XCD-contiguous order (else grid.z = slice)
 };
 
 // physical byte offset of logical 16-B chunk `c16` (8 columns) of row `row`
@@ -237,9 +238,24 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
-  const int tile = blockIdx.x;
+  // Which tile and which row slice?  Every tile re-reads the A panel of its n-tile and the B panel of its k-tile for its slice of
+  // rows, so the workgroups that share panels must share an L2.  Workgroup b runs on XCD b % 8 (round-robin dispatch): each XCD is
+  // given a CONTIGUOUS range of the (slice-major, then row-major tile) order, i.e. its ~32 resident workgroups are one slice's
+  // consecutive tiles -- e.g. 32 tiles of a 12 x 3 grid touch 11 + 3 panels instead of 64.  (With the tiles of a slice dealt
+  // round-robin over the eight XCDs every panel crossed the fabric once per tile: 25-30 % of the launch, GEMM_BENCH_LDA0 in
+  // tools/gemm_bench.)
+  int tile, zsplit;
+  if (p.nsplit > 0) {
+    const int tiles = ntn * ntk, G = tiles * p.nsplit;
+    const int b = blockIdx.x, q = G >> 3, r = G & 7, xcd = b & 7, i = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    zsplit = L / tiles;
+    tile = L - zsplit * tiles;
+  } else {
+    tile = blockIdx.x; zsplit = blockIdx.z;
+  }
   const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
-  const int mbeg = blockIdx.z * p.rsplit;
+  const int mbeg = zsplit * p.rsplit;
   const int mend = min(p.M, mbeg + p.rsplit);
   const int nk = (mend - mbeg) / 64;                   // steps of 64 rows: even and >= 2 (the launcher hands out multiples of 128 rows)
   (void)ntn;
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
   // Straight from the accumulators a store instruction would write 16 rows x 64 B (12 B/clk/CU, tools/store_bench: 22 k cycles
   // for the 256-KiB tile); the ring is free now, so each quarter (64 output rows x 256 columns) is transposed through LDS
   // (row pitch 260 floats: the 16 rows of a lane group land in disjoint banks) and leaves as whole 1-KiB rows, 8 rows per wave.
-  float* out = SLAB ? p.slab + (long)blockIdx.z * p.N * p.K : p.C;
+  float* out = SLAB ? p.slab + (long)zsplit * p.N * p.K : p.C;
   const long ldo = SLAB ? p.K : p.ldc;
   float* tl = (float*)smem_tp;
   constexpr int TPITCH = 260;
@@ -560,8 +576,10 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
                             float* C, long ldc, float* workspace, int kernel, spmm_stream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(N % 4 == 0 && K % 4 == 0 && ldc % 4 == 0, "spmm_gemm_tn: N=%d K=%d ldc=%ld must be multiples of 4", N, K, ldc);
+#ifndef P8_PROFILE   // (the profiling build of tools/ aliases all rows onto row 0 with lda = ldb = 0: cache-resident operands)
   SPMM_CHECK_SHAPE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((N + 7) & ~7) && ldb >= ((K + 7) & ~7),
                    "spmm_gemm_tn: lda=%ld / ldb=%ld must be multiples of 8 covering the 8-column chunks of N=%d / K=%d", lda, ldb, N, K);
+#endif
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "spmm_gemm_tn: A/B must be 16-B aligned");
   SPMM_CHECK_SHAPE(kernel == 0 || kernel == 1 || kernel == 8, "spmm_gemm_tn: unknown kernel selector %d", kernel);
   SPMM_CHECK_SHAPE(kernel != 8 || (N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8), "spmm_gemm_tn: the 8-phase kernel needs N %% 8 == 0 and K %% 8 == 0");
@@ -572,7 +590,7 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
                    "spmm_gemm_tn: the 8-phase kernel addresses its operands with 32-bit byte offsets (< 4 GiB)");
   TnP p;
   p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
-  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha;
+  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha; p.nsplit = 0;
   auto reduce = [&](int nsplit) {
     long blocks = ((long)N * (K / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -593,6 +611,8 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
     const int ns = (M8 + rs - 1) / rs;
     p.M = M8; p.rsplit = rs;
     dim3 grid(((N + 255) / 256) * ((K + 255) / 256), 1, ns);
+    p.nsplit = ns;
+    grid = dim3(grid.x * ns, 1, 1);
     if (ns > 1) {
       hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
       reduce(ns);

@@ -173,7 +173,9 @@ static int tn_run(int kernel, const Buf& A, const Buf& B, int M, int N, int K, B
   const int splits = spmm_gemm_tn_splits(M, N, K, kernel);
   if (splits_out) *splits_out = splits;
   if ((size_t)spmm_gemm_tn_workspace_bytes(M, N, K, splits) > ws.bytes) { printf("workspace too small\n"); return 1; }
-  return spmm_gemm_tn(A.d, N, B.d, K, M, N, K, splits, 1.0f, (float*)C.d, K, (float*)ws.d, kernel, 0);
+  // GEMM_BENCH_LDA0=1: all rows of both operands alias row 0 (cache-resident operands: what the schedule does without HBM / fabric)
+  static const bool ld0 = getenv("GEMM_BENCH_LDA0") != nullptr;
+  return spmm_gemm_tn(A.d, ld0 ? 0 : N, B.d, ld0 ? 0 : K, M, N, K, splits, 1.0f, (float*)C.d, K, (float*)ws.d, kernel, 0);
 }
 static int cmd_tncheck() {
   int fails = 0;
