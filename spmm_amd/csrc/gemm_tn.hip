@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 // out[c] += sum_r x[r][c]   (bias gradients).  A workgroup reduces a CS_ROWS-row x 128-column strip: 16 column groups of
 // 8 bf16 (16-byte loads) x 16 row lanes, eight loads in flight per thread, LDS tree over the row lanes, one atomicAdd per column.
-constexpr int CS_ROWS = 1024;
+constexpr int CS_ROWS = 256;    // (1024-row strips were measured SLOWER: 37 vs 26 us per launch -- fewer workgroups, less memory-level parallelism)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, float* __restrict__ out) {
   __shared__ float red[16][129];
   const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
