@@ -35,6 +35,7 @@ struct TnP {
   float* slab;                // slab mode: slab[z][n][k] (dense N*K)
   float alpha;
   int nsplit;                 // 8-phase kernel: > 0 = 1-D grid of tiles x nsplit workgroups in XCD-contiguous order (else grid.z = slice)
+  int rlast, ndup;            // 8-phase kernel: the LAST slice is rows [M - rlast, M); its first ndup rows belong to the slice before (masked)
 };
 
 // physical byte offset of logical 16-B chunk `c16` (8 columns) of row `row`
@@ -255,9 +256,13 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
     tile = blockIdx.x; zsplit = blockIdx.z;
   }
   const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
-  const int mbeg = zsplit * p.rsplit;
-  const int mend = min(p.M, mbeg + p.rsplit);
-  const int nk = (mend - mbeg) / 64;                   // steps of 64 rows: even and >= 2 (the launcher hands out multiples of 128 rows)
+  // Row slices are multiples of 128 rows (pairs of 64-row steps).  M is not: the last slice is moved back to END at row M, and the
+  // ndup rows it then shares with the slice before are zeroed in LDS (A side) after they land -- LDS-DMA cannot zero-fill, and
+  // reading past row M is not an option.
+  const bool lastz = p.nsplit > 0 && zsplit == p.nsplit - 1;
+  const int mbeg = lastz ? p.M - p.rlast : zsplit * p.rsplit;
+  const int nk = (lastz ? p.rlast : min(p.M, mbeg + p.rsplit) - mbeg) / 64;     // steps of 64 rows: even and >= 2
+  const int ndup = lastz ? p.ndup : 0;
   (void)ntn;
 
   f32x4 acc[2][4][4];                                  // [n half][n block mi][k half * 2 + k block]
@@ -371,6 +376,18 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
   TP_STG_A(0, 0, 0); TP_STG_B(0, 0, 0); TP_STG_B(1, 0, 0); TP_STG_A(1, 0, 0);
   TP_STG_B(0, 1, 1); TP_STG_A(0, 1, 1); TP_STG_B(1, 1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  // rows of step S (buffer S & 1) this thread staged: i * 32 + (tid >> 4) for DMA instruction i, both column halves of A
+#define TP_MASK(S)                                                                                                   \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                 \
+      if ((S) * 64 + i_ * 32 + (tid >> 4) < ndup) {                                                                  \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                             \
+          *(LDS_AS f32x4*)(uintptr_t)(lds0 + ((S) & 1) * TP_BUF + h_ * TP_HT + wave * 1024 + lane * 16 + i_ * 8192) = \
+              f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
+      }                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+  } while (0)
+  if (ndup > 0) TP_MASK(0);                            // (wave-uniform; step 0 has landed: this thread's own pieces)
   TP_BAR();
   TP_SB();
   if (wr == 1) TP_BAR();                               // the second wave row runs one barrier behind the first
@@ -395,6 +412,7 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (kt == 0 && ndup > 64) TP_MASK(1);                                         // step 1 has landed; it is read from phase 5 on
     TP_COMPUTE(1, 0, tb0);
     // ---------------- step kt+1 (buffer 1)
     TP_RD_B(1, 0, tb0); TP_SB(); TP_RD_A(1, 0);                                   // phase 5
@@ -414,6 +432,7 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) {
     TP_COMPUTE(1, 0, tb0);
   }
   if (wr == 0) TP_BAR();
+#undef TP_MASK
 #undef TP_STG
 #undef TP_STG_A
 #undef TP_STG_B
@@ -606,22 +625,26 @@ extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, in
       spmm_set_error("spmm_gemm_tn: cannot raise dynamic LDS to %d: %s", TP_LDS, hipGetErrorString(attr_rc));
       return SPMM_ERR_LAUNCH;
     }
-    const int M8 = M & ~127;                            // rows the 8-phase kernel takes: whole pairs of 64-row steps
-    int rs = (((M8 / 128) + splits - 1) / splits) * 128;
-    const int ns = (M8 + rs - 1) / rs;
-    p.M = M8; p.rsplit = rs;
-    dim3 grid(((N + 255) / 256) * ((K + 255) / 256), 1, ns);
-    p.nsplit = ns;
-    grid = dim3(grid.x * ns, 1, 1);
+    // slices of rs rows (multiples of 128); the last one ends at row M and is masked where it overlaps the one before
+    int rs = ((((M + 127) / 128) + splits - 1) / splits) * 128;
+    const int ns = (M + rs - 1) / rs;
+    const int over = ns * rs - M;                       // rows the uniform slicing would run past M
+    p.rsplit = rs; p.nsplit = ns;
+    p.rlast = rs - (over / 128) * 128;                  // whole 128-row pairs past M are dropped, the rest is overlap
+    p.ndup = over % 128;
+    if (ns == 1) { p.rlast = ((M + 127) / 128) * 128 > M ? (M / 128) * 128 : M; p.ndup = 0; }   // a single slice cannot overlap anything
+    const int single_left = ns == 1 ? M - p.rlast : 0;
+    dim3 grid(((N + 255) / 256) * ((K + 255) / 256) * ns, 1, 1);
     if (ns > 1) {
       hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
       reduce(ns);
     } else {
       hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, grid, dim3(512), TP_LDS, stream, p);
     }
-    if (M8 < M) {                                       // the < 128 leftover rows: one pass of the 128x128 kernel, accumulated into C
+    if (single_left > 0) {                              // one slice = rows [M % 128, M); the first M % 128 rows: one pass of the 128x128 kernel, accumulated into C
       TnP q = p;
-      q.A = (const bf16*)A + (long)M8 * lda; q.B = (const bf16*)B + (long)M8 * ldb; q.M = M - M8; q.rsplit = ((M - M8 + BR - 1) / BR) * BR;
+      q.nsplit = 0;
+      q.M = single_left; q.rsplit = ((single_left + BR - 1) / BR) * BR;
       hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(((N + BT - 1) / BT) * ((K + BT - 1) / BT), 1, 1), dim3(256), 0, stream, q);
     }
     SPMM_LAUNCH_CHECK("spmm_gemm_tn(8-phase)");

@@ -152,7 +152,10 @@ def test_gemm_f32_epilogues_and_splitk(ops):
 
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (216, 128, 256, 1), (216, 128, 256, 3), (6912, 768, 768, None),
                                           (4096, 2304, 768, None), (1000, 300, 128, 2), (130, 64, 192, 1), (8192, 768, 3072, None),
-                                          (2100, 300, 520, 2), (13824, 768, 768, None)])
+                                          (2100, 300, 520, 2), (13824, 768, 768, None),
+                                          # M % 128 = 1, 63, 64, 65, 127, 32: the last row slice of the 8-phase kernel overlaps the one before (masked in LDS)
+                                          (4097, 768, 768, None), (8255, 768, 768, None), (8256, 2304, 768, None), (8257, 768, 3072, None),
+                                          (4223, 768, 768, None), (84256, 768, 768, None), (5000, 768, 768, 1), (5000, 768, 768, 3)])
 @pytest.mark.parametrize("kernel", [1, 8])      # 128x128 tiles | 256x256 tiles on the 8-phase schedule (+ the 128x128 kernel for M % 128 rows)
 def test_gemm_tn_weight_gradient(ops, M, N, K, splits, kernel):
     if kernel == 8 and (N % 8 or K % 8):
