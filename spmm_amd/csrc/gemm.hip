@@ -777,8 +777,13 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
 #ifdef P8_NOSTORE          // experiment (tools/Makefile gemm_bench_nostore): what the stores of the epilogue cost the NEXT tile's DMA waits
       if (p.M < 0) {
 #endif
+#ifdef P8_STORE_POLICY     // experiment: cache policy of the C stores ("nt", "sc1", "sc0 sc1")
+      if (ok1) asm volatile("global_store_dwordx4 %0, %1, off " P8_STORE_POLICY :: "v"(cp + (long)blk * 16 * p.ldc), "v"(o1) : "memory");
+      if (ok2) asm volatile("global_store_dwordx4 %0, %1, off " P8_STORE_POLICY :: "v"(cp + (long)blk * 16 * p.ldc + 8 * p.ldc), "v"(o2) : "memory");
+#else
       if (ok1) *(u32x4*)(cp + (long)blk * 16 * p.ldc) = o1;
       if (ok2) *(u32x4*)(cp + (long)blk * 16 * p.ldc + 8 * p.ldc) = o2;
+#endif
 #ifdef P8_NOSTORE
       }
 #endif

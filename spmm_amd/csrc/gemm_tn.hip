@@ -572,8 +572,9 @@ static int tn_pick(int M, int N, int K, int kernel) {
   if (kernel == 1 || kernel == 8) return kernel;
   const bool ok8 = N % 8 == 0 && K % 8 == 0 && N >= 256 && K >= 256;
   const long tiles8 = (long)((N + 255) / 256) * ((K + 255) / 256);
-  // the big tile needs >= ~1000 reduction rows per workgroup to amortise its 256-KiB fp32 tile store and 14-load prologue
-  return (ok8 && M >= 4096 && (long)M * tiles8 >= 256L * 1024) ? 8 : 1;
+  // the big tile needs enough reduction rows per workgroup to amortise its 256-KiB fp32 tile store and 14-load prologue: measured
+  // cross-over (tools/gemm_bench tntime, k1 vs k8) between M x tiles = 124 k (6912 x 18, 13824 x 9: 128x128 wins) and 147 k (16384 x 9)
+  return (ok8 && M >= 4096 && (long)M * tiles8 >= 136L * 1024) ? 8 : 1;
 }
 
 extern "C" int spmm_gemm_tn_splits(int M, int N, int K, int kernel) {

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <math.h>
 #include <vector>
 #include <array>
@@ -265,7 +266,64 @@ static int cmd_f8time(int M, int N, int K, int epi, int rounds) {
   return 0;
 }
 
+// `sustain M N K [epi] [launches]`: back-to-back launches of one GEMM, TF/s per block of 100 -- does the rate of the first
+// milliseconds (what `time` reports) hold once the chip has been at full MFMA load for a second?  With GEMM_BENCH_ROTATE=n the
+// launches rotate over n different A / C buffer pairs (as the training step's GEMMs do) instead of re-using one.
+static int cmd_sustain(int M, int N, int K, int epi, int launches) {
+  const int nrot = getenv("GEMM_BENCH_ROTATE") ? atoi(getenv("GEMM_BENCH_ROTATE")) : 1;
+  auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
+  std::vector<Buf> A(nrot), C(nrot);
+  Buf W, C2, G;
+  for (int i = 0; i < nrot; ++i) { A[i].alloc(hA.size() * 2); C[i].alloc((size_t)M * N * 2); CK(hipMemcpy(A[i].d, hA.data(), A[i].bytes, hipMemcpyHostToDevice)); }
+  W.alloc(hW.size() * 2); C2.alloc((size_t)M * N * 2); G.alloc((size_t)M * N * 2);
+  CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice)); CK(hipMemset(G.d, 0, G.bytes));
+  const int nb = launches / 100;
+  // GEMM_BENCH_BETWEEN=1: a 256-MiB memset between launches (a memory-bound kernel that also sweeps the caches);
+  // GEMM_BENCH_BETWEEN=2: the GPU idles ~100 us between launches (the host waits); =3: a read-only sweep of 256 MiB (column sums:
+  // the caches end up full of CLEAN lines).  Only the GEMMs are timed.
+  const int between = getenv("GEMM_BENCH_BETWEEN") ? atoi(getenv("GEMM_BENCH_BETWEEN")) : 0;
+  if (between) {
+    Buf scratch, cs; scratch.alloc((size_t)(256 + 16) << 20); cs.alloc(768 * 4); CK(hipMemset(scratch.d, 0, scratch.bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double tot = 0; int n = 0;
+    std::vector<double> blocks;
+    for (int i = 0; i < launches; ++i) {
+      const int r = i % nrot;
+      if (between == 1) CK(hipMemsetAsync(scratch.d, i & 255, scratch.bytes, 0));
+      else if (between == 3) { if (spmm_colsum_bf16(scratch.d, 768, 174762, 768, (float*)cs.d, 0)) { printf("%s\n", spmm_last_error()); return 1; } }   // read-only sweep of 256 MiB
+      else { CK(hipDeviceSynchronize()); struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr); }
+      CK(hipEventRecord(e0, 0));
+      if (run(8, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
+              (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; ++n;
+      if (n == 100) { blocks.push_back(100 * 2.0 * M * N * K / (tot * 1e-3) / 1e12); tot = 0; n = 0; }
+    }
+    printf("%d x %d x %d epi %d, %d buffer pair(s), between=%d: TF/s per 100 launches:", M, N, K, epi, nrot, between);
+    for (double b : blocks) printf(" %.0f", b);
+    printf("\n");
+    return 0;
+  }
+  std::vector<hipEvent_t> ev(nb + 1);
+  for (auto& e : ev) CK(hipEventCreate(&e));
+  CK(hipEventRecord(ev[0], 0));
+  for (int b = 0; b < nb; ++b) {
+    for (int i = 0; i < 100; ++i) {
+      const int r = (b * 100 + i) % nrot;
+      if (run(8, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
+              (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; }
+    }
+    CK(hipEventRecord(ev[b + 1], 0));
+  }
+  CK(hipDeviceSynchronize());
+  printf("%d x %d x %d epi %d, %d buffer pair(s): TF/s per 100 launches:", M, N, K, epi, nrot);
+  for (int b = 0; b < nb; ++b) { float ms; CK(hipEventElapsedTime(&ms, ev[b], ev[b + 1])); printf(" %.0f", 100 * 2.0 * M * N * K / (ms * 1e-3) / 1e12); }
+  printf("\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 5 && !strcmp(argv[1], "sustain")) return cmd_sustain(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 2000);
   if (argc >= 5 && !strcmp(argv[1], "f8time")) return cmd_f8time(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 5);
   if (argc >= 2 && !strcmp(argv[1], "check")) return cmd_check();
   if (argc >= 2 && !strcmp(argv[1], "tncheck")) return cmd_tncheck();
