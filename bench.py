@@ -133,11 +133,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (NOT the benchmark configuration)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (dense text layout, one rank; implies --no-kernel-timing)")
     ap.add_argument("--fp8", action="store_true", help="fp8 (E4M3) FFN forward GEMMs (BASELINE configs[4] tier; NOT the headline configuration)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
     args = ap.parse_args()
     if args.fp8:
         os.environ["SPMM_FP8"] = "1"
+    if args.graph:
+        args.no_kernel_timing = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: start one as a CHILD process (never exec from a process that may touch the GPU) and pass its
@@ -197,6 +200,8 @@ def main():
 
     def one_step(i):
         prop, ids, mask = batches[i % len(batches)]
+        if args.graph:                   # the step as one hipGraph replay (dense text layout, single rank): NOT the headline configuration
+            return model.fused_step_graphed(prop, ids, mask, 0.4)
         return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync)
 
     for i in range(args.warmup):
@@ -344,7 +349,8 @@ def main():
            "dtype": "fp8 (E4M3 FFN forward GEMMs) + bf16" if args.fp8 else "bf16", "data": "synthetic", "step_ms": spread,
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
-                      "parallelism": f"dp{world}"},
+                      "parallelism": f"dp{world}", "schedule": "one hipGraph replay per step, dense text layout" if args.graph else
+                      "eager launches on three HIP streams, packed text rows"},
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
                                          - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= 128 else 0.0)) / 1e12, 2),

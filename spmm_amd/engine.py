@@ -62,7 +62,8 @@ class KVSource:
         idx = torch.cat(self._idx)
         order = torch.sort(idx, stable=True).indices
         start = torch.zeros(self.U + 1, dtype=torch.int32, device=idx.device)
-        start[1:] = torch.cumsum(torch.bincount(idx, minlength=self.U), 0)
+        counts = torch.zeros(self.U, dtype=torch.int64, device=idx.device).index_add_(0, idx, torch.ones_like(idx))
+        start[1:] = torch.cumsum(counts, 0)             # (torch.bincount reads max(idx) back to the host: a hidden sync per source)
         self.start, self.list = start, order.to(torch.int32)
         return self
 

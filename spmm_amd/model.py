@@ -59,9 +59,10 @@ class _FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.store.grad.zero_()
 
-    def step(self):
+    def step(self, fill_lr: bool = True):
         g = self.param_groups[0]
-        self.eng.lr.fill_(g["lr"])
+        if fill_lr:                                  # (a host value: set outside a captured graph, see SPMM.fused_step_graphed)
+            self.eng.lr.fill_(g["lr"])
         self.normsq.zero_()
         ops.grad_sqnorm(self.store.grad, self.normsq)
         ops.adamw_step(self.store.flat, self.store.grad, self.store.adam_m, self.store.adam_v, self.store.shadow, lr=self.eng.lr,
@@ -110,6 +111,7 @@ class SPMM(_Base):
         self.cfg = spmm_config if spmm_config is not None else SPMMConfig.from_reference_dict(config)
         self.no_train = no_train
         self._grad_sync = None
+        self._graphs = {}            # fused_step_graphed: shape -> "warm" | (CUDAGraph, static buffers)
         self.store = ParamStore(self.cfg, self.device_, train=not no_train)
         self.engine = PretrainStep(self.cfg, self.store, self.device_)
         self._param_names = []
@@ -338,6 +340,63 @@ class SPMM(_Base):
             if grad_sync is not None:
                 grad_sync(self.store.grad)
         opt.step()
+        return losses
+
+    def fused_step_graphed(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None):
+        """The same step as ONE hipGraph launch (single rank; SPMM_models.py:348-380 has no counterpart -- this removes the ~26 ms
+        of host enqueue per step).  Every step-varying scalar already lives in device memory (lr, alpha, dropout seed, Adam step
+        count, queue pointer, NaN flag); the three that come from the host are written before the replay.  The captured step uses
+        the DENSE text layout: the packed layout's row count changes with every batch and sizes ~120 GEMMs, a graph cannot follow
+        it -- so replay trades the packing gain (~26 % of the text rows at U{L/2..L} lengths) for a near-zero host cost.
+        First call of a shape: eager (lazy initialisations happen outside capture); second: capture + replay; then replay."""
+        eng, opt = self.engine, self.optimizers()
+        dev = self.device_
+        key = (tuple(ids.shape), mpm_mask is not None, neg_idx is not None, bool(self.training))
+        eng.train_mode = self.training
+        eng.alpha.fill_(float(alpha))
+        eng.gscale.fill_(1.0)
+        eng.lr.fill_(opt.param_groups[0]["lr"])
+        st = self._graphs.get(key)
+        if st is None:                                   # first step of this shape: eager, dense layout
+            pack, eng.pack_text = eng.pack_text, False
+            try:
+                losses = self._step_body(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask, neg_idx)
+            finally:
+                eng.pack_text = pack
+            self._graphs[key] = "warm"
+            return losses
+        if st == "warm":
+            static = dict(prop=prop.to(dev).clone(), ids=ids.to(dev).clone(), mask=mask.to(dev).clone(),
+                          mpm=None if mpm_mask is None else mpm_mask.to(dev).clone(),
+                          neg=None if neg_idx is None else tuple(t.to(dev).clone() for t in neg_idx))
+            pack, eng.pack_text = eng.pack_text, False
+            graph = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph):
+                    static["losses"] = self._step_body(static["prop"], static["ids"], static["mask"], static["mpm"], static["neg"])
+            finally:
+                eng.pack_text = pack
+            st = self._graphs[key] = (graph, static)
+        graph, static = st
+        static["prop"].copy_(prop, non_blocking=True)
+        static["ids"].copy_(ids, non_blocking=True)
+        static["mask"].copy_(mask, non_blocking=True)
+        if static["mpm"] is not None:
+            static["mpm"].copy_(mpm_mask, non_blocking=True)
+        if static["neg"] is not None:
+            for d, t in zip(static["neg"], neg_idx):
+                d.copy_(t, non_blocking=True)
+        graph.replay()
+        return static["losses"]
+
+    def _step_body(self, prop, ids, mask, mpm_mask, neg_idx):
+        """zero_grad -> forward -> backward -> clip -> AdamW on device-resident scalars only (what a hipGraph can hold)."""
+        eng, opt = self.engine, self.optimizers()
+        self.store.grad.zero_()
+        losses = eng.forward(prop, ids, mask, mpm_mask=mpm_mask, neg_idx=neg_idx, gather=None)
+        eng.backward()
+        opt.step(fill_lr=False)
         return losses
 
     def training_step(self, train_batch, batch_idx):

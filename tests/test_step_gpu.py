@@ -826,6 +826,38 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
     assert (m.store.flat - want_flat).abs().max().item() < 2.5e-3            # one AdamW step at lr 1e-3: sign flips of ~0 gradients move a weight by <= 2 lr
 
 
+def test_training_step_as_one_hipgraph(env):
+    """SPMM.fused_step_graphed: the whole step (zero_grad, forward, backward, clip, AdamW, EMA, enqueue) captured once and replayed.
+    Against the eager run of the same dense-layout step on a twin model: identical batches and draws, six steps -- the losses
+    of every step agree to the run-to-run noise of the fp32 atomic sums as six training steps amplify it (rtol 3e-3; 7e-4 seen) and so
+    do the weights at the end; the host
+    side of a replay costs a few hundred microseconds."""
+    import time
+    O = env[0]
+    batches = []
+    for i in range(6):
+        prop, ids, mask = O.synthetic_batch(8, 24, seed=100 + i)
+        mpm = (torch.rand(8, 53, generator=torch.Generator().manual_seed(i)) < 0.5).float()
+        neg = (torch.arange(8).roll(1 + i % 3), torch.arange(8).roll(2 + i % 3))
+        batches.append(_cuda(prop, ids, mask, mpm, *neg))
+    eager, graphed = _tiny_train_model(env), _tiny_train_model(env)
+    eager.engine.pack_text = False
+    le, lg, host = [], [], []
+    for i, (prop, ids, mask, mpm, n0, n1) in enumerate(batches):
+        le.append([float(x) for x in eager.fused_step(prop, ids, mask, 0.1 * i, mpm_mask=mpm, neg_idx=(n0, n1))])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = graphed.fused_step_graphed(prop, ids, mask, 0.1 * i, mpm_mask=mpm, neg_idx=(n0, n1))
+        host.append(time.perf_counter() - t0)
+        lg.append([float(x) for x in out])
+    assert isinstance(graphed._graphs[next(iter(graphed._graphs))], tuple)          # captured (step 2) and replayed (steps 3-6)
+    print("eager", le[-1], "graph", lg[-1], "host ms per replay", [round(h * 1e3, 3) for h in host])
+    np.testing.assert_allclose(np.array(lg), np.array(le), rtol=3e-3)
+    assert (graphed.store.flat - eager.store.flat).abs().max().item() < 2.5e-3      # six AdamW steps at lr <= 1e-3, sign noise on ~0 gradients
+    assert int(graphed.queue_ptr) == int(eager.queue_ptr) and int(graphed.engine.seed) == int(eager.engine.seed)
+    assert max(host[2:]) < 5e-3, host                                               # replay: host-side cost of a step
+
+
 def test_rccl_code_path_single_rank(env):
     """The collective code path on real RCCL with a one-rank group (this box has one GPU): per-layer asynchronous all-reduces
     issued from the backward streams, the final sweep, the feature all-gather -- the step must produce the losses of the
