@@ -14,6 +14,9 @@ import os
 import sys
 import time
 
+# HIP maps streams onto 4 hardware queues by default and streams sharing a queue serialise; the step uses five
+# (main, two side streams, weight gradients, RCCL): ask for 8 before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -121,6 +121,8 @@ class Engine:
         # the unimodal text and PV chains (and their backward) are independent: run them on two HIP streams so the small-M
         # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
         self.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
+        self.wgrad_async = os.environ.get("SPMM_WGRAD_STREAM", "1") != "0" and self.multi_stream
+        self._wg_stream, self._wg_pending = None, False
         self.fp8 = os.environ.get("SPMM_FP8", "0") == "1"                    # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._side = None
         self._salt = 0
@@ -171,11 +173,42 @@ class Engine:
     def _wT(self, key, src_fp32):
         return self.P.wT(key, src_fp32)
 
-    def _wgrad(self, dY, X, gW, gb=None):
-        """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY (TN GEMM: no transposed copies)."""
-        if gb is not None:
-            ops.colsum_bf16(dY, gb)
-        ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
+    def _wgrad(self, dY, X, gW, gb=None, inline=False):
+        """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY (TN GEMM: no transposed copies).
+        Nothing on the backward's critical path reads a weight gradient, so (unless `inline`) the two launches go to a side stream
+        behind an event on the current one: they fill the CUs the data-gradient chain leaves idle (attention / LayerNorm backward,
+        tails of small-M GEMMs).  All weight gradients share ONE such stream (accumulations into the same tensor stay ordered);
+        `wgrad_join()` makes the current stream wait for it (before a layer's gradient exchange, before the optimiser)."""
+        ws = None if inline else self._wgrad_side()
+        if ws is None:
+            if gb is not None:
+                ops.colsum_bf16(dY, gb)
+            ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            if gb is not None:
+                ops.colsum_bf16(dY, gb)
+            ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
+        dY.record_stream(ws)                      # the caching allocator must not hand these blocks out before the side stream is done
+        X.record_stream(ws)
+        self._wg_pending = True
+
+    def _wgrad_side(self):
+        if not self.wgrad_async or self.dev.type != "cuda" or ops._DRY_RUN:
+            return None
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        return self._wg_stream
+
+    def wgrad_join(self):
+        """The current stream waits for every weight-gradient launch issued so far."""
+        if self._wg_stream is not None and self._wg_pending:
+            ev = torch.cuda.Event()
+            ev.record(self._wg_stream)
+            torch.cuda.current_stream().wait_event(ev)
 
     # ---------------------------------------------------------------------------------------- attention launches
     @staticmethod
@@ -383,6 +416,7 @@ class Engine:
         for i, sv in zip(reversed(list(layers)), reversed(tape)):
             dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
             if self.layer_done_cb is not None:           # this layer's gradients are final: data-parallel reduce may start
+                self.wgrad_join()
                 self.layer_done_cb(f"{pfx}encoder.layer.{i}.")
         return dY
 
@@ -454,7 +488,8 @@ class Engine:
         P, H, V, M = self.P, c.hidden_size, c.vocab_size, dlogits.shape[0]
         Vp = dlogits.shape[1]
         # wgrad of the tied decoder: dWord[V,H] += dlogits^T y ; dbias += colsum
-        self._wgrad(dlogits[:, :V], sv["y"], P.g(pfx + "bert.embeddings.word_embeddings.weight"), P.g(pfx + "cls.predictions.bias"))
+        # (inline: the tied word-embedding gradient is also written by embed_bwd's atomics on the compute stream)
+        self._wgrad(dlogits[:, :V], sv["y"], P.g(pfx + "bert.embeddings.word_embeddings.weight"), P.g(pfx + "cls.predictions.bias"), inline=True)
         key = pfx + "cls.decoderT"
         if key not in self.P._wT:           # [H, Vpad] zero-padded transposed shadow (K of the dgrad GEMM must be %64)
             self.P._wT[key] = torch.zeros(H, Vp, dtype=BF, device=self.dev)

@@ -755,10 +755,12 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
     if os.environ.get("SPMM_OVERLAP_CHILD") != "1":
         # HIP maps streams onto a few hardware queues (4 by default) and streams that share a queue serialise: after the ~60 streams
         # the earlier tests of this process created, the "communication" stream below may sit behind a compute stream.  A training
-        # process has four streams (main, two side streams, RCCL's), so the timeline is checked in a fresh process.
+        # process has five streams (main, two side streams, the weight-gradient stream, RCCL's) and raises the queue count to 8
+        # (GPU_MAX_HW_QUEUES, set by bench.py / pretrain.py before HIP initialises), so the timeline is checked in a fresh process
+        # with the same setting.
         import subprocess, sys
         out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__) + "::test_gradient_exchange_overlaps_backward"],
-                             capture_output=True, text=True, timeout=600, env=dict(os.environ, SPMM_OVERLAP_CHILD="1"))
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, SPMM_OVERLAP_CHILD="1", GPU_MAX_HW_QUEUES="8"))
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
         return
     from spmm_amd import parallel
