@@ -264,6 +264,7 @@ def main():
             return 2.0 * M * N * K
 
         model.engine.multi_stream = False     # per-launch events need one stream; concurrency would also smear the durations
+        model.engine.wgrad_async = False      # (the weight-gradient side stream too)
         # What an event pair adds to the interval it brackets (command-processor time between the first event's timestamp and the
         # kernel's start, and between its end and the second timestamp): intervals around ONE and around TWO minimal kernels through
         # the same launch path, overhead = 2 I1 - I2 (the kernel's own cost cancels).  rocprofv3's kernel trace has no such term;
@@ -310,6 +311,7 @@ def main():
         torch.cuda.synchronize()
         eng._attn_block_fwd = orig_blk
         model.engine.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
+        model.engine.wgrad_async = model.engine.multi_stream and os.environ.get("SPMM_WGRAD_STREAM", "1") != "0"
         x_ms = sum(a.elapsed_time(b) for a, b, _ in ev["xattn"])
         x_alg = sum(fl[0] for _, _, fl in ev["xattn"])
         x_exe = sum(fl[1] for _, _, fl in ev["xattn"])

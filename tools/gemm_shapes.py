@@ -20,6 +20,7 @@ batch = bench.synthetic_batch(128, 128, 42, dev)
 for _ in range(2):
     model.fused_step(*batch, 0.4)
 model.engine.multi_stream = False
+model.engine.wgrad_async = False
 ev = []
 stream = torch.cuda.current_stream()
 orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn
