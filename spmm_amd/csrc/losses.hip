@@ -83,12 +83,30 @@ __global__ __launch_bounds__(256) void ita_rows_kernel(const float* __restrict__
   const float* s = S + (long)row * ldj;
   const float* sm = SM + (long)row * ldj;
   const float alpha = *alpha_ptr;
+  // (one workgroup per row and only 2B rows: the three passes are latency-bound, so they read 16 bytes per lane where the row
+  //  stride allows it -- J4 = the part of the row covered by whole float4's)
+  const int J4 = (ldj % 4 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)SM % 16 == 0)) ? (J & ~3) : 0;
   float mx = -INFINITY, mxm = -INFINITY;
-  for (int j = threadIdx.x; j < J; j += 256) { mx = fmaxf(mx, s[j]); mxm = fmaxf(mxm, sm[j]); }
+  for (int j = threadIdx.x * 4; j < J4; j += 1024) {
+    const f32x4 a = *(const f32x4*)(s + j), b = *(const f32x4*)(sm + j);
+    mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+    mxm = fmaxf(fmaxf(mxm, fmaxf(b[0], b[1])), fmaxf(b[2], b[3]));
+  }
+  for (int j = J4 + threadIdx.x; j < J; j += 256) { mx = fmaxf(mx, s[j]); mxm = fmaxf(mxm, sm[j]); }
   mx = block_max(mx, sh);
   mxm = block_max(mxm, sh);
   float se = 0.f, sem = 0.f, dot = 0.f;
-  for (int j = threadIdx.x; j < J; j += 256) {
+  for (int j = threadIdx.x * 4; j < J4; j += 1024) {
+    const f32x4 a = *(const f32x4*)(s + j), b = *(const f32x4*)(sm + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float em = __expf(b[e] - mxm);
+      se += __expf(a[e] - mx);
+      sem += em;
+      dot += em * a[e];
+    }
+  }
+  for (int j = J4 + threadIdx.x; j < J; j += 256) {
     const float v = s[j];
     const float em = __expf(sm[j] - mxm);
     se += __expf(v - mx);
@@ -104,7 +122,18 @@ __global__ __launch_bounds__(256) void ita_rows_kernel(const float* __restrict__
   const float inv_se = 1.f / se, inv_sem = alpha / sem;
   float dt = 0.f;
   bf16* d = dS + (long)row * ldd;
-  for (int j = threadIdx.x; j < Jpad; j += 256) {
+  const int J4d = (J4 && ldd % 4 == 0 && ((uintptr_t)dS % 8 == 0)) ? J4 : 0;
+  for (int j = threadIdx.x * 4; j < J4d; j += 1024) {
+    const f32x4 a = *(const f32x4*)(s + j), b = *(const f32x4*)(sm + j);
+    float g4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g4[e] = (__expf(a[e] - mx) * inv_se - __expf(b[e] - mxm) * inv_sem - (j + e == diag ? 1.f - alpha : 0.f)) * rscale;
+      dt += g4[e] * a[e];
+    }
+    *(bf16x4*)(d + j) = to_bf16x4(g4[0], g4[1], g4[2], g4[3]);
+  }
+  for (int j = J4d + threadIdx.x; j < Jpad; j += 256) {
     float g = 0.f;
     if (j < J) {
       const float v = s[j];
