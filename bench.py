@@ -38,7 +38,7 @@ def synthetic_batch(B, Lt, seed, device):
         ids[b, 0] = 2
         ids[b, 1:n - 1] = torch.randint(4, 300, (n - 2,), generator=g)
         ids[b, n - 1] = 3
-    return prop.to(device), ids.to(device), (ids != 0).long().to(device)
+    return prop.to(device), ids.to(device), (ids != 0).long().to(device), int(lens.sum())      # (token count: host metadata of the batch)
 
 
 def step_flops(B, Lt, Lp=54, H=768, I=3072, V=300, E=256, Q=36864, n_text=12, fusion=6, n_pv=6):
@@ -199,13 +199,13 @@ def main():
     B, Lt = args.batch, args.seq_len
     batches = [synthetic_batch(B, Lt, 42 + 1000 * rank + i, dev) for i in range(4)]
     sync = grad_sync_fn(model.store)
-    n_valid = sum(int(b[2].sum()) for b in batches) / len(batches)     # real (non-padding) text tokens per batch
+    n_valid = sum(b[3] for b in batches) / len(batches)                # real (non-padding) text tokens per batch
 
     def one_step(i):
-        prop, ids, mask = batches[i % len(batches)]
+        prop, ids, mask, ntok = batches[i % len(batches)]
         if args.graph:                   # the step as one hipGraph replay (dense text layout, single rank): NOT the headline configuration
             return model.fused_step_graphed(prop, ids, mask, 0.4)
-        return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync)
+        return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync, n_tokens=ntok)   # the data pipeline knows the token count (host mask sum)
 
     for i in range(args.warmup):
         losses = one_step(i)

@@ -81,8 +81,10 @@ def batches(dataset, batch_size: int, rank: int, world: int, device):
                 if torch.is_tensor(items[0][1]):
                     ids = torch.stack([t for _, t in items])
                     keep = int((ids != 0).any(0).nonzero().max()) + 1          # padding='longest'
-                    ids = ids[:, :keep].to(device)
-                    yield prop, (ids, (ids != 0).long())
+                    ids = ids[:, :keep]
+                    n_tokens = int((ids != 0).sum())            # host-side: sizes the packed GEMMs without a device read per step
+                    ids = ids.to(device)
+                    yield prop, (ids, (ids != 0).long()), {"n_tokens": n_tokens}
                 else:
                     yield prop, [t for _, t in items]
     return _Loader()

@@ -316,17 +316,18 @@ class SPMM(_Base):
             self.configure_optimizers()
         return self._scheduler
 
-    def fused_step(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None, grad_sync=None):
-        """zero_grad -> forward -> backward (unit loss weights, SPMM_models.py:358) -> [grad all-reduce] -> clip -> AdamW,
-        with a single host read (the number of non-padding tokens, which sizes the packed GEMMs).  Returns the device tensor of
-        the four losses."""
+    def fused_step(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None, grad_sync=None, n_tokens=None):
+        """zero_grad -> forward -> backward (unit loss weights, SPMM_models.py:358) -> [grad all-reduce] -> clip -> AdamW.
+        `n_tokens` (optional, host int from the data pipeline: sum of the attention mask, every row a non-empty prefix) sizes the
+        packed GEMMs without the one blocking device read the step otherwise needs.  Returns the device tensor of the four losses."""
         eng, opt = self.engine, self.optimizers()
         eng.train_mode = self.training
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
         self.store.grad.zero_()
         dev = self.device_
-        losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn())
+        losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn(),
+                             n_tokens=n_tokens)
         if hasattr(grad_sync, "layer_done"):             # overlapped: slices are reduced as their layers finish backward
             grad_sync.begin(self.store.grad)
             eng.layer_done_cb = grad_sync.layer_done
@@ -413,8 +414,13 @@ class SPMM(_Base):
         from .parallel import grad_sync_fn
         if self._grad_sync is None:
             self._grad_sync = grad_sync_fn(self.store) or False
+        n_tokens = draws.get("n_tokens")
+        if n_tokens is None and torch.is_tensor(mask) and mask.device.type == "cpu":       # a host mask (the tokenizer's): count it here
+            lens = mask.sum(1)
+            if bool((lens > 0).all()) and bool(((torch.arange(mask.shape[1])[None, :] < lens[:, None]) == (mask != 0)).all()):
+                n_tokens = int(lens.sum())
         losses = self.fused_step(prop, ids, mask, alpha, grad_sync=self._grad_sync or None, mpm_mask=draws.get("mpm_mask"),
-                                 neg_idx=draws.get("neg_idx"))
+                                 neg_idx=draws.get("neg_idx"), n_tokens=n_tokens)
         if self.global_rank == 0:
             self.logged = {"lr": opt.param_groups[0]["lr"], "losses": losses}      # device tensor: no host read per step
         step_size, warm = 100, self.warmup_steps

@@ -10,16 +10,24 @@ from .engine import BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, K
 
 
 class PretrainStep(Engine):
-    def _pack_plan(self, mask32: torch.Tensor, B: int, Lt: int):
+    def _pack_plan(self, mask32: torch.Tensor, B: int, Lt: int, n_tokens: Optional[int] = None):
         """Row bookkeeping for the packed text passes: valid rows of the dense [B*Lt] layout in order, per-sequence start
-        and length.  One host read per step (the packed row count sizes the GEMMs); returns None -- dense fallback -- when
-        a sequence does not start with a valid token (position 0 is what the losses read) or nothing would be saved."""
+        and length.  The packed row count sizes the GEMMs, so the host must know it: either the data pipeline says so
+        (`n_tokens`: the tokenizer's attention mask is a host tensor, its sum costs nothing there -- and the caller then vouches
+        that every mask row is a non-empty prefix, which is what padding='longest' produces) or it is read back from the device,
+        one blocking read per step.  Returns None -- dense fallback -- when a sequence does not start with a valid token
+        (position 0 is what the losses read) or nothing would be saved."""
         lens = mask32.sum(1)
-        prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
-        stats = torch.stack([lens.sum(), (lens > 0).sum(), prefix.all().to(lens.dtype)]).cpu()
-        M, nonempty, is_prefix = int(stats[0]), int(stats[1]), int(stats[2])
-        if nonempty != B or not is_prefix or M >= B * Lt:       # holes in the mask: the packed index would not be the position
-            return None
+        if n_tokens is not None:
+            M = int(n_tokens)
+            if M >= B * Lt:
+                return None
+        else:
+            prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
+            stats = torch.stack([lens.sum(), (lens > 0).sum(), prefix.all().to(lens.dtype)]).cpu()
+            M, nonempty, is_prefix = int(stats[0]), int(stats[1]), int(stats[2])
+            if nonempty != B or not is_prefix or M >= B * Lt:   # holes in the mask: the packed index would not be the position
+                return None
         rows = torch.argsort((mask32.view(-1) == 0), stable=True)[:M]          # valid rows first, original order kept
         row0 = torch.cumsum(lens, 0) - lens
         return dict(M=M, rows=rows, row0=row0.to(torch.int32), row0_64=row0.to(torch.int64), len=lens.to(torch.int32))
@@ -27,7 +35,7 @@ class PretrainStep(Engine):
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, prop: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, *, mpm_mask: Optional[torch.Tensor] = None,
                 neg_idx: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, gather: Optional[Callable] = None,
-                save: bool = True, aux: Optional[dict] = None) -> torch.Tensor:
+                save: bool = True, aux: Optional[dict] = None, n_tokens: Optional[int] = None) -> torch.Tensor:
         """Returns the device tensor losses[0:4] = (loss_mlm, 5*loss_mpm, loss_ita, loss_itm).  `alpha` is read from
         self.alpha (device).  Mutates temp (clamp), the momentum arena (EMA), the queues and the queue pointer exactly as
         the reference's forward does."""
@@ -54,7 +62,7 @@ class PretrainStep(Engine):
 
         # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
         # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
-        pk = self._pack_plan(mask32, B, Lt) if (self.pack_text and aux is None and Lt <= 128) else None   # packed layouts: <= 128 tokens
+        pk = self._pack_plan(mask32, B, Lt, n_tokens) if (self.pack_text and aux is None and Lt <= 128) else None   # packed layouts: <= 128 tokens
         M = pk["M"] if pk else B * Lt
         ids2 = torch.cat([ids32, ids32])
         side = self._fork()

@@ -828,6 +828,21 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
     assert (m.store.flat - want_flat).abs().max().item() < 2.5e-3            # one AdamW step at lr 1e-3: sign flips of ~0 gradients move a weight by <= 2 lr
 
 
+def test_token_count_hint_equals_device_read(env):
+    """fused_step(..., n_tokens=) (the data pipeline's host-side mask sum) must give the step the device read-back gives."""
+    O = env[0]
+    prop, ids, mask = O.synthetic_batch(8, 24, seed=31)
+    mpm = (torch.rand(8, 53, generator=torch.Generator().manual_seed(3)) < 0.5).float()
+    neg = (torch.arange(8).roll(1), torch.arange(8).roll(2))
+    out = []
+    for hint in (None, int(mask.sum())):
+        m = _tiny_train_model(env, dropout=False)
+        l = m.fused_step(*_cuda(prop, ids, mask), 0.3, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)), n_tokens=hint)
+        out.append(([float(x) for x in l], m.store.flat.clone()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-5)
+    assert (out[0][1] - out[1][1]).abs().max().item() < 2.5e-3
+
+
 def test_training_step_as_one_hipgraph(env):
     """SPMM.fused_step_graphed: the whole step (zero_grad, forward, backward, clip, AdamW, EMA, enqueue) captured once and replayed.
     Against the eager run of the same dense-layout step on a twin model: identical batches and draws, six steps -- the losses

@@ -16,19 +16,19 @@ model = SPMM(config=tc, spmm_config=cfg, loader_len=1000).train()
 model.store.refresh_shadows()
 batch = bench.synthetic_batch(128, 128, 42, dev)
 for _ in range(3):
-    model.fused_step(*batch, 0.4)
+    model.fused_step(*batch[:3], 0.4, n_tokens=batch[3])
 torch.cuda.synchronize()
 host = []
 t0 = time.perf_counter()
 for _ in range(6):
     a = time.perf_counter()
-    model.fused_step(*batch, 0.4)
+    model.fused_step(*batch[:3], 0.4, n_tokens=batch[3])
     host.append(time.perf_counter() - a)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 6
 print("host enqueue ms per step:", [round(h * 1e3, 1) for h in host], " wall ms per step:", round(wall * 1e3, 1))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
-model.fused_step(*batch, 0.4)
+model.fused_step(*batch[:3], 0.4, n_tokens=batch[3])
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)

@@ -18,7 +18,7 @@ model = SPMM(config=tc, spmm_config=cfg, loader_len=1000).train()
 model.store.refresh_shadows()
 batch = bench.synthetic_batch(128, 128, 42, dev)
 for _ in range(2):
-    model.fused_step(*batch, 0.4)
+    model.fused_step(*batch[:3], 0.4, n_tokens=batch[3])
 model.engine.multi_stream = False
 model.engine.wgrad_async = False
 ev = []
@@ -40,7 +40,7 @@ def wrap(kind, fn):
     return w
 
 ops.gemm_nt, ops.gemm_tn = wrap("nt", orig_nt), wrap("tn", orig_tn)
-model.fused_step(*batch, 0.4)
+model.fused_step(*batch[:3], 0.4, n_tokens=batch[3])
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for key, e0, e1, fl in ev:

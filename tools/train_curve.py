@@ -27,7 +27,7 @@ t0 = time.time()
 print(f"{'step':>5s} {'mlm':>9s} {'5*mpm':>9s} {'ita':>9s} {'itm':>9s} {'|g|':>10s} {'temp':>7s}")
 for s in range(a.steps):
     alpha = 0.4 * min(1.0, s / 1000)
-    losses = model.fused_step(*batches[s % 4], alpha)
+    losses = model.fused_step(*batches[s % 4][:3], alpha, n_tokens=batches[s % 4][3])
     if s % a.every == 0 or s == a.steps - 1:
         l = losses.cpu().tolist()
         assert all(x == x and abs(x) < 1e6 for x in l), (s, l)
