@@ -194,15 +194,21 @@ __global__ void sample_neg_kernel(const float* __restrict__ S, long ldj, int B, 
 // ---------------------------------------------------------------- LM loss (one wave per token row)
 // logits / logits_m: [nseq*L, ldl] fp32 (V real columns).  Position t predicts ids[b, t+1]; t = L-1 has no label.
 // loss = (1-alpha) * mean_all CE + alpha * mean_{label != 0} distill.   dlogits (bf16, [rows, ldd], zero padded to Vpad).
-__global__ void count_nonpad_kernel(const int* __restrict__ ids, long nseq, int L, int* __restrict__ out) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(1024) void count_nonpad_kernel(const int* __restrict__ ids, long nseq, int L, int* __restrict__ out) {
+  __shared__ float sh[16];                             // one workgroup of 16 waves (the count is needed before lm_loss starts)
   float c = 0.f;
-  for (long i = threadIdx.x; i < nseq * L; i += 256) {
+  for (long i = threadIdx.x; i < nseq * L; i += 1024) {
     const int t = (int)(i % L);
     if (t >= 1 && ids[i] != 0) c += 1.f;
   }
-  c = block_sum(c, sh);
-  if (threadIdx.x == 0) *out = (int)(c + 0.5f);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *out = (int)(t + 0.5f);
+  }
 }
 // One wave per row, workgroups stride over the rows and add ONE loss atomic each: 16 384 same-address atomics (one per row) serialise
 // at ~13 ns apiece -- 213 us of a 215-us launch, measured.
@@ -481,7 +487,7 @@ extern "C" int spmm_lm_loss(const float* logits, const float* logits_m, long ldl
                             const float* alpha_ptr, int* n_nonpad_ws, const float* gscale, void* dlogits, long ldd, int Vpad,
                             float* losses, int loss_slot, hipStream_t stream) {
   SPMM_CHECK_SHAPE(nseq > 0 && L > 1 && V > 0 && Vpad >= V, "spmm_lm_loss: nseq=%ld L=%d V=%d Vpad=%d", nseq, L, V, Vpad);
-  hipLaunchKernelGGL(count_nonpad_kernel, dim3(1), dim3(256), 0, stream, ids, nseq, L, n_nonpad_ws);
+  hipLaunchKernelGGL(count_nonpad_kernel, dim3(1), dim3(1024), 0, stream, ids, nseq, L, n_nonpad_ws);
   hipLaunchKernelGGL(lm_loss_kernel, dim3((nseq * L + 3) / 4 < 1024 ? (nseq * L + 3) / 4 : 1024), dim3(256), 0, stream, logits, logits_m, ldl, ids, nseq, L, V, alpha_ptr,
                      n_nonpad_ws, gscale, (bf16*)dlogits, ldd, Vpad, losses, loss_slot);
   SPMM_LAUNCH_CHECK("spmm_lm_loss");

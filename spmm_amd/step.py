@@ -145,7 +145,7 @@ class PretrainStep(Engine):
         dfeat = None
         if save:   # d loss_ita / d [prop_feat ; text_feat], before the queue is overwritten (:208)
             dfeat = self._zeros(2 * B, E, dtype=torch.float32)
-            sp = max(1, min(Jp // 64, 64))
+            sp = max(1, min(Jp // 64, 16))      # K = B + Q split 16 ways: 52 us at K = 36 992 (64 ways: 102 us, the fp32 atomics dominate; tools/bench_splitk.py)
             ops.gemm_nt(dS_text, bank["text"][1], dfeat, epi=ops.EPI_F32_ATOMIC, splits=sp, div=temp)
             ops.gemm_nt(dS_prop, bank["prop"][1], dfeat, epi=ops.EPI_F32_ATOMIC, splits=sp, div=temp)
 
