@@ -122,7 +122,7 @@ class Engine:
         # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
         self.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
         self.wgrad_async = os.environ.get("SPMM_WGRAD_STREAM", "1") != "0" and self.multi_stream
-        self._wg_stream, self._wg_pending = None, False
+        self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self.fp8 = os.environ.get("SPMM_FP8", "0") == "1"                    # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._side = None
         self._salt = 0
@@ -192,8 +192,9 @@ class Engine:
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
             ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
-        dY.record_stream(ws)                      # the caching allocator must not hand these blocks out before the side stream is done
-        X.record_stream(ws)
+        # The operands must outlive the side stream's use of them.  They are simply kept referenced until the next join
+        # (`record_stream` on ~100 tensors per step makes the caching allocator poll events on every allocation).
+        self._wg_keep.append((dY, X))
         self._wg_pending = True
 
     def _wgrad_side(self):
@@ -203,12 +204,14 @@ class Engine:
             self._wg_stream = torch.cuda.Stream(device=self.dev)
         return self._wg_stream
 
-    def wgrad_join(self):
+    def wgrad_join(self, release: bool = False):
         """The current stream waits for every weight-gradient launch issued so far."""
         if self._wg_stream is not None and self._wg_pending:
             ev = torch.cuda.Event()
             ev.record(self._wg_stream)
             torch.cuda.current_stream().wait_event(ev)
+            if release:                               # the current stream is now ordered behind every use: the blocks may go back to it
+                self._wg_keep.clear()
 
     # ---------------------------------------------------------------------------------------- attention launches
     @staticmethod

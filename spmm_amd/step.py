@@ -358,6 +358,6 @@ class PretrainStep(Engine):
                       d_w=P.g("property_embed.weight"), d_b=P.g("property_embed.bias"), d_cls=P.g("property_cls"),
                       d_masktok=P.g("property_mask"))
         self._join(side)
-        self.wgrad_join()                                       # the weight gradients of the side stream are complete from here on
+        self.wgrad_join(release=True)                           # the weight gradients of the side stream are complete from here on
         self._wg_pending = False
         self.tape = None
