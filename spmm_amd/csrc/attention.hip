@@ -62,6 +62,8 @@ struct AttnP {
 __device__ __forceinline__ int frot(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int swz(int row, int c16) { return row * ROWB + ((c16 ^ frot(row)) << 4); }
 
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
 // reference mask arithmetic: (1 - causal*mask) * -10000 (self) / (1 - mask) * finfo.min (cross)
 __device__ __forceinline__ float score_bias(int mask_kv, bool causal, int q, int kv, float mask_neg) {
   const bool ok = mask_kv && (!causal || kv <= q);
@@ -167,9 +169,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
   stage_head(Kg, p.ldk, Lkv, Ks, tid, nthreads, NT * 32);
   stage_head(Vg, p.ldv, Lkv, Vs, tid, nthreads, NT * 32);
-  // additive score bias per key: 0 (attend), mask_neg (masked: (1 - m) * -10000 resp. finfo.min), -inf (tile padding past Lkv)
+  // additive score bias per key: 0 (attend), mask_neg (masked: (1 - m) * -10000 resp. finfo.min), -inf (tile padding past Lkv).
+  // Scores are kept in units of log2 (x log2 e): softmax = exp2(s2 - max2), one FMA per score.  (finfo.min x log2 e is clamped back to
+  // finfo.min: a row with every key masked must stay finite and come out uniform, as in the reference.)
+  const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
   for (int j = tid; j < 128; j += nthreads)
-    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : p.mask_neg) : -INFINITY;
+    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
   const int q = wave * 32 + (lane & 31);
   const int qc = q < Lq ? q : Lq - 1;
@@ -197,11 +202,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       f32x4 b = *(const f32x4*)(mb + kv0);
       if (causal) {                                 // workgroup-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], p.mask_neg) : b[j];
+        for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], neg2) : b[j];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float sc = st[t][gq * 4 + j] * 0.125f + b[j];
+        const float sc = __builtin_fmaf(st[t][gq * 4 + j], 0.125f * LOG2E, b[j]);
         st[t][gq * 4 + j] = sc;
         mx = fmaxf(mx, sc);
       }
@@ -212,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(st[t][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
       st[t][r] = e;
       sum += e;
     }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
-  if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx + __logf(sum);
+  if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx * LN2 + __logf(sum);
   if (p.drop_thresh16) {
     const uint32_t rowkey = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q);
 #pragma unroll
@@ -325,8 +330,11 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   stage_head(dOg, p.lddo, Lq, dOs, tid, 256, qrows);
   if (tid < 128) {
     const int j = tid;
-    mb[j] = j < Lkv ? (p.kmask ? (float)p.kmask[(long)seq * p.Lkv + j] : 1.f) : -1.f;
-    lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] : 0.f;
+    // additive score bias per key as in the forward: 0 (attend), mask_neg (masked), -inf (tile padding past Lkv: P = 0 exactly);
+    // query rows past Lq get lse = +inf, i.e. P = exp(s - inf) = 0, so neither needs a per-element test below
+    const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);     // (units of log2, as in the forward)
+    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
+    lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] * LOG2E : INFINITY;
   }
   __syncthreads();
 
@@ -350,6 +358,8 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
       dof[kk] = ld_rm(dOs, q, kk * 2 + g);
     }
     const float lq = lse[q];
+    const int qpos = q + p.q_off - p.kv_off;           // causal: key kv is visible iff kv <= qpos
+    const float neg2c = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
     const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) : 0u;
     f32x16 dp[NT];
     uint32_t keepbits[NT];
@@ -378,19 +388,25 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
       }
       keepbits[t] = kb;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float mv = mb[kv];
-        float pr = 0.f, dpr = 0.f;
-        if (mv >= 0.f && q < Lq) {
-          const float s = st[r] * 0.125f + score_bias(mv > 0.5f, causal, q + p.q_off, kv + p.kv_off, p.mask_neg);
-          pr = __expf(s - lq);
-          dpr = dp[t][r];
-          if (drop) dpr = ((kb >> r) & 1u) ? dpr * p.drop_scale : 0.f;
+      for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3: the 4 consecutive keys t*32 + 8*gq + 4*g + {0..3}
+        const int kv0 = t * 32 + 8 * gq + 4 * g;
+        f32x4 b = *(const f32x4*)(mb + kv0);
+        if (causal) {                                  // workgroup-uniform
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], neg2c) : b[j];
         }
-        st[r] = pr;
-        dp[t][r] = dpr;
-        dloc += pr * dpr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] -= lq;          // (lq already in units of log2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = gq * 4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], 0.125f * LOG2E, b[j]));
+          float dpr = dp[t][r];
+          if (drop) dpr = ((kb >> r) & 1u) ? dpr * p.drop_scale : 0.f;
+          st[r] = pr;
+          dp[t][r] = dpr;
+          dloc += pr * dpr;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) ppk[t][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
