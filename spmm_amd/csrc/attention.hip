@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   const uint64_t seed = drop ? seed_mix(p.seed_ptr, p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
   const int NTq = (Lq + 31) >> 5;
+  const float dsc = drop ? p.drop_scale : 1.f, qsc = 0.125f * dsc;     // (see the dropout note in phase A)
 
   // ---- phase A: wave owns query tile `wave`: ONE pass over the scores gives D[q] = sum_kv P dP (fp32, exactly consistent with
   // ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and dS = P (dP - D).
@@ -402,7 +403,9 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
           const int r = gq * 4 + j;
           const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], 0.125f * LOG2E, b[j]));
           float dpr = dp[t][r];
-          if (drop) dpr = ((kb >> r) & 1u) ? dpr * p.drop_scale : 0.f;
+          // dropout: dP is only MASKED here (bit r of kb, sign-extended to an all-ones word); the factor 1 / (1 - p) is linear in
+          // everything downstream (D, dS, P~) and is applied once to the dQ / dK / dV accumulators at their stores
+          if (drop) dpr = __builtin_bit_cast(float, __builtin_bit_cast(int, dpr) & __builtin_amdgcn_sbfe((int)kb, r, 1));
           st[r] = pr;
           dp[t][r] = dpr;
           dloc += pr * dpr;
@@ -426,7 +429,9 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         for (int i = 0; i < 8; ++i) {
           const float p0 = up_lo(ppk[t][i]), p1 = up_hi(ppk[t][i]);
           dpk[t][i] = pk2(p0 * (dp[t][2 * i] - dloc), p1 * (dp[t][2 * i + 1] - dloc));
-          ppk[t][i] = pk2(((kb >> (2 * i)) & 1u) ? p0 * p.drop_scale : 0.f, ((kb >> (2 * i + 1)) & 1u) ? p1 * p.drop_scale : 0.f);
+          if (drop)                                     // P~ = P masked (the packed bf16 pair AND a per-half all-ones / zero word)
+            ppk[t][i] &= ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i, 1) & 0xffffu) |
+                         ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i + 1, 1) & 0xffff0000u);
         }
         {
           const u32x4 w0 = {dpk[t][0], dpk[t][1], dpk[t][2], dpk[t][3]}, w1 = {dpk[t][4], dpk[t][5], dpk[t][6], dpk[t][7]};
@@ -446,8 +451,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq)
             *(bf16x4*)(dQg + dt * 32 + 8 * gq + 4 * g) =
-                to_bf16x4(dq[dt][gq * 4] * 0.125f, dq[dt][gq * 4 + 1] * 0.125f, dq[dt][gq * 4 + 2] * 0.125f,
-                          dq[dt][gq * 4 + 3] * 0.125f);
+                to_bf16x4(dq[dt][gq * 4] * qsc, dq[dt][gq * 4 + 1] * qsc, dq[dt][gq * 4 + 2] * qsc, dq[dt][gq * 4 + 3] * qsc);
       }
     }
   }
@@ -507,9 +511,8 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int d = dt * 32 + 8 * gq + 4 * g;
-          *(bf16x4*)(dKg + d) = to_bf16x4(dk[dt][gq * 4] * 0.125f, dk[dt][gq * 4 + 1] * 0.125f,
-                                          dk[dt][gq * 4 + 2] * 0.125f, dk[dt][gq * 4 + 3] * 0.125f);
-          *(bf16x4*)(dVg + d) = to_bf16x4(dv[dt][gq * 4], dv[dt][gq * 4 + 1], dv[dt][gq * 4 + 2], dv[dt][gq * 4 + 3]);
+          *(bf16x4*)(dKg + d) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
+          *(bf16x4*)(dVg + d) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
         }
     }
   }
