@@ -232,10 +232,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
         const uint32_t pr = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
         const uint32_t r0 = drop_pair(rowkey, pr), r1 = drop_pair(rowkey, pr + 1);
-        st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] * p.drop_scale : 0.f;
-        st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] * p.drop_scale : 0.f;
-        st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] * p.drop_scale : 0.f;
-        st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] * p.drop_scale : 0.f;
+        st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] : 0.f;
+        st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] : 0.f;
+        st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] : 0.f;
+        st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] : 0.f;
       }
   }
   // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
@@ -252,13 +252,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   }
   if (q < Lq) {
     bf16* Og = p.O + (qrow + q) * p.ldo + h * HD;
+    const float osc = p.drop_thresh16 ? inv * p.drop_scale : inv;      // the dropped probabilities were only zeroed above: 1 / (1 - p) goes here
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int d = dt * 32 + 8 * gq + 4 * g;
-        *(bf16x4*)(Og + d) = to_bf16x4(ot[dt][gq * 4] * inv, ot[dt][gq * 4 + 1] * inv, ot[dt][gq * 4 + 2] * inv,
-                                       ot[dt][gq * 4 + 3] * inv);
+        *(bf16x4*)(Og + d) = to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc,
+                                       ot[dt][gq * 4 + 3] * osc);
       }
   }
 }
