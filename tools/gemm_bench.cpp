@@ -271,6 +271,7 @@ static int cmd_f8time(int M, int N, int K, int epi, int rounds) {
 // launches rotate over n different A / C buffer pairs (as the training step's GEMMs do) instead of re-using one.
 static int cmd_sustain(int M, int N, int K, int epi, int launches) {
   const int nrot = getenv("GEMM_BENCH_ROTATE") ? atoi(getenv("GEMM_BENCH_ROTATE")) : 1;
+  const bool rot_c_only = getenv("GEMM_BENCH_ROTATE_C_ONLY") != nullptr;     // A stays the same (cache-resident), only the output buffer rotates
   auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
   std::vector<Buf> A(nrot), C(nrot);
   Buf W, C2, G;
@@ -310,7 +311,7 @@ static int cmd_sustain(int M, int N, int K, int epi, int launches) {
   for (int b = 0; b < nb; ++b) {
     for (int i = 0; i < 100; ++i) {
       const int r = (b * 100 + i) % nrot;
-      if (run(8, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
+      if (run(8, epi, A[rot_c_only ? 0 : r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
               (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; }
     }
     CK(hipEventRecord(ev[b + 1], 0));
