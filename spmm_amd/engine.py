@@ -116,6 +116,7 @@ class Engine:
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)
         self.train_mode = True
+        self.hint_bad = torch.zeros(1, dtype=torch.int32, device=device)      # a caller's token-count hint contradicted the mask (step.py)
         self.pack_text = os.environ.get("SPMM_PACK_TEXT", "1") != "0"       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
         # the unimodal text and PV chains (and their backward) are independent: run them on two HIP streams so the small-M

@@ -22,6 +22,13 @@ class PretrainStep(Engine):
             M = int(n_tokens)
             if M >= B * Lt:
                 return None
+            # The caller vouches for the hint (SPMM.training_step derives it from the tokenizer's host mask itself).  Best effort
+            # against a wrong one, without a read-back: the mismatch is detected on the device and raises the NaN flag (AdamW, EMA
+            # and enqueue become no-ops, as for a non-finite loss, SPMM_models.py:132-134), and the per-sequence bookkeeping below
+            # is clamped to the rows the hint sized; launches sized from other derived quantities may still misbehave.
+            prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
+            bad = (lens.sum() != M) | (lens.min() < 1) | ~prefix.all()
+            self.hint_bad.copy_(bad.to(self.hint_bad.dtype))
         else:
             prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
             stats = torch.stack([lens.sum(), (lens > 0).sum(), prefix.all().to(lens.dtype)]).cpu()
@@ -30,6 +37,11 @@ class PretrainStep(Engine):
                 return None
         rows = torch.argsort((mask32.view(-1) == 0), stable=True)[:M]          # valid rows first, original order kept
         row0 = torch.cumsum(lens, 0) - lens
+        if n_tokens is not None:            # whatever the hint was, no launch may index past the M rows it sized (the step is skipped then)
+            if M < 1:
+                return None
+            row0 = row0.clamp(max=M - 1)
+            lens = torch.minimum(lens, M - row0).clamp(min=1)
         return dict(M=M, rows=rows, row0=row0.to(torch.int32), row0_64=row0.to(torch.int64), len=lens.to(torch.int32))
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -62,7 +74,10 @@ class PretrainStep(Engine):
 
         # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
         # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
+        self.hint_bad.zero_()
         pk = self._pack_plan(mask32, B, Lt, n_tokens) if (self.pack_text and aux is None and Lt <= 128) else None   # packed layouts: <= 128 tokens
+        if n_tokens is not None:
+            self.nan_flag.bitwise_or_(self.hint_bad)
         M = pk["M"] if pk else B * Lt
         ids2 = torch.cat([ids32, ids32])
         side = self._fork()
