@@ -646,6 +646,51 @@ def _check_cached_beam_search(O, SPMM, tiny_config, decode, sep_gap):
     assert n_hyp >= N
 
 
+def test_decode_at_published_widths(env):
+    """BASELINE configs[3] at the published widths (H=768, 12 heads; 2 text layers with 1 fusion layer + 2 PV layers to keep the CPU
+    oracle quick): teacher-forced next-token top-k against the fp32 oracle (log-probabilities within 2e-2, same ids where the
+    margin exceeds twice that), and the batched K/V-cache search against the uncached search of the same model."""
+    O, SPMM, *_ = env
+    from spmm_amd import decode
+    cfg, ocfg = _mid_cfg(env)
+    sd = _peaky_lm(O.init_state_dict(ocfg, seed=21), sep_gap=0.6)
+    om = O.OracleModule(sd, ocfg)
+    m = _mk(SPMM, cfg, sd).eval()
+    k = 3
+    prop = torch.randn(53, generator=torch.Generator().manual_seed(19))
+    pe_o = decode.encode_properties(om, prop.reshape(1, -1))
+    pe_h = decode.encode_properties(m, prop.reshape(1, -1))
+    assert (pe_h.cpu() - pe_o).abs().max().item() < 8e-2
+    text = torch.full((1, 1), decode.CLS_ID, dtype=torch.long)
+    vo, io = decode_oracle.next_token_topk(om, pe_o, text, k)
+    text = torch.cat([torch.full((k, 1), decode.CLS_ID, dtype=torch.long), io.squeeze(0).unsqueeze(-1)], dim=-1)
+    cur = vo.squeeze(0)
+    worst = 0.0
+    for step in range(5):
+        vo, io = decode_oracle.next_token_topk(om, pe_o, text, k)
+        vh, ih = decode_oracle.next_token_topk(m, pe_h, text.cuda(), k)
+        worst = max(worst, (vh.cpu() - vo).abs().max().item())
+        gap = (vo[:, :-1] - vo[:, 1:]).min(dim=1).values
+        for b in range(k):
+            if gap[b] > 1e-1:
+                assert torch.equal(ih[b].cpu(), io[b]), (step, b)
+        k2 = cur[:, None] + vo
+        cur, flat = torch.topk(k2.flatten(), k)
+        text = torch.cat([text.unsqueeze(1).repeat(1, k, 1), io.unsqueeze(-1)], dim=-1)[flat // k, flat % k]
+    print("decode H=768: worst |d log p| vs oracle", worst)
+    assert worst < 2e-2                                              # measured 6.8e-3
+    N = 5
+    props = torch.randn(N, 53, generator=torch.Generator().manual_seed(6)) * 2
+    got = decode.beam_search_batched(m, props, k=5, max_steps=12)
+    ref = decode.beam_search_batched(m, props, k=5, max_steps=12, cached=False)
+    for n in range(N):
+        assert bool(got[n]) == bool(ref[n])
+        if got[n]:
+            assert abs(got[n][0][0] - ref[n][0][0]) < 0.15, (n, got[n][0], ref[n][0])
+            for p, seq in got[n]:
+                assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and p <= 0.0
+
+
 def test_smiles_to_pv_matches_oracle(env):
     """SMILES -> PV autoregressive regression (d_smiles2pv.py:14-52) on the facades vs the fp32 oracle running the same
     loop.  The predictions feed back into the prefix, so bf16 error compounds over the steps: tolerance 5e-2 absolute on
