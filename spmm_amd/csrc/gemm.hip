@@ -1221,9 +1221,12 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum; p.sa = nullptr; p.sw = nullptr;
-  // tile order 3 (row-major inside two column groups, so an XCD's W panel stays L2-resident) when W is wide and K short:
-  // the lowest HBM-side traffic measured (profiles/r01_pmc_nt_gemm.txt); launch time itself is order-insensitive
-  p.order = K > 1024 ? 0 : 3;
+  // tile order (tile_of): K <= 1024 -> 2 (blocks of 8 row panels x up to 4 column tiles per XCD), longer K -> 0 (row-major).  Measured in
+  // the cache state the step presents (a 256-MiB memset between launches, tools/gemm_bench sustain GEMM_BENCH_BETWEEN=1): 84256x2304x768
+  // 1 072 TF/s with order 2 against 960 with the column-group order 3 used before (which had the lowest counter traffic with warm
+  // caches, profiles/r01_pmc_nt_gemm.txt) and 1 040 row-major; x3072x768 1 113 / 1 105 / 1 050; x768x768 893 / 874 / 880;
+  // K = 3072: row-major 1 313 against 1 268.
+  p.order = K > 1024 ? 0 : 2;
 
   // kernel: 0 = choose (below); 1 = 128x128 (all epilogues, split-K); 2 = 256x128 three-stage ring (no atomics);
   // 3 = 256x256 one-barrier-per-k-step (bf16 outputs); 8 = 256x256 8-phase (bf16 outputs, K % 128 == 0)
@@ -1267,7 +1270,7 @@ extern "C" int spmm_gemm_nt_f8(const void* A8, long lda, const float* sa, const 
   p.M = M; p.N = N; p.K = K; p.ksplit = K; p.bias = bias; p.div_ptr = nullptr; p.alpha = 1.f;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = nullptr; p.ldg = 0; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = nullptr; p.sa = sa; p.sw = sw;
-  p.order = K > 2048 ? 0 : 3;
+  p.order = K > 2048 ? 0 : 2;
   int rc;
   if (epi == EPI_BF16) rc = launch_p8_one<EPI_BF16, true>(p, stream, true);
   else rc = launch_p8_one<EPI_GELU_DERIV, true>(p, stream, true);
