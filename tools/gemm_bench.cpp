@@ -271,7 +271,8 @@ static int cmd_f8time(int M, int N, int K, int epi, int rounds) {
 // launches rotate over n different A / C buffer pairs (as the training step's GEMMs do) instead of re-using one.
 static int cmd_sustain(int M, int N, int K, int epi, int launches) {
   const int nrot = getenv("GEMM_BENCH_ROTATE") ? atoi(getenv("GEMM_BENCH_ROTATE")) : 1;
-  const bool rot_c_only = getenv("GEMM_BENCH_ROTATE_C_ONLY") != nullptr;     // A stays the same (cache-resident), only the output buffer rotates
+  const bool rot_c_only = getenv("GEMM_BENCH_ROTATE_C_ONLY") != nullptr;
+  const int kern = getenv("GEMM_BENCH_KERNEL") ? atoi(getenv("GEMM_BENCH_KERNEL")) : 8;      // 8 persistent 8-phase, 9 one workgroup per tile, 3 / 2 / 1     // A stays the same (cache-resident), only the output buffer rotates
   auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
   std::vector<Buf> A(nrot), C(nrot);
   Buf W, C2, G;
@@ -294,7 +295,7 @@ static int cmd_sustain(int M, int N, int K, int epi, int launches) {
       else if (between == 3) { if (spmm_colsum_bf16(scratch.d, 768, 174762, 768, (float*)cs.d, 0)) { printf("%s\n", spmm_last_error()); return 1; } }   // read-only sweep of 256 MiB
       else { CK(hipDeviceSynchronize()); struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr); }
       CK(hipEventRecord(e0, 0));
-      if (run(8, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
+      if (run(kern, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
               (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; }
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; ++n;
