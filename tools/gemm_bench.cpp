@@ -219,6 +219,25 @@ static int cmd_tntime(int M, int N, int K, int rounds) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int kernels[] = {1, 8};
   std::vector<float> med[2];
+  if (getenv("GEMM_BENCH_BETWEEN")) {                  // a 256-MiB memset between launches: the cache state inside the training step
+    Buf scratch; scratch.alloc((size_t)256 << 20);
+    for (int ki = 0; ki < 2; ++ki) {
+      double tot = 0;
+      for (int i = 0; i < 60; ++i) {
+        CK(hipMemsetAsync(scratch.d, i & 255, scratch.bytes, 0));
+        CK(hipEventRecord(e0, 0));
+        if (tn_run(kernels[ki], A, B, M, N, K, C, ws)) { printf("%s\n", spmm_last_error()); return 1; }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 10) tot += ms;
+      }
+      med[ki].push_back((float)(tot / 50));
+    }
+    printf("tn %6d : %5d x %5d (dirty caches):", M, N, K);
+    for (int ki = 0; ki < 2; ++ki) printf("  k%d %8.1f us %7.1f TF", kernels[ki], med[ki][0] * 1e3, 2.0 * M * N * K / (med[ki][0] * 1e-3) / 1e12);
+    printf("\n");
+    return 0;
+  }
   for (int r = 0; r < rounds; ++r)
     for (int ki = 0; ki < 2; ++ki) {
       for (int w = 0; w < 2; ++w) tn_run(kernels[ki], A, B, M, N, K, C, ws);
