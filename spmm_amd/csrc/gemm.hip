@@ -788,7 +788,20 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
       }
 #endif
       hook(blk);
-      if (blk == 3) { P8_LOAD_EX(1); }
+      // the second half's R / G pieces are requested as soon as the first half's pieces of the same block row have been used
+      // (three blocks of lead instead of one: the loads come from HBM)
+      if constexpr (HAS_EX && EPI == EPI_GELU_GRAD) {       // (this epilogue's math leaves no registers for the staggered form: it spilled)
+        if (blk == 3) { P8_LOAD_EX(1); }
+      } else if constexpr (HAS_EX) {
+        if (h == 0) {
+#pragma unroll
+          for (int i_ = 2 * mi; i_ < 2 * mi + 2; ++i_) {
+            long r_ = row0 + 64 + i_ * 8;
+            if (!INTERIOR) r_ = r_ < p.M ? r_ : p.M - 1;
+            ex[i_] = *(const u32x4*)(esrc + r_ * eld + nn);
+          }
+        }
+      }
     }
 #undef P8_LOAD_EX
   if constexpr (!GELU2) {
