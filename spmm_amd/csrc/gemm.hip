@@ -726,7 +726,23 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
             v[ni][j] = gg.x; v[ni][j + 1] = gg.y;
             w[ni][j] = dd.x; w[ni][j + 1] = dd.y;
           }
-        if (c2p) {
+        if (c2p && !F8) {
+          // both outputs of the block go through the wave's two LDS images at once (second output in this block's image, the
+          // activation in the other one): one LDS round trip per block instead of two
+          u32x4 q1, q2;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(w[ni][0], w[ni][1]), p8_pack2(w[ni][2], w[ni][3]));
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + (bo ^ 2048u), p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
+          p8_dsr128u<0>(q1, rad + bo);
+          p8_dsr128u<1024>(q2, rad + bo);
+          p8_dsr128u<0>(o1, rad + (bo ^ 2048u));
+          p8_dsr128u<1024>(o2, rad + (bo ^ 2048u));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (ok1) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2) = q1;
+          if (ok2) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2 + 8 * p.ldc2) = q2;
+        } else if (c2p) {                                       // (fp8 variant: no registers for four pieces in flight)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(w[ni][0], w[ni][1]), p8_pack2(w[ni][2], w[ni][3]));
           p8_dsr128u<0>(o1, rad + bo);
@@ -738,12 +754,14 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
         }
       }
       // (the same wave's LDS operations execute in order: the image writes below cannot pass the reads above)
+      if (!(GELU2 && c2p && !F8)) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
-      p8_dsr128u<0>(o1, rad + bo);
-      p8_dsr128u<1024>(o2, rad + bo);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+        for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
+        p8_dsr128u<0>(o1, rad + bo);
+        p8_dsr128u<1024>(o2, rad + bo);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (EPI == EPI_BF16 && HAS_EX) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -790,7 +808,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
       hook(blk);
       // the second half's R / G pieces are requested as soon as the first half's pieces of the same block row have been used
       // (three blocks of lead instead of one: the loads come from HBM)
-      if constexpr (HAS_EX && EPI == EPI_GELU_GRAD) {       // (this epilogue's math leaves no registers for the staggered form: it spilled)
+      if constexpr (HAS_EX && (EPI == EPI_GELU_GRAD || F8)) {   // (these variants have no registers left for the staggered form: it spilled)
         if (blk == 3) { P8_LOAD_EX(1); }
       } else if constexpr (HAS_EX) {
         if (h == 0) {
