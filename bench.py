@@ -16,7 +16,13 @@ import time
 
 # HIP maps streams onto 4 hardware queues by default and streams sharing a queue serialise; the step uses five
 # (main, two side streams, weight gradients, RCCL): ask for 8 before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Not when several ranks share ONE GPU (the gloo test vehicle, tests/test_step_gpu.py): two processes x 8 queues oversubscribe the
+# hardware scheduler -- the same 2-rank run takes 2 s with 4 queues per process, 12x longer with 16, and stalled for minutes with 8.
+if os.environ.get("SPMM_DIST_BACKEND") != "gloo":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("SPMM_BENCH_WATCHDOG"):        # seconds: dump every thread's Python stack and exit if the run is still going (hang diagnosis)
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["SPMM_BENCH_WATCHDOG"]), exit=True)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -379,7 +385,7 @@ def main():
         assert_replicas_identical(model.store.buffers["queue_ptr"], "queue_ptr")
         if rank == 0:
             print("replicas identical after", args.warmup + args.steps, "steps; queue_ptr =", int(model.queue_ptr), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -53,12 +53,17 @@ const char* spmm_last_error(void);
  * kernel (per call, no process state): 0 = chosen from the shape; SPMM_GEMM_K128 = 128x128 tile (every epilogue, split-K);
  * SPMM_GEMM_K256x128 = 256x128 three-stage ring (no atomic epilogue); SPMM_GEMM_K256 = 256x256 tile, one barrier per k-step;
  * SPMM_GEMM_K256P8 = 256x256 tile on the 8-phase schedule (bf16-output epilogues, K % 128 == 0) -- the default for the
- * training step's large GEMMs. */
+ * training step's large GEMMs: one persistent workgroup per CU walking its XCD's tile range.  SPMM_GEMM_K256P8_TILES = the same
+ * kernel with one workgroup per tile, SPMM_GEMM_AUTO_TILES = the automatic choice with that variant wherever the 8-phase kernel
+ * is chosen: for launches that share the GPU with a long-running kernel on another stream (a collective): the hardware dispatcher
+ * then places tiles on whatever CUs are free instead of 1/256th of the work waiting for an occupied CU (tools/gemm_bench contend). */
 #define SPMM_GEMM_AUTO 0
 #define SPMM_GEMM_K128 1
 #define SPMM_GEMM_K256x128 2
 #define SPMM_GEMM_K256 3
 #define SPMM_GEMM_K256P8 8
+#define SPMM_GEMM_K256P8_TILES 9
+#define SPMM_GEMM_AUTO_TILES 16
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
                  void* C2, long ldc2, int epi, float* colsum, int kernel, spmm_stream_t stream);

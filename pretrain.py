@@ -20,7 +20,8 @@ from pathlib import Path
 
 # HIP maps streams onto 4 hardware queues by default and streams sharing a queue serialise; the step uses five
 # (main, two side streams, weight gradients, RCCL): ask for 8 before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("SPMM_DIST_BACKEND") != "gloo":          # (not for several gloo ranks on one GPU: see bench.py)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

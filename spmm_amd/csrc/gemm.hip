@@ -1261,10 +1261,10 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
 
   // kernel: 0 = choose (below); 1 = 128x128 (all epilogues, split-K); 2 = 256x128 three-stage ring (no atomics);
   // 3 = 256x256 one-barrier-per-k-step (bf16 outputs); 8 = 256x256 8-phase (bf16 outputs, K % 128 == 0)
-  int k = kernel;
+  int k = kernel == SPMM_GEMM_AUTO_TILES ? 0 : kernel;
   if (k == 0) {
     const int tile = splits > 1 ? 1 : pick_tile(M, N, epi);
-    k = tile == 3 ? (p8_ok(p, epi) ? 8 : 3) : tile;
+    k = tile == 3 ? (p8_ok(p, epi) ? (kernel == SPMM_GEMM_AUTO_TILES ? 9 : 8) : 3) : tile;
     if (k == 2 && (epi == EPI_F32_ATOMIC || M < 512)) k = 1;
   }
   SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 8 || k == 9, "spmm_gemm_nt: unknown kernel selector %d", kernel);

@@ -124,6 +124,8 @@ class Engine:
         self.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
         self.wgrad_async = os.environ.get("SPMM_WGRAD_STREAM", "1") != "0" and self.multi_stream
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
+        # data-parallel backward: the weight-gradient stream waits for each exchange it issues (Engine._layer_done)
+        self.chain_exchange = os.environ.get("SPMM_CHAIN_EXCHANGE", "1") != "0"
         self.fp8 = os.environ.get("SPMM_FP8", "0") == "1"                    # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._side = None
         self._salt = 0
@@ -213,6 +215,7 @@ class Engine:
             torch.cuda.current_stream().wait_event(ev)
             if release:                               # the current stream is now ordered behind every use: the blocks may go back to it
                 self._wg_keep.clear()
+                self._wg_pending = False
 
     # ---------------------------------------------------------------------------------------- attention launches
     @staticmethod
@@ -420,9 +423,22 @@ class Engine:
         for i, sv in zip(reversed(list(layers)), reversed(tape)):
             dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
             if self.layer_done_cb is not None:           # this layer's gradients are final: data-parallel reduce may start
-                self.wgrad_join()
-                self.layer_done_cb(f"{pfx}encoder.layer.{i}.")
+                self._layer_done(f"{pfx}encoder.layer.{i}.")
         return dY
+
+    def _layer_done(self, prefix):
+        """Hand a finished layer's slice to the gradient exchange.  Its last writers are the current stream (LayerNorm / bias
+        gradients) and, when weight gradients run on their own stream, that stream.  The exchange is then issued FROM the
+        weight-gradient stream behind an event on the current one: the collective is ordered after both, and the stream carrying the
+        backward's critical path never waits (making it join the weight-gradient stream at every layer cost 17 ms of a 59-ms step)."""
+        ws = self._wg_stream if self._wg_pending else None
+        if ws is None:
+            return self.layer_done_cb(prefix)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            self.layer_done_cb(prefix, chained=self.chain_exchange)
 
     # --------------------------------------------------------------------------------------------- embeddings
     def embed_text(self, pfx, c, ids32, nseq, L, save):

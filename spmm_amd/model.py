@@ -331,10 +331,20 @@ class SPMM(_Base):
         if hasattr(grad_sync, "layer_done"):             # overlapped: slices are reduced as their layers finish backward
             grad_sync.begin(self.store.grad)
             eng.layer_done_cb = grad_sync.layer_done
+            # The exchange's kernels on RCCL's stream are a third chip-filling stream next to the backward chain and the asynchronous
+            # weight gradients: measured with a one-rank RCCL group (tools/dist_variants.sh) that combination runs the step in 75-78 ms
+            # against 62 with the weight gradients back on the backward's own stream (59 without any exchange) -- the same collapse
+            # as two weight-gradient streams.  So the weight-gradient stream rests while slices are exchanged.
+            wg_async = eng.wgrad_async
+            eng.wgrad_async = wg_async and not getattr(grad_sync, "exclusive", False)
             try:
-                eng.backward()
+                # a collective kernel is resident on RCCL's stream for much of this backward: the persistent NT GEMM, which counts on
+                # one workgroup per CU, loses 30-55 % beside one, the per-tile launch 3-8 % (tools/gemm_bench contend)
+                with ops.nt_tiles_per_workgroup(getattr(grad_sync, "tiles_under_comm", False)):
+                    eng.backward()
             finally:
                 eng.layer_done_cb = None
+                eng.wgrad_async = wg_async
             grad_sync.finish()
         else:
             eng.backward()

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/spmm_hip.h).  Every function enqueues HIP kernels on
 torch's current stream and returns immediately; torch is used for device memory and streams only."""
 import ctypes
+import os
 
 import torch
 
@@ -24,8 +25,17 @@ def _st():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_DEBUG_SYNC = os.environ.get("SPMM_DEBUG_SYNC") == "1"      # hang diagnosis: name every launch on stderr and drain the GPU after it
+
+
 def _call(name, *args):
     if not _DRY_RUN:
+        if _DEBUG_SYNC:
+            import sys
+            r = lib().call(name, *args)
+            print(f"[launch] {name} {[a for a in args if isinstance(a, int) and not isinstance(a, bool)][:8]}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            return r
         return lib().call(name, *args)
     res, argtypes = lib().protos[name]
     if len(args) != len(argtypes):
@@ -45,9 +55,36 @@ def _row_stride(t):
     return t.stride(0)
 
 
+GEMM_AUTO, GEMM_AUTO_TILES = 0, 16      # SPMM_GEMM_AUTO / SPMM_GEMM_AUTO_TILES (include/spmm_hip.h)
+_nt_auto = GEMM_AUTO
+
+
+class nt_tiles_per_workgroup:
+    """While active, automatically chosen NT GEMMs run one workgroup per tile instead of one persistent workgroup per CU: for the
+    stretch of a step during which a collective kernel holds CUs on RCCL's stream (the data-parallel backward).  Same results bit
+    for bit (same tiles, same accumulation order)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global _nt_auto
+        self._prev = _nt_auto
+        if self.on:
+            _nt_auto = GEMM_AUTO_TILES
+        return self
+
+    def __exit__(self, *exc):
+        global _nt_auto
+        _nt_auto = self._prev
+        return False
+
+
 def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None, kernel=0):
     """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride).  kernel: 0 = chosen from the shape,
-    1 / 2 / 3 / 8 force a tile kernel (SPMM_GEMM_* in include/spmm_hip.h)."""
+    1 / 2 / 3 / 8 / 9 force a tile kernel (SPMM_GEMM_* in include/spmm_hip.h)."""
+    if kernel == 0:
+        kernel = _nt_auto
     M, Ka = A.shape
     N = W.shape[0]
     K = Ka if K is None else K

@@ -58,8 +58,9 @@ class OverlappedGradSync:
     (28-38 MB fp32: long messages for the point-to-point xGMI links).  RCCL runs it on its own stream behind an event on the
     compute stream while the next layers' backward kernels keep the CUs busy.  `finish()` reduces what no layer covered
     (embeddings, heads, projections: ~2 % of the bytes) and joins the streams before the optimiser.
-    The collective is issued from the stream context the layer's backward ran in (S2's backward runs on a side stream): its
-    implicit dependency is exactly the stream that wrote the slice."""
+    The collective's implicit dependency is the stream context `layer_done` is called in: the engine calls it from the stream that
+    is ordered behind every writer of the slice (the weight-gradient stream when there is one, behind an event on the stream the
+    layer's backward ran on -- S2's backward runs on a side stream; Engine._layer_done)."""
 
     def __init__(self, order, offset, total, wire=None):
         self.total = int(total)
@@ -81,6 +82,12 @@ class OverlappedGradSync:
         self.wire = os.environ.get("SPMM_GRAD_WIRE", "fp32") if wire is None else wire
         if self.wire not in ("fp32", "bf16"):
             raise ValueError(f"SPMM_GRAD_WIRE must be fp32 or bf16, not {self.wire!r}")
+        # NT GEMMs of the backward as one workgroup per tile while slices are in flight (see SPMM.fused_step); SPMM_NT_UNDER_COMM=persistent
+        # keeps the persistent launch
+        self.tiles_under_comm = os.environ.get("SPMM_NT_UNDER_COMM", "tiles") != "persistent"
+        # the exchange is the only stream beside the backward chain (no asynchronous weight-gradient stream meanwhile; SPMM.fused_step);
+        # SPMM_WGRAD_UNDER_COMM=1 keeps that stream running
+        self.exclusive = os.environ.get("SPMM_WGRAD_UNDER_COMM", "0") != "1"
         self.trace = None            # set to [] to record (lo, hi, issue event, done event) per slice (tests / timeline checks)
         self._observer = None
 
@@ -125,10 +132,16 @@ class OverlappedGradSync:
                 done.record()
             self.trace.append((lo, hi, issue, done))
 
-    def layer_done(self, prefix: str):
+    def layer_done(self, prefix: str, chained: bool = False):
+        """`chained`: the calling stream also waits for the collective it has just issued (the engine's weight-gradient stream does:
+        that stream then carries weight gradients OR an exchange at any moment, so at most two chip-filling streams run side by side)."""
         if self._grad is None or prefix not in self._ranges:
             return
+        n0 = len(self._work)
         self._reduce(*self._ranges[prefix])
+        if chained:
+            for w in self._work[n0:]:
+                w.wait()
 
     def finish(self):
         pos = 0
@@ -136,10 +149,23 @@ class OverlappedGradSync:
             for a in range(pos, lo, BUCKET_ELEMS):
                 self._reduce(a, min(lo, a + BUCKET_ELEMS))
             pos = max(pos, hi)
+        if os.environ.get("SPMM_SYNC_DEBUG") == "1":             # hang diagnosis: is it the GPU or a collective that does not finish?
+            import sys, time
+            print(f"[rank {dist.get_rank()}] finish: {len(self._work)} works, slices {self._done}", file=sys.stderr, flush=True)
+            if self._grad.is_cuda:
+                torch.cuda.synchronize()
+                print(f"[rank {dist.get_rank()}] finish: GPU drained", file=sys.stderr, flush=True)
+            for i, w in enumerate(self._work):
+                t0 = time.time()
+                while not w.is_completed() and time.time() - t0 < 10:
+                    time.sleep(0.01)
+                print(f"[rank {dist.get_rank()}] work {i}: {'done' if w.is_completed() else 'NOT COMPLETED after 10 s'}", file=sys.stderr, flush=True)
         for w in self._work:
             w.wait()
-        for lo, hi, buf, _ in self._staged:
+        for lo, hi, buf, shard in self._staged:
             self._grad[lo:hi].copy_(buf[:hi - lo])
+            if buf.is_cuda:                                      # allocated in the issuing stream's pool, last read here
+                buf.record_stream(torch.cuda.current_stream())
         if not self._avg or self.wire == "bf16":
             self._grad.div_(world())
         self._grad, self._work, self._staged = None, [], []

@@ -47,14 +47,15 @@ def test_gemm_bf16_bias(ops, M, N, K):
     assert (Cbuf[:, N:] == 7.0).all()
 
 
-# kernel selector of spmm_gemm_nt (include/spmm_hip.h): 1 = 128x128, 2 = 256x128 ring, 3 = 256x256, 8 = 256x256 8-phase
+# kernel selector of spmm_gemm_nt (include/spmm_hip.h): 1 = 128x128, 2 = 256x128 ring, 3 = 256x256, 8 = 256x256 8-phase (persistent),
+# 9 = the same kernel with one workgroup per tile
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072), (70000, 768, 128),
                                    (66000, 1024, 256)])
-@pytest.mark.parametrize("kernel", [1, 2, 3, 8])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 8, 9])
 def test_gemm_tile_kernels(ops, M, N, K, kernel):
     """Every tile kernel forced on small / ragged / large shapes (the heuristic alone would never run the big tiles there):
     bias + residual epilogue, GELU with pre-activation output, and untouched padding columns."""
-    if kernel == 8 and N % 8:
+    if kernel in (8, 9) and N % 8:
         pytest.skip("the 8-phase kernel stores whole 16-B chunks: N % 8 == 0")
     A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
     bias = rnd(N, seed=23, dtype=torch.float32)
@@ -87,6 +88,31 @@ def test_gemm_tile_kernels(ops, M, N, K, kernel):
     ops.gemm_nt(A, W, D[:, :N], epi=ops.EPI_MUL, G=C2[:, :N], colsum=cs, kernel=kernel)
     close(D[:, :N], (A.float() @ W.float().t()) * C2[:, :N].float(), 3e-2, 1.5e-2, "multiply epilogue")
     close(cs, 1.0 + D[:, :N].float().sum(0), 5e-2 * math.sqrt(M / 256), 2e-3, "fused column sums (multiply epilogue)")
+
+
+def test_gemm_one_workgroup_per_tile_mode_is_bit_identical(ops):
+    """`ops.nt_tiles_per_workgroup()` (what the data-parallel backward switches on while collectives hold CUs): automatically chosen
+    NT GEMMs launch one workgroup per tile; the tiles and their accumulation order are the persistent kernel's, so every output --
+    including the fused column sums' inputs -- is identical bit for bit, and the switch is restored on exit."""
+    for (M, N, K, epi) in [(70000, 768, 768, ops.EPI_BF16), (33000, 3072, 768, ops.EPI_GELU_DERIV), (33000, 768, 3072, ops.EPI_BF16),
+                           (33000, 3072, 768, ops.EPI_MUL), (520, 256, 128, ops.EPI_BF16)]:
+        A, W = rnd(M, K, seed=31), rnd(N, K, scale=0.05, seed=32)
+        bias = rnd(N, seed=33, dtype=torch.float32)
+        G = rnd(M, N, seed=34) if epi == ops.EPI_MUL else None
+        outs = []
+        for tiles in (False, True):
+            C = torch.zeros(M, N, dtype=BF, device="cuda")
+            C2 = torch.zeros(M, N, dtype=BF, device="cuda") if epi == ops.EPI_GELU_DERIV else None
+            with ops.nt_tiles_per_workgroup(tiles):
+                assert ops._nt_auto == (ops.GEMM_AUTO_TILES if tiles else ops.GEMM_AUTO)
+                ops.gemm_nt(A, W, C, bias=None if epi == ops.EPI_MUL else bias, epi=epi, C2=C2, G=G)
+            assert ops._nt_auto == ops.GEMM_AUTO
+            outs.append((C, C2))
+        assert torch.equal(outs[0][0], outs[1][0]), (M, N, K, epi)
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], outs[1][1])
+        if epi == ops.EPI_BF16:
+            close(outs[1][0], A.float() @ W.float().t() + bias, 3e-2, 1e-2, "per-tile launch")
 
 
 def test_gemm_kernel_selector_rejects_unsupported(ops):

@@ -523,7 +523,10 @@ def test_two_rank_data_parallel_step_on_one_gpu(env):
     import subprocess, sys, json, socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    envv = dict(os.environ, SPMM_DIST_BACKEND="gloo")
+    # two processes on one GPU: the HIP default of 4 hardware queues each (bench.py does not raise it for gloo; more oversubscribe the
+    # hardware scheduler and the run crawls); the watchdog turns a hang into Python stacks after 4 minutes instead of a silent timeout
+    envv = dict(os.environ, SPMM_DIST_BACKEND="gloo", SPMM_BENCH_WATCHDOG="240")
+    envv.pop("GPU_MAX_HW_QUEUES", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
            "--seq-len", "32", "--layers", "2,1,1", "--queue", "64", "--no-cpu-baseline", "--check-replicas"]

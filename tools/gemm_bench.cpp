@@ -343,7 +343,41 @@ static int cmd_sustain(int M, int N, int K, int epi, int launches) {
   return 0;
 }
 
+// `contend M N K epi kernel nocc us [launches]`: the GEMM on stream 0 while `nocc` workgroups of a do-nothing kernel hold CUs for `us`
+// microseconds on a second stream (what a long-running collective kernel does to a grid that counts on one workgroup per CU).
+__global__ void __launch_bounds__(256) occupy_kernel(long long ticks) {
+  __shared__ int pad[4096];                                  // 16 KiB of LDS: cannot share a CU with a 160-KiB GEMM workgroup
+  pad[threadIdx.x] = 0;
+  const long long t0 = wall_clock64();                       // 100 MHz
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static int cmd_contend(int M, int N, int K, int epi, int kern, int nocc, int us, int launches) {
+  auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
+  Buf A, W, C, C2, G;
+  A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); C.alloc((size_t)M * N * 2); C2.alloc((size_t)M * N * 2); G.alloc((size_t)M * N * 2);
+  CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice)); CK(hipMemset(G.d, 0, G.bytes));
+  hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<float> t;
+  for (int i = 0; i < launches + 10; ++i) {
+    if (nocc > 0) { occupy_kernel<<<nocc, 256, 0, s2>>>((long long)us * 100); struct timespec ts = {0, 30000}; nanosleep(&ts, nullptr); }   // the occupier is resident first
+    CK(hipEventRecord(e0, 0));
+    if (run(kern, epi, A, W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C,
+            (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? &C2 : nullptr, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; }
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (i >= 10) t.push_back(ms);
+  }
+  std::sort(t.begin(), t.end());
+  const float med = t[t.size() / 2];
+  printf("%d x %d x %d epi %d kernel %d, %d occupier workgroups for %d us: GEMM median %.1f us (%.0f TF/s), p10 %.1f, p90 %.1f\n", M, N, K, epi, kern, nocc, us,
+         med * 1e3, 2.0 * M * N * K / (med * 1e-3) / 1e12, t[t.size() / 10] * 1e3, t[t.size() * 9 / 10] * 1e3);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 9 && !strcmp(argv[1], "contend"))
+    return cmd_contend(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), argc > 9 ? atoi(argv[9]) : 100);
   if (argc >= 5 && !strcmp(argv[1], "sustain")) return cmd_sustain(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 2000);
   if (argc >= 5 && !strcmp(argv[1], "f8time")) return cmd_f8time(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 5);
   if (argc >= 2 && !strcmp(argv[1], "check")) return cmd_check();
