@@ -361,7 +361,8 @@ def main():
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}", "schedule": "one hipGraph replay per step, dense text layout" if args.graph else
-                      "eager launches on three HIP streams, packed text rows"},
+                      ("eager launches on three HIP streams, packed text rows" + ("" if sync is None else
+                       "; per-layer gradient exchange overlapped with the backward, weight gradients on the backward's stream meanwhile"))},
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
                                          - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= 128 else 0.0)) / 1e12, 2),

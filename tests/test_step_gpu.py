@@ -945,6 +945,28 @@ def test_rccl_code_path_single_rank(env):
     np.testing.assert_allclose(outs[2], outs[1], rtol=2e-2, atol=0)
 
 
+def test_data_parallel_code_path_costs_little_on_one_gpu(env):
+    """The benchmark step through the N>1 code path with a one-rank RCCL group -- per-layer exchanges issued during the backward,
+    RCCL's own stream, its reduce kernel per slice (with one rank the mean all-reduce is still a kernel) -- against the plain step on
+    the same GPU, same process conditions.  Guards the schedule of DESIGN.md section 6: with the asynchronous weight-gradient stream left
+    running beside the exchange this ratio was 1.32 (78 vs 59 ms); it is 1.04-1.06 as shipped.  Bound: 1.15."""
+    import subprocess, sys, json, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-kernel-timing"]
+    ms = {}
+    for force in ("1", "0"):
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        envv = dict(os.environ, SPMM_FORCE_DIST=force, MASTER_PORT=str(port), SPMM_BENCH_WATCHDOG="400")
+        for k in ("GPU_MAX_HW_QUEUES", "SPMM_WGRAD_UNDER_COMM", "SPMM_NT_UNDER_COMM", "SPMM_GRAD_OVERLAP", "SPMM_STREAMS"):
+            envv.pop(k, None)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=envv, cwd=root)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        js = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert all(np.isfinite(js["losses"]))
+        ms[force] = js["step_ms"]["median"]
+    assert ms["1"] < 1.15 * ms["0"], f"data-parallel code path {ms['1']:.1f} ms vs plain step {ms['0']:.1f} ms"
+
+
 @pytest.mark.parametrize("case", ["min_len", "full_len_128", "odd_33", "mask_holes", "one_long_rest_short"])
 def test_edge_shapes_match_oracle(env, case):
     """Ragged and extreme batches, losses vs the fp32 oracle (tiny config, dropout off, fixed draws): the shortest sequences
