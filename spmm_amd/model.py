@@ -14,6 +14,8 @@ from typing import Optional
 import torch
 from torch import nn
 
+import os
+
 from . import ops
 from .config import SPMMConfig, is_buffer, student_of
 
@@ -24,6 +26,8 @@ except Exception:                       # not installed on the target image: the
     _Base, _HAS_PL = nn.Module, False
 from .params import ParamStore
 from .step import PretrainStep
+
+_NT_TILES_BWD = os.environ.get("SPMM_NT_TILES") == "bwd"      # experiment switch: per-tile NT GEMMs in every backward
 
 
 class _CosineSchedule:
@@ -347,7 +351,8 @@ class SPMM(_Base):
                 eng.wgrad_async = wg_async
             grad_sync.finish()
         else:
-            eng.backward()
+            with ops.nt_tiles_per_workgroup(_NT_TILES_BWD):
+                eng.backward()
             if grad_sync is not None:
                 grad_sync(self.store.grad)
         opt.step()
