@@ -20,9 +20,12 @@ import time
 # hardware scheduler -- the same 2-rank run takes 2 s with 4 queues per process, 12x longer with 16, and stalled for minutes with 8.
 if os.environ.get("SPMM_DIST_BACKEND") != "gloo":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-if os.environ.get("SPMM_BENCH_WATCHDOG"):        # seconds: dump every thread's Python stack and exit if the run is still going (hang diagnosis)
+# Watchdog: a run still going after this many seconds dumps every thread's Python stack and EXITS NON-ZERO (never a re-exec, never a
+# silent hang of the driver's scaling run).  Default for N>1: 300 s -- 60 default steps take ~4 s, the rest is start-up.
+_wd = os.environ.get("SPMM_BENCH_WATCHDOG") or ("300" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
+if _wd and float(_wd) > 0:
     import faulthandler
-    faulthandler.dump_traceback_later(float(os.environ["SPMM_BENCH_WATCHDOG"]), exit=True)
+    faulthandler.dump_traceback_later(float(_wd), exit=True)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -130,6 +133,86 @@ def cpu_baseline(B, Lt, seconds_budget=45.0):
             "sample": f"oracle/spmm_oracle.py OracleTrainer, full 12+6-layer H=768 model fp32, B={B}, Lt={Lt}, {n} timed step(s) after 1 warm-up"}
 
 
+def decode_bench(args):
+    """BASELINE.json configs[3]: PV -> SMILES k-beam decode (d_pv2smiles_batched.py:18-59) on synthetic PVs with the batched
+    K/V-cache decoder (spmm_amd/decode.py), full-size random-init model.  A "step" is one chunk of molecules decoded to
+    `--decode-steps` positions (with random weights [SEP] rarely wins, so nearly every molecule runs all positions: the worst case).
+    Roofline: the `decode_attn` launches (single-query attention over the K/V cache, HBM gather) -- algorithmic bytes = the K and V
+    rows every beam reads once + q + out, against their HIP-event time in one instrumented (non-graph) chunk."""
+    torch.cuda.set_device(0)
+    from spmm_amd import decode, ops
+    from spmm_amd.config import BertConfig, SPMMConfig
+    from spmm_amd.model import SPMM
+    torch.manual_seed(0)
+    cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross_attention=True),
+                     prop=BertConfig(num_hidden_layers=6, fusion_layer=6, vocab_size=1), embed_dim=256, queue_size=36864)
+    m = SPMM(spmm_config=cfg, no_train=True).eval()
+    m.store.refresh_shadows()
+    N, chunk, k, T = args.molecules, args.chunk, args.beams, args.decode_steps
+    props = torch.randn(N, 53, generator=torch.Generator().manual_seed(42))
+    chunks = [props[i:i + chunk] for i in range(0, N, chunk)]
+    decode.beam_search_batched(m, props[:min(8, N)], k=k, max_steps=4)                      # warm-up (kernel attributes, allocator)
+    for c in chunks[:args.warmup]:
+        decode.beam_search_batched(m, c, k=k, max_steps=T, graph=not args.no_graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nfin = 0
+    for c in chunks:
+        nfin += sum(len(r) for r in decode.beam_search_batched(m, c, k=k, max_steps=T, graph=not args.no_graph))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "PV->SMILES k-beam decode molecules/sec", "value": round(N / dt, 2), "unit": "molecules/s", "n_gpus": 1, "steps": len(chunks),
+           "warmup": min(args.warmup, len(chunks)), "ms_per_step": round(dt / len(chunks) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"d_pv2smiles_batched.py: {N} synthetic PVs, k={k} beams, <= {T} positions, chunks of {chunk} molecules, 12-layer "
+                                  "causal text encoder with cross-attention to the 54-token PV embeddings, K/V cache"
+                                  + ("" if args.no_graph else ", one hipGraph replay per position"), "global_batch": chunk, "seq_len": T},
+           "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin}
+    # ---- instrumented chunk: HIP events around every decode_attn launch (eager, single stream)
+    ev, orig = [], ops.decode_attn
+    stream = torch.cuda.current_stream()
+
+    def timed(q, K, V, o, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_div=1, group=1, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = orig(q, K, V, o, nH=nH, Lkv=Lkv, seq_stride=seq_stride, tok_stride=tok_stride, anc=anc, kv_div=kv_div, group=group, **kw)
+        e1.record(stream)
+        R, H = q.shape[0], nH * 64
+        kv_rows = R * Lkv if anc is not None else (R // kv_div) * Lkv      # self: every beam's own prefix; cross: one source per molecule
+        ev.append((e0, e1, 2.0 * (2 * kv_rows * H + 2 * R * H)))
+        return r
+    ops.decode_attn = timed
+    try:
+        decode.beam_search_batched(m, chunks[0], k=k, max_steps=T, graph=False)
+    finally:
+        ops.decode_attn = orig
+    torch.cuda.synchronize()
+    tms = sum(a.elapsed_time(b) for a, b, _ in ev)
+    nbytes = sum(b for _, _, b in ev)
+    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_kernel (csrc/decode.hip): one wave per (beam row, head) over the K/V cache",
+                       "achieved": round(nbytes / (tms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": round(nbytes / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches": len(ev),
+                       "avg_launch_us": round(tms * 1e3 / len(ev), 2), "algorithmic_bytes_per_launch": round(nbytes / len(ev)),
+                       "measured": "HIP events around every decode_attn launch of one eager chunk (event-pair overhead ~2 us included)"}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import spmm_oracle as O
+        import decode_oracle
+        cores = min(os.cpu_count() or 1, 64)
+        torch.set_num_threads(cores)
+        ocfg = O.full_cfg()
+        om = O.OracleModule(O.init_state_dict(ocfg, seed=0), ocfg)
+        Tc = min(T, 24)
+        t0 = time.perf_counter()
+        decode_oracle.beam_search(om, props[0], k=k, max_steps=Tc)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / dtc, 4), "unit": "molecules/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle/decode_oracle.py beam_search (the reference's one-molecule whole-prefix-per-step loop) on the fp32 "
+                                         f"oracle model, 1 molecule, k={k}, {Tc} positions (the GPU figure runs {T}: the CPU cost grows ~quadratically "
+                                         "with the positions, so this flatters the CPU)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,9 +228,17 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (dense text layout, one rank; implies --no-kernel-timing)")
     ap.add_argument("--fp8", action="store_true", help="fp8 (E4M3) FFN forward GEMMs (BASELINE configs[4] tier; NOT the headline configuration)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
+    ap.add_argument("--decode", action="store_true", help="BASELINE configs[3]: PV->SMILES k-beam decode throughput instead of the pretrain step")
+    ap.add_argument("--molecules", type=int, default=1000)
+    ap.add_argument("--chunk", type=int, default=250, help="--decode: molecules decoded together")
+    ap.add_argument("--beams", type=int, default=5)
+    ap.add_argument("--decode-steps", type=int, default=100)
+    ap.add_argument("--no-graph", action="store_true", help="--decode: eager launches instead of one hipGraph replay per position")
     args = ap.parse_args()
-    if args.fp8:
-        os.environ["SPMM_FP8"] = "1"
+    if args.decode:
+        if args.warmup == 10:
+            args.warmup = 1
+        return decode_bench(args)
     if args.graph:
         args.no_kernel_timing = True
 
@@ -176,7 +267,7 @@ def main():
             torch.distributed.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-        if os.environ.get("SPMM_FORCE_DIST") == "1":
+        if os.environ.get("SPMM_FORCE_DIST") == "1":        # (EngineOptions.force_dist; the process group must exist before the model)
             # single-rank RCCL group: drives the real collective code path (overlapped per-layer all-reduce on RCCL's stream,
             # feature all-gather) on a one-GPU box; used by tests/test_step_gpu.py
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -187,6 +278,7 @@ def main():
     from spmm_amd import ops
     from spmm_amd.config import BertConfig, SPMMConfig
     from spmm_amd.model import SPMM
+    from spmm_amd.options import EngineOptions
     from spmm_amd.parallel import grad_sync_fn, broadcast_state_
 
     nt, f, npv = (int(x) for x in args.layers.split(","))
@@ -197,14 +289,15 @@ def main():
     tc = {'embed_dim': 256, 'temp': 0.07, 'mlm_probability': 0.15, 'queue_size': args.queue, 'momentum': 0.995, 'alpha': 0.4,
           'schedular': sched, 'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
     torch.manual_seed(42)                                   # SPMM_pretrain.py:48 default seed; same init on every rank
-    model = SPMM(config=tc, spmm_config=cfg, loader_len=1000)
+    opts = EngineOptions.from_env(**({"fp8": True} if args.fp8 else {}))
+    model = SPMM(config=tc, spmm_config=cfg, loader_len=1000, options=opts)
     broadcast_state_([model.store.flat, model.store.flat_m] + [model.store.buffers[k] for k in ("prop_queue", "text_queue")])
     model.store.refresh_shadows()
     model.engine.invalidate_banks()
     model.train(not args.eval_mode)
     B, Lt = args.batch, args.seq_len
     batches = [synthetic_batch(B, Lt, 42 + 1000 * rank + i, dev) for i in range(4)]
-    sync = grad_sync_fn(model.store)
+    sync = grad_sync_fn(model.store, opts)
     n_valid = sum(b[3] for b in batches) / len(batches)                # real (non-padding) text tokens per batch
 
     def one_step(i):
@@ -213,8 +306,26 @@ def main():
             return model.fused_step_graphed(prop, ids, mask, 0.4)
         return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync, n_tokens=ntok)   # the data pipeline knows the token count (host mask sum)
 
+    def check_replicas(after):
+        from spmm_amd.parallel import assert_replicas_identical
+        for t, what in ((model.store.flat, "student parameters"), (model.store.flat_m, "momentum parameters"),
+                        (model.store.buffers["prop_queue"], "prop_queue"), (model.store.buffers["text_queue"], "text_queue"),
+                        (model.store.buffers["queue_ptr"], "queue_ptr")):
+            assert_replicas_identical(t, what)
+        if rank == 0:
+            print("replicas identical after", after, "steps; queue_ptr =", int(model.queue_ptr), flush=True)
+
+    rccl_ranks = None
+    if world > 1:
+        # what every rank's communicator believes the job is: [world size seen] per rank, gathered through the collective itself
+        seen = torch.tensor([torch.distributed.get_world_size()], device=dev, dtype=torch.int32)
+        allseen = torch.empty(world, dtype=torch.int32, device=dev)
+        torch.distributed.all_gather_into_tensor(allseen, seen)
+        rccl_ranks = {"backend": torch.distributed.get_backend(), "world_size_seen_by_rank": allseen.cpu().tolist()}
     for i in range(args.warmup):
         losses = one_step(i)
+        if world > 1 and i == 1:         # replicas must agree from the start (no per-step buffer broadcast): checked after 2 steps, untimed
+            check_replicas(2)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -316,8 +427,8 @@ def main():
             one_step(i)
         torch.cuda.synchronize()
         eng._attn_block_fwd = orig_blk
-        model.engine.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
-        model.engine.wgrad_async = model.engine.multi_stream and os.environ.get("SPMM_WGRAD_STREAM", "1") != "0"
+        model.engine.multi_stream = opts.multi_stream
+        model.engine.wgrad_async = opts.multi_stream and opts.wgrad_stream
         x_ms = sum(a.elapsed_time(b) for a, b, _ in ev["xattn"])
         x_alg = sum(fl[0] for _, _, fl in ev["xattn"])
         x_exe = sum(fl[1] for _, _, fl in ev["xattn"])
@@ -369,6 +480,11 @@ def main():
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses}
+    from spmm_amd import streams
+    if rccl_ranks is not None:
+        out["rccl_ranks"] = rccl_ranks
+    if streams.log():
+        out["stream_placement"] = streams.log()
     if rank == 0:
         if roof is not None:
             out["roofline"] = roof
@@ -378,14 +494,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(16, Lt)
         print(json.dumps(out), flush=True)
     if args.check_replicas and world > 1:
-        from spmm_amd.parallel import assert_replicas_identical
-        assert_replicas_identical(model.store.flat, "student parameters")
-        assert_replicas_identical(model.store.flat_m, "momentum parameters")
-        assert_replicas_identical(model.store.buffers["prop_queue"], "prop_queue")
-        assert_replicas_identical(model.store.buffers["text_queue"], "text_queue")
-        assert_replicas_identical(model.store.buffers["queue_ptr"], "queue_ptr")
-        if rank == 0:
-            print("replicas identical after", args.warmup + args.steps, "steps; queue_ptr =", int(model.queue_ptr), flush=True)
+        check_replicas(args.warmup + args.steps)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -22,6 +22,8 @@ from pathlib import Path
 # (main, two side streams, weight gradients, RCCL): ask for 8 before the runtime initialises.
 if os.environ.get("SPMM_DIST_BACKEND") != "gloo":          # (not for several gloo ranks on one GPU: see bench.py)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:             # dmabuf IPC for RCCL; must be in place before the HIP runtime initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -103,7 +105,6 @@ def main(args, config):
         torch.cuda.set_device(local)
         device = torch.device(f"cuda:{local}")
         if world > 1:
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.distributed.init_process_group("nccl", device_id=device)
     torch.manual_seed(args.seed)
 
@@ -129,7 +130,7 @@ def main(args, config):
 
     model = SPMM(config=config, tokenizer=tokenizer, loader_len=len(loader), device=device)
     if args.checkpoint and not args.resume:          # weights only (SPMM_pretrain.py:24-26); --resume continues optimizer / epoch / seed too
-        model.load_checkpoint(torch.load(args.checkpoint, map_location="cpu"))
+        model.load_checkpoint(torch.load(args.checkpoint, map_location="cpu"), weights_only=True)
     if world > 1:
         broadcast_state_([model.store.flat, model.store.flat_m] + [model.store.buffers[k] for k in ("prop_queue", "text_queue")])
         model.store.refresh_shadows()

@@ -21,14 +21,14 @@ device memory; the one host read per step is the packed row count that sizes the
 from __future__ import annotations
 
 import contextlib
-import os
 from dataclasses import dataclass
 from typing import List, Optional
 
 import torch
 
-from . import ops
+from . import ops, streams
 from .config import BertConfig, SPMMConfig
+from .options import EngineOptions
 from .params import ParamStore
 
 BF = torch.bfloat16
@@ -100,8 +100,9 @@ class Group:
 
 
 class Engine:
-    def __init__(self, cfg: SPMMConfig, params: ParamStore, device):
+    def __init__(self, cfg: SPMMConfig, params: ParamStore, device, options: Optional[EngineOptions] = None):
         self.cfg, self.P, self.dev = cfg, params, device
+        self.opt = options if options is not None else EngineOptions.from_env()
         f32 = dict(dtype=torch.float32, device=device)
         self.alpha = torch.zeros(1, **f32)
         self.lr = torch.zeros(1, **f32)
@@ -111,23 +112,21 @@ class Engine:
         # dropout / negative-sampling seed: a device counter advanced once per training-mode forward (step.py), different on every
         # data-parallel rank, saved and restored with the checkpoint (model.py)
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
-        self.seed = torch.full((1,), (0x5DEECE66D + rank * 0x9E3779B97F4A7C15) % (1 << 62), dtype=torch.int64, device=device)
+        self.seed_rank_offset = rank * 0x9E3779B97F4A7C15 % (1 << 62)      # (checkpoints hold the rank-independent part: model.py)
+        self.seed = torch.full((1,), (0x5DEECE66D + self.seed_rank_offset) % (1 << 62), dtype=torch.int64, device=device)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
         self.dtemp_ita = torch.zeros(1, **f32)
         self.train_mode = True
         self.hint_bad = torch.zeros(1, dtype=torch.int32, device=device)      # a caller's token-count hint contradicted the mask (step.py)
-        self.pack_text = os.environ.get("SPMM_PACK_TEXT", "1") != "0"       # drop the rows of padding tokens from the passes that only read position 0 (step.py)
+        self.pack_text = self.opt.pack_text                 # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
         # the unimodal text and PV chains (and their backward) are independent: run them on two HIP streams so the small-M
         # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
-        self.multi_stream = os.environ.get("SPMM_STREAMS", "2") != "1"
-        self.wgrad_async = os.environ.get("SPMM_WGRAD_STREAM", "1") != "0" and self.multi_stream
+        self.multi_stream = self.opt.multi_stream
+        self.wgrad_async = self.opt.wgrad_stream and self.multi_stream
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
-        # data-parallel backward: the weight-gradient stream waits for each exchange it issues (Engine._layer_done)
-        self.chain_exchange = os.environ.get("SPMM_CHAIN_EXCHANGE", "1") != "0"
-        self.fp8 = os.environ.get("SPMM_FP8", "0") == "1"                    # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
-        self._side = None
+        self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
         self.tape = None
         E, Q = cfg.embed_dim, cfg.queue_size
@@ -138,14 +137,11 @@ class Engine:
         """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
         if not self.multi_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
-        if self._side is None:
-            self._side = {}
-        if which not in self._side:
-            self._side[which] = torch.cuda.Stream(device=self.dev)
+        side = streams.get(self.dev, f"side{which}")        # process-wide: every model of a process shares the same streams
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self._side[which].wait_event(ev)
-        return self._side[which]
+        side.wait_event(ev)
+        return side
 
     def _join(self, side):
         if side is not None:
@@ -203,8 +199,7 @@ class Engine:
     def _wgrad_side(self):
         if not self.wgrad_async or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
-        if self._wg_stream is None:
-            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        self._wg_stream = streams.get(self.dev, "wgrad")
         return self._wg_stream
 
     def wgrad_join(self, release: bool = False):
@@ -427,18 +422,10 @@ class Engine:
         return dY
 
     def _layer_done(self, prefix):
-        """Hand a finished layer's slice to the gradient exchange.  Its last writers are the current stream (LayerNorm / bias
-        gradients) and, when weight gradients run on their own stream, that stream.  The exchange is then issued FROM the
-        weight-gradient stream behind an event on the current one: the collective is ordered after both, and the stream carrying the
-        backward's critical path never waits (making it join the weight-gradient stream at every layer cost 17 ms of a 59-ms step)."""
-        ws = self._wg_stream if self._wg_pending else None
-        if ws is None:
-            return self.layer_done_cb(prefix)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        ws.wait_event(ev)
-        with torch.cuda.stream(ws):
-            self.layer_done_cb(prefix, chained=self.chain_exchange)
+        """Hand a finished layer's slice to the gradient exchange.  While slices are exchanged the weight gradients run on the
+        backward's own stream (SPMM.fused_step), so the stream calling this is ordered behind every writer of the slice."""
+        self.wgrad_join()
+        return self.layer_done_cb(prefix)
 
     # --------------------------------------------------------------------------------------------- embeddings
     def embed_text(self, pfx, c, ids32, nseq, L, save):

@@ -14,10 +14,9 @@ from typing import Optional
 import torch
 from torch import nn
 
-import os
-
 from . import ops
 from .config import SPMMConfig, is_buffer, student_of
+from .options import EngineOptions
 
 try:                                    # the reference subclasses pl.LightningModule (SPMM_models.py:16); keep that when it is importable
     import pytorch_lightning as _pl
@@ -26,8 +25,6 @@ except Exception:                       # not installed on the target image: the
     _Base, _HAS_PL = nn.Module, False
 from .params import ParamStore
 from .step import PretrainStep
-
-_NT_TILES_BWD = os.environ.get("SPMM_NT_TILES") == "bwd"      # experiment switch: per-tile NT GEMMs in every backward
 
 
 class _CosineSchedule:
@@ -101,8 +98,10 @@ class _StepFn(torch.autograd.Function):
 
 
 class SPMM(_Base):
-    def __init__(self, tokenizer=None, config=None, loader_len=0, no_train=False, device=None, spmm_config: Optional[SPMMConfig] = None):
+    def __init__(self, tokenizer=None, config=None, loader_len=0, no_train=False, device=None, spmm_config: Optional[SPMMConfig] = None,
+                 options: Optional[EngineOptions] = None):
         super().__init__()
+        self.options = options if options is not None else EngineOptions.from_env()
         if not torch.cuda.is_available() and not ops._DRY_RUN:
             raise RuntimeError("spmm_amd.SPMM needs an MI355X (HIP device); there is no CPU fallback")
         self.automatic_optimization = False
@@ -117,7 +116,7 @@ class SPMM(_Base):
         self._grad_sync = None
         self._graphs = {}            # fused_step_graphed: shape -> "warm" | (CUDAGraph, static buffers)
         self.store = ParamStore(self.cfg, self.device_, train=not no_train)
-        self.engine = PretrainStep(self.cfg, self.store, self.device_)
+        self.engine = PretrainStep(self.cfg, self.store, self.device_, self.options)
         self._param_names = []
         # register every tensor under the reference's state_dict name (dots are legal in _parameters/_buffers keys)
         for name, t in self.store.named_tensors():
@@ -241,7 +240,9 @@ class SPMM(_Base):
         bit-for-bit -- Adam moments and step count, the schedule position / lr, the dropout seed (Lightning's ckpt_path resume,
         SPMM_pretrain.py:37, restores optimizer and scheduler state too)."""
         sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
-        ck = dict(state_dict=sd, epoch=int(self.current_epoch), global_step=int(self.global_step_), rng_seed=int(self.engine.seed.item()))
+        # the dropout / sampling counter is saved WITHOUT the rank's offset (engine.py): every rank re-applies its own on load
+        ck = dict(state_dict=sd, epoch=int(self.current_epoch), global_step=int(self.global_step_),
+                  rng_seed=(int(self.engine.seed.item()) - self.engine.seed_rank_offset) % (1 << 62))
         if self._optimizer is not None:
             o = self._optimizer
             ck["optimizer_states"] = [dict(adam_m=self.store.adam_m.detach().cpu().clone(), adam_v=self.store.adam_v.detach().cpu().clone(),
@@ -249,17 +250,19 @@ class SPMM(_Base):
         ck.update(extra)
         torch.save(ck, path)
 
-    def load_checkpoint(self, path_or_dict, strict: bool = False):
+    def load_checkpoint(self, path_or_dict, strict: bool = False, weights_only: bool = False):
         """Accepts the Lightning dict ('state_dict'), the legacy 'model' key, or a bare state_dict; applies the legacy
         `_unk -> _mask` rename and drops nothing the arena knows.  strict=False mirrors SPMM_pretrain.py:26.  Optimizer state,
-        epoch / global step and the dropout seed are restored when the checkpoint carries them."""
+        epoch / global step and the dropout seed are restored when the checkpoint carries them -- unless `weights_only` (the
+        reference's `--checkpoint` warm start, SPMM_pretrain.py:24-26: a fresh optimiser, schedule and step count on old weights;
+        only `trainer.fit(ckpt_path=)` :37 continues a run)."""
         ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
         sd = ck.get("state_dict", ck.get("model", ck))
         sd = {k.replace("_unk", "_mask"): v for k, v in sd.items()}
         res = self.load_state_dict(sd, strict=strict)
-        if isinstance(ck, dict):
+        if isinstance(ck, dict) and not weights_only:
             if "rng_seed" in ck:
-                self.engine.seed.fill_(int(ck["rng_seed"]))
+                self.engine.seed.fill_((int(ck["rng_seed"]) + self.engine.seed_rank_offset) % (1 << 62))
             if "epoch" in ck and isinstance(ck["epoch"], int) and not _HAS_PL:
                 self.current_epoch = ck["epoch"]
             if "global_step" in ck:
@@ -297,7 +300,8 @@ class SPMM(_Base):
         return losses
 
     def _gather_fn(self):
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        d = torch.distributed
+        if d.is_available() and d.is_initialized() and (d.get_world_size() > 1 or self.options.force_dist):
             from .parallel import all_gather_features
             return all_gather_features
         return None
@@ -351,8 +355,7 @@ class SPMM(_Base):
                 eng.wgrad_async = wg_async
             grad_sync.finish()
         else:
-            with ops.nt_tiles_per_workgroup(_NT_TILES_BWD):
-                eng.backward()
+            eng.backward()
             if grad_sync is not None:
                 grad_sync(self.store.grad)
         opt.step()
@@ -428,11 +431,14 @@ class SPMM(_Base):
         opt, sch = self.optimizers(), self.lr_schedulers()
         from .parallel import grad_sync_fn
         if self._grad_sync is None:
-            self._grad_sync = grad_sync_fn(self.store) or False
+            self._grad_sync = grad_sync_fn(self.store, self.options) or False
         n_tokens = draws.get("n_tokens")
-        if n_tokens is None and torch.is_tensor(mask) and mask.device.type == "cpu":       # a host mask (the tokenizer's): count it here
+        if torch.is_tensor(mask) and mask.device.type == "cpu":       # a host mask (the tokenizer's): count / verify it here, for free
             lens = mask.sum(1)
-            if bool((lens > 0).all()) and bool(((torch.arange(mask.shape[1])[None, :] < lens[:, None]) == (mask != 0)).all()):
+            prefix = bool((lens > 0).all()) and bool(((torch.arange(mask.shape[1])[None, :] < lens[:, None]) == (mask != 0)).all())
+            if n_tokens is not None and (not prefix or int(n_tokens) != int(lens.sum())):
+                raise ValueError(f"n_tokens={n_tokens} contradicts the attention mask (sum {int(lens.sum())}, prefix rows: {prefix})")
+            if n_tokens is None and prefix:
                 n_tokens = int(lens.sum())
         losses = self.fused_step(prop, ids, mask, alpha, grad_sync=self._grad_sync or None, mpm_mask=draws.get("mpm_mask"),
                                  neg_idx=draws.get("neg_idx"), n_tokens=n_tokens)

@@ -56,7 +56,7 @@ def _row_stride(t):
 
 
 GEMM_AUTO, GEMM_AUTO_TILES = 0, 16      # SPMM_GEMM_AUTO / SPMM_GEMM_AUTO_TILES (include/spmm_hip.h)
-_nt_auto = GEMM_AUTO_TILES if os.environ.get("SPMM_NT_TILES") == "all" else GEMM_AUTO
+_nt_auto = GEMM_AUTO
 
 
 class nt_tiles_per_workgroup:

@@ -1,0 +1,69 @@
+"""`EngineOptions`: every switch that steers the product path, in one place.
+
+A field is set (in this order of precedence) by the `options=` argument of `spmm_amd.SPMM`, by its environment variable (read
+ONCE, when `EngineOptions.from_env()` runs in the constructor), or by its default.  The defaults are the benchmark
+configuration; nothing else in the package reads `os.environ` for behaviour (the debugging aids listed at the
+bottom aside)."""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass
+
+# field -> (environment variable, parser)
+_ENV = {
+    "pack_text": ("SPMM_PACK_TEXT", lambda s: s != "0"),
+    "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
+    "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
+    "fp8": ("SPMM_FP8", lambda s: s == "1"),
+    "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
+    "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
+    "grouped_wgrad": ("SPMM_GROUPED_WGRAD", lambda s: s != "0"),
+    "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
+    "grad_wire": ("SPMM_GRAD_WIRE", str),
+    "nt_under_comm": ("SPMM_NT_UNDER_COMM", str),
+    "force_dist": ("SPMM_FORCE_DIST", lambda s: s == "1"),
+    "probe_streams": ("SPMM_PROBE_STREAMS", lambda s: s != "0"),
+}
+
+
+@dataclass
+class EngineOptions:
+    # --- schedule of one step (spmm_amd/step.py, engine.py) ---
+    pack_text: bool = True        # drop padding-token rows from the text passes whose losses read only position 0
+    multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
+    wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
+    grouped_wgrad: bool = False   # one work-list launch for all weight-gradient problems of a layer (csrc/gemm_tn.hip)
+    fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)
+    # --- precision tiers (NOT the headline configuration) ---
+    fp8: bool = False             # E4M3 FFN forward GEMMs (BASELINE configs[4])
+    resid_fp32: bool = False      # fp32 residual stream through the LayerNorms and fp32 inputs to the loss heads
+    # --- data parallelism (spmm_amd/parallel.py) ---
+    grad_overlap: bool = True     # per-layer gradient exchange issued during the backward; False = one bucketed all-reduce after it
+    grad_wire: str = "fp32"       # "fp32": all-reduce on the arena; "bf16": cast + reduce-scatter + all-gather (half the link bytes)
+    nt_under_comm: str = "tiles"  # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile) or "persistent"
+    force_dist: bool = False      # run the N>1 code path with a one-rank process group (tests on a one-GPU box)
+    probe_streams: bool = True    # at start-up of a data-parallel run, check that RCCL's stream and the compute streams sit on
+    #                               different hardware queues and re-draw a compute stream that does not (spmm_amd/streams.py)
+
+    @classmethod
+    def from_env(cls, **overrides) -> "EngineOptions":
+        kw = {}
+        for field, (var, parse) in _ENV.items():
+            if var in os.environ:
+                kw[field] = parse(os.environ[var])
+        kw.update(overrides)
+        o = cls(**kw)
+        if o.grad_wire not in ("fp32", "bf16"):
+            raise ValueError(f"grad_wire must be fp32 or bf16, not {o.grad_wire!r}")
+        if o.nt_under_comm not in ("tiles", "persistent"):
+            raise ValueError(f"nt_under_comm must be tiles or persistent, not {o.nt_under_comm!r}")
+        return o
+
+    def replace(self, **kw) -> "EngineOptions":
+        return dataclasses.replace(self, **kw)
+
+
+# Debugging aids outside EngineOptions (they change no result): SPMM_DEBUG_SYNC=1 names every launch and drains the GPU after it
+# (ops.py); SPMM_BENCH_WATCHDOG=<s> makes bench.py dump all Python stacks and exit non-zero after <s> seconds;
+# SPMM_DIST_BACKEND=gloo lets the test harness put two ranks on one GPU (bench.py / pretrain.py).

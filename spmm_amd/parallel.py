@@ -10,10 +10,12 @@ Buffers are NOT broadcast every step (DDP's broadcast_buffers, C3 in SURVEY.md):
 every rank enqueues the same gathered features; `assert_replicas_identical` checks that."""
 from __future__ import annotations
 
-import os
+from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+from .options import EngineOptions
 
 BUCKET_ELEMS = 32 * 1024 * 1024      # 128 MiB of fp32 per all-reduce
 
@@ -23,8 +25,9 @@ def world():
 
 
 def all_gather_features(t: torch.Tensor) -> torch.Tensor:
+    """C1.  With a one-rank group (EngineOptions.force_dist) the collective still runs: the code path is the N>1 one."""
     ws = world()
-    if ws == 1 and not (os.environ.get("SPMM_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -62,8 +65,9 @@ class OverlappedGradSync:
     is ordered behind every writer of the slice (the weight-gradient stream when there is one, behind an event on the stream the
     layer's backward ran on -- S2's backward runs on a side stream; Engine._layer_done)."""
 
-    def __init__(self, order, offset, total, wire=None):
+    def __init__(self, order, offset, total, wire=None, options: Optional[EngineOptions] = None):
         self.total = int(total)
+        opt = options if options is not None else EngineOptions.from_env()
         names = list(order)
         ends = [offset[n] for n in names[1:]] + [self.total]
         self._ranges = {}
@@ -79,17 +83,15 @@ class OverlappedGradSync:
         self._grad, self._work, self._done = None, [], []
         # wire format of the gradient exchange: "fp32" = one all-reduce per slice on the arena itself; "bf16" = the slice is cast
         # to bf16, reduce-scattered and all-gathered (half the bytes on every xGMI link, sums in bf16: |rel err| <= 2^-8 per element)
-        self.wire = os.environ.get("SPMM_GRAD_WIRE", "fp32") if wire is None else wire
+        self.wire = opt.grad_wire if wire is None else wire
         if self.wire not in ("fp32", "bf16"):
-            raise ValueError(f"SPMM_GRAD_WIRE must be fp32 or bf16, not {self.wire!r}")
-        # NT GEMMs of the backward as one workgroup per tile while slices are in flight (see SPMM.fused_step); SPMM_NT_UNDER_COMM=persistent
-        # keeps the persistent launch
-        self.tiles_under_comm = os.environ.get("SPMM_NT_UNDER_COMM", "tiles") != "persistent"
-        # the exchange is the only stream beside the backward chain (no asynchronous weight-gradient stream meanwhile; SPMM.fused_step);
-        # SPMM_WGRAD_UNDER_COMM=1 keeps that stream running
-        self.exclusive = os.environ.get("SPMM_WGRAD_UNDER_COMM", "0") != "1"
+            raise ValueError(f"grad_wire must be fp32 or bf16, not {self.wire!r}")
+        # NT GEMMs of the backward as one workgroup per tile while slices are in flight (see SPMM.fused_step)
+        self.tiles_under_comm = opt.nt_under_comm != "persistent"
+        # The exchange is the only stream beside the backward chain: the asynchronous weight-gradient stream rests meanwhile
+        # (three chip-filling streams side by side ran the step in 76-78 ms against 61-62)
+        self.exclusive = True
         self.trace = None            # set to [] to record (lo, hi, issue event, done event) per slice (tests / timeline checks)
-        self._observer = None
 
     def begin(self, grad: torch.Tensor):
         assert grad.numel() == self.total
@@ -123,25 +125,18 @@ class OverlappedGradSync:
         self._work.extend(works)
         self._done.append((lo, hi))
         if issue is not None:
-            if self._observer is None:
-                self._observer = torch.cuda.Stream()
+            from . import streams
             done = torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(self._observer):              # the observer waits for the collective; the compute stream does not
+            with torch.cuda.stream(streams.get(sl.device, "observer")):   # the observer waits for the collective; the compute stream does not
                 for w in works:
                     w.wait()
                 done.record()
             self.trace.append((lo, hi, issue, done))
 
-    def layer_done(self, prefix: str, chained: bool = False):
-        """`chained`: the calling stream also waits for the collective it has just issued (the engine's weight-gradient stream does:
-        that stream then carries weight gradients OR an exchange at any moment, so at most two chip-filling streams run side by side)."""
+    def layer_done(self, prefix: str):
         if self._grad is None or prefix not in self._ranges:
             return
-        n0 = len(self._work)
         self._reduce(*self._ranges[prefix])
-        if chained:
-            for w in self._work[n0:]:
-                w.wait()
 
     def finish(self):
         pos = 0
@@ -149,17 +144,6 @@ class OverlappedGradSync:
             for a in range(pos, lo, BUCKET_ELEMS):
                 self._reduce(a, min(lo, a + BUCKET_ELEMS))
             pos = max(pos, hi)
-        if os.environ.get("SPMM_SYNC_DEBUG") == "1":             # hang diagnosis: is it the GPU or a collective that does not finish?
-            import sys, time
-            print(f"[rank {dist.get_rank()}] finish: {len(self._work)} works, slices {self._done}", file=sys.stderr, flush=True)
-            if self._grad.is_cuda:
-                torch.cuda.synchronize()
-                print(f"[rank {dist.get_rank()}] finish: GPU drained", file=sys.stderr, flush=True)
-            for i, w in enumerate(self._work):
-                t0 = time.time()
-                while not w.is_completed() and time.time() - t0 < 10:
-                    time.sleep(0.01)
-                print(f"[rank {dist.get_rank()}] work {i}: {'done' if w.is_completed() else 'NOT COMPLETED after 10 s'}", file=sys.stderr, flush=True)
         for w in self._work:
             w.wait()
         for lo, hi, buf, shard in self._staged:
@@ -171,13 +155,25 @@ class OverlappedGradSync:
         self._grad, self._work, self._staged = None, [], []
 
 
-def grad_sync_fn(store=None):
-    """None on a single rank; otherwise the overlapped reducer when the parameter layout is given, else the plain bucketed one."""
-    forced = os.environ.get("SPMM_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()
-    if world() == 1 and not forced:
+_placed = set()
+
+
+def grad_sync_fn(store=None, options: Optional[EngineOptions] = None):
+    """None on a single rank; otherwise the overlapped reducer when the parameter layout is given, else the plain bucketed one.
+    On RCCL the first call also checks (once per device) that the compute streams and RCCL's stream sit on different hardware
+    queues (spmm_amd/streams.py)."""
+    opt = options if options is not None else EngineOptions.from_env()
+    live = dist.is_available() and dist.is_initialized()
+    if not live or (world() == 1 and not opt.force_dist):
         return None
-    if store is not None and os.environ.get("SPMM_GRAD_OVERLAP", "1") != "0":
-        return OverlappedGradSync(store.order, store.offset, store.total)
+    if opt.probe_streams and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        dev = torch.cuda.current_device()
+        if dev not in _placed:
+            _placed.add(dev)
+            from . import streams
+            streams.place_beside_collectives(dev)
+    if store is not None and opt.grad_overlap:
+        return OverlappedGradSync(store.order, store.offset, store.total, options=opt)
     return allreduce_mean_
 
 
