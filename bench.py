@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (dense text layout, one rank; implies --no-kernel-timing)")
     ap.add_argument("--fp8", action="store_true", help="fp8 (E4M3) FFN forward GEMMs (BASELINE configs[4] tier; NOT the headline configuration)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
+    ap.add_argument("--extra-streams", type=int, default=0, help="diagnostic: create N more HIP streams and run one tiny kernel on each before the "
+                    "run (what the number of ACTIVE hardware queues costs; profiles/r03_hw_queues.txt)")
     ap.add_argument("--decode", action="store_true", help="BASELINE configs[3]: PV->SMILES k-beam decode throughput instead of the pretrain step")
     ap.add_argument("--molecules", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=250, help="--decode: molecules decoded together")
@@ -274,6 +276,11 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+    extra = [torch.cuda.Stream() for _ in range(args.extra_streams)]
+    for st_ in extra:
+        with torch.cuda.stream(st_):
+            torch.zeros(8, device=dev).add_(1.0)
+    torch.cuda.synchronize()
 
     from spmm_amd import ops
     from spmm_amd.config import BertConfig, SPMMConfig

@@ -101,6 +101,25 @@ int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* 
                   long lddq, void* dK, long lddk, void* dV, long lddv, int nseq, int nH, int Lq, int Lkv, int causal_from,
                   int is_cross, float dropout_p, const uint64_t* seed_ptr, uint64_t seed_salt, int q_off, int kv_off, int d_mode,
                   float* Dbuf, spmm_stream_t stream);
+
+/* Fused cross-attention block, forward (csrc/xattn.hip) -- the unit BASELINE.json's metric names, one launch:
+ *   Y = LayerNorm(dropout_h(dropout_a(softmax(Q K^T / 8 + mask)) V . Wo^T + bo) + R)
+ * Replaces BertSelfAttention.forward xbert.py:305-354 (cross instantiation :285-290, encoder mask 0/finfo.min from
+ * invert_attention_mask :1038-1043) followed by BertSelfOutput.forward xbert.py:369-373.  Q (already projected, xbert.py:280)
+ * and K / V (:286-287, projected once per unique source) come from GEMM launches.  Layout arguments as spmm_attn_fwd
+ * (kv_seq, packed q_row0/q_len, kv_row0/kv_len); R / Y / Z / mean / rstd / CTX are indexed by query row like Q.
+ * WoF = spmm_xattn_pack_wo(attention.output.dense.weight).  Optional outputs (null = not kept): Z (pre-LayerNorm sum, what
+ * spmm_ln_bwd reads), mean/rstd, CTX (attention context: weight gradient of Wo, spmm_attn_bwd), LSE.  The two dropouts draw the
+ * masks spmm_attn_fwd (salt_a) and spmm_ln_fwd (salt_h, row counter row_base + row) would draw, so the existing backward kernels
+ * regenerate them.  H = nH*64 in {128, 256, 768}, Lkv <= 128 (spmm_xattn_supported). */
+int spmm_xattn_supported(int H, int nH, int Lq, int Lkv);
+int spmm_xattn_pack_wo(const void* W, long ldw, void* out, int H, spmm_stream_t stream);
+int spmm_xattn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
+                   const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len,
+                   const void* WoF, const float* bo, const void* R, long ldr, const float* gamma, const float* beta, float eps,
+                   void* Y, long ldy, void* Z, long ldz, float* mean, float* rstd, void* CTX, long ldc, float* LSE,
+                   int nseq, int nH, int Lq, int Lkv, float attn_dropout_p, uint64_t salt_a, float hidden_dropout_p,
+                   uint64_t salt_h, const uint64_t* seed_ptr, long row_base, spmm_stream_t stream);
 /* out[u] = sum over k in [start[u], start[u+1]) of src[list[k]]  (rows of W bf16 elements, fp32 accumulation, fixed order).
  * Folds the per-query-sequence dK/dV of a cross-attention whose sequences share key/value sources (kv_seq) back onto the
  * unique sources before the K/V weight- and data-gradient GEMMs. */

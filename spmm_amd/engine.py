@@ -260,7 +260,20 @@ class Engine:
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
             shared = {}                                          # K/V of a shared source: projected once per layer
-            for g in groups:
+            fused = self.opt.fused_xattn and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
+            if fused:
+                # ONE launch per group for core + output projection + dropout + residual + LayerNorm (csrc/xattn.hip); the salts are
+                # drawn in the composite's order (every group's attention salt, then the hidden one): both forms draw the same masks
+                salts_a = [self._next_salt() for _ in groups]
+                salt_h = self._next_salt()
+                y = self._new(M, H)
+                z = self._new(M, H) if save else None
+                mean = self._new(M, dtype=torch.float32) if save else None
+                rstd = self._new(M, dtype=torch.float32) if save else None
+                if not save:
+                    ctx = None
+                WoF = P.wF(pfx + ".output.dense.weight")
+            for gi, g in enumerate(groups):
                 if g.src is not None:
                     if id(g.src) not in shared:
                         shared[id(g.src)] = ops.gemm_nt(g.src.kv, Wkv, self._new(g.src.kv.shape[0], 2 * H), bias=bkv)
@@ -269,15 +282,27 @@ class Engine:
                     KV = self._new(g.nseq * g.Lkv, 2 * H)
                     ops.gemm_nt(g.kv, Wkv, KV, bias=bkv)
                 lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
-                salt = self._next_salt()
                 r = g.rows
                 src = g.src
-                self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, kmask=g.kv_mask,
-                             is_cross=True, dropout_p=pa, seed=self.seed, salt=salt, kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
-                             kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)
+                lay = dict(kmask=g.kv_mask, kv_seq=g.kv_idx, q_row0=g.q_row0, q_len=g.q_len,
+                           kv_row0=None if src is None else src.row0, kv_len=None if src is None else src.len)
+                if fused:
+                    salt = salts_a[gi]
+                    ops.xattn_fwd(Qc[r], KV[:, :H], KV[:, H:], WoF, P.w(pfx + ".output.dense.bias"), X[r], P.w(pfx + ".output.LayerNorm.weight"),
+                                  P.w(pfx + ".output.LayerNorm.bias"), y[r], nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, eps=c.layer_norm_eps,
+                                  Z=None if z is None else z[r], mean=None if mean is None else mean[r.start:r.stop],
+                                  rstd=None if rstd is None else rstd[r.start:r.stop], CTX=None if ctx is None else ctx[r], lse=lse,
+                                  attn_dropout_p=pa, salt_a=salt, hidden_dropout_p=ph, salt_h=salt_h, seed=self.seed, row_base=r.start, **lay)
+                else:
+                    salt = self._next_salt()
+                    self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, is_cross=True,
+                                   dropout_p=pa, seed=self.seed, salt=salt, **lay)
                 sv["KV"].append(KV)
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
+            if fused:
+                sv.update(ctx=ctx, z=z, mean=mean, rstd=rstd, salt_h=salt_h)
+                return y, (sv if save else None)
         x = self._new(M, H)
         ops.gemm_nt(ctx, P.wb(pfx + ".output.dense.weight"), x, bias=P.w(pfx + ".output.dense.bias"))
         y = self._new(M, H)

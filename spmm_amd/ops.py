@@ -140,6 +140,31 @@ def attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, 
                _p(dbuf), _st())
 
 
+def xattn_supported(H, nH, Lq, Lkv):
+    return bool(_DRY_RUN or lib().cdll.spmm_xattn_supported(int(H), int(nH), int(Lq), int(Lkv)))
+
+
+def xattn_pack_wo(W, out=None):
+    """Fragment-ordered bf16 image of an output-projection weight [H, H] (bf16, [out, in]) for xattn_fwd."""
+    H = W.shape[0]
+    assert W.dtype == BF16 and W.shape[1] == H
+    out = torch.empty(H * H, dtype=BF16, device=W.device) if out is None else out
+    _call("spmm_xattn_pack_wo", _p(W), _row_stride(W), _p(out), H, _st())
+    return out
+
+
+def xattn_fwd(Q, K, V, WoF, bo, R, gamma, beta, Y, *, nseq, nH, Lq, Lkv, eps=1e-12, kmask=None, kv_seq=None, q_row0=None, q_len=None,
+              kv_row0=None, kv_len=None, Z=None, mean=None, rstd=None, CTX=None, lse=None, attn_dropout_p=0.0, salt_a=0,
+              hidden_dropout_p=0.0, salt_h=0, seed=None, row_base=0):
+    """Fused cross-attention block: Y = LN(dropout_h(softmax(Q K^T / 8 + mask) V . Wo^T + bo) + R)  (csrc/xattn.hip).  Q, R, Y, Z, CTX:
+    [rows, H] views of the group's query rows; K, V: [source rows, >= H] views; optional outputs Z / mean / rstd / CTX / lse."""
+    _call("spmm_xattn_fwd", _p(Q), _row_stride(Q), _p(K), _row_stride(K), _p(V), _row_stride(V), _p(kmask), _p(kv_seq), _p(q_row0), _p(q_len),
+          _p(kv_row0), _p(kv_len), _p(WoF), _p(bo), _p(R), _row_stride(R), _p(gamma), _p(beta), float(eps), _p(Y), _row_stride(Y), _p(Z),
+          0 if Z is None else _row_stride(Z), _p(mean), _p(rstd), _p(CTX), 0 if CTX is None else _row_stride(CTX), _p(lse), nseq, nH, Lq, Lkv,
+          float(attn_dropout_p), salt_a, float(hidden_dropout_p), salt_h, _p(seed), int(row_base), _st())
+    return Y
+
+
 def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0):
     rows, H = x.shape
     _call("spmm_ln_fwd", _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(zout), _p(mean), _p(rstd), rows, H, float(eps),

@@ -69,6 +69,7 @@ class ParamStore:
                 self.buffers[n] = torch.zeros(1, dtype=torch.long, device=device)
         self._wT: Dict[str, torch.Tensor] = {}     # transposed bf16 shadows for dgrad, keyed by (fused) name
         self._w8: Dict[str, tuple] = {}            # fp8 tier: name -> (fp32 master view, E4M3 bytes, per-row scales)
+        self._wF: Dict[str, tuple] = {}            # fused cross-attention: name -> (bf16 shadow view, fragment-ordered image, is momentum)
 
     # ---- views -----------------------------------------------------------------------------------------------
     def _resolve(self, name: str):
@@ -128,6 +129,21 @@ class ParamStore:
             ops.cast_transpose(src, None, self._wT[key])
         return self._wT[key]
 
+    def wF(self, name: str) -> torch.Tensor:
+        """Fragment-ordered bf16 image of a cross-attention output-projection weight (csrc/xattn.hip: every wave-level load of the
+        MFMA A operand is 1 KiB contiguous); built from the bf16 shadow on first use, refreshed by refresh_frag()."""
+        if name not in self._wF:
+            src = self.wb(name)
+            self._wF[name] = (src, torch.empty(src.numel(), dtype=torch.bfloat16, device=self.device), student_of(name) is not None)
+            ops.xattn_pack_wo(src, self._wF[name][1])
+        return self._wF[name][1]
+
+    def refresh_frag(self, momentum: bool):
+        """Re-pack the fragment-ordered images after their shadows changed (student: optimiser step; momentum twins: EMA)."""
+        for src, out, mom in self._wF.values():
+            if mom == momentum:
+                ops.xattn_pack_wo(src, out)
+
     def w8(self, name: str):
         """(fp8 E4M3 bytes [out,in], per-output-row scale [out]) of a weight for the fp8 tier (spmm_gemm_nt_f8); quantised from the
         fp32 master (student or momentum twin) on first use and again by refresh_shadows()."""
@@ -147,6 +163,9 @@ class ParamStore:
             ops.cast_f32_bf16(self.flat_m, self.shadow_m)
         for src, q, sc in self._w8.values():
             ops.quant_rows_fp8(src, q, sc)
+        self.refresh_frag(False)
+        if not transposed_only:
+            self.refresh_frag(True)
         srcs = getattr(self, "_wT_src", {})
         if not srcs:
             return

@@ -99,6 +99,7 @@ class PretrainStep(Engine):
             # EMA of the momentum parameters (:99 / :266-269) at the head of the momentum stream: the student chains do not
             # read them, so they start at once; the PV momentum pass below waits on `ema_done`
             ops.ema_update(P.flat_m, P.flat, P.shadow_m, cfg.momentum)
+            P.refresh_frag(True)                 # (fragment-ordered images of the momentum cross-attention output projections)
             if side_m is not None:
                 ema_done = torch.cuda.Event()
                 ema_done.record(side_m)

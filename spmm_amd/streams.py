@@ -87,10 +87,31 @@ def place_beside_collectives(device, names=("side0", "side1", "wgrad"), max_redr
     queue with the stream RCCL runs asynchronous collectives on.  Returns {stream name: "ok" | "redrawn xN" | "COLLIDES"}; the
     current stream cannot be re-drawn, a collision there is reported (and printed once)."""
     import torch.distributed as dist
+    import os
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    var = os.environ.get("SPMM_PROBE_VARIANT", "")      # TEMPORARY experiment switch
+    if var == "wgrad_only":                              # no probe: only create + touch the wgrad stream
+        with torch.cuda.stream(get(idx, "wgrad")):
+            torch.zeros(8, device=f"cuda:{idx}").add_(1.0)
+        torch.cuda.synchronize(); return {}
+    if var == "early_rccl":                              # no probe: only an early collective (RCCL's stream exists before the side streams)
+        dist.all_reduce(torch.zeros(256, device=f"cuda:{idx}")); torch.cuda.synchronize(); return {}
+    if var == "sleep_only":
+        for n in ("side0", "side1"):
+            with torch.cuda.stream(get(idx, n)):
+                torch.cuda._sleep(16000000)
+        torch.cuda.synchronize(); return {}
+    if var == "sides_first":                             # touch side0/side1 first, then an early collective
+        for n in ("side0", "side1"):
+            with torch.cuda.stream(get(idx, n)):
+                torch.zeros(8, device=f"cuda:{idx}").add_(1.0)
+        torch.cuda.synchronize()
+        dist.all_reduce(torch.zeros(256, device=f"cuda:{idx}")); torch.cuda.synchronize(); return {}
+    if var == "no_wgrad":
+        names = ("side0", "side1")
     t = torch.zeros(256, device=f"cuda:{idx}")
-    idle = torch.cuda.Stream(device=idx)             # the collective's implicit dependency: a stream with nothing on it
+    idle = torch.cuda.current_stream(idx) if var == "no_idle" else torch.cuda.Stream(device=idx)   # the collective's implicit dependency: a stream with nothing on it
 
     def issue():
         with torch.cuda.stream(idle):

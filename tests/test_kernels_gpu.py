@@ -347,6 +347,102 @@ def test_cross_attention_with_shared_kv_sources(ops, nseq, U, nH, Lq, Lkv):
     assert torch.equal(folded, ref.to(BF))
 
 
+def _xattn_composite(ops, Q, K, V, Wo, bo, R, gamma, beta, *, nseq, nH, Lq, Lkv, eps, pa, ph, seed, salt_a, salt_h, row_base, **lay):
+    """The five-launch form the fused block replaces: attention core -> output GEMM -> LayerNorm(dropout(x) + residual)."""
+    M, H = Q.shape
+    ctx = torch.zeros(M, H, dtype=BF, device="cuda")
+    lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    ops.attn_fwd(Q, K, V, ctx, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, is_cross=True, dropout_p=pa, seed=seed, salt=salt_a, **lay)
+    x = torch.zeros(M, H, dtype=BF, device="cuda")
+    ops.gemm_nt(ctx, Wo, x, bias=bo)
+    # spmm_ln_fwd counts dropout rows from the first row it is given: embed the group at row_base of a larger batch
+    xb = torch.zeros(row_base + M, H, dtype=BF, device="cuda"); xb[row_base:] = x
+    rb = torch.zeros(row_base + M, H, dtype=BF, device="cuda"); rb[row_base:] = R
+    y, z = torch.zeros_like(xb), torch.zeros_like(xb)
+    mean, rstd = torch.zeros(row_base + M, device="cuda"), torch.zeros(row_base + M, device="cuda")
+    ops.ln_fwd(xb, rb, gamma, beta, y, zout=z, mean=mean, rstd=rstd, eps=eps, dropout_p=ph, seed=seed, salt=salt_h)
+    return dict(y=y[row_base:], z=z[row_base:], mean=mean[row_base:], rstd=rstd[row_base:], ctx=ctx, lse=lse)
+
+
+@pytest.mark.parametrize("nH,nseq,U,Lq,Lkv,packed,drop", [
+    (12, 6, 3, 54, 128, False, False),      # property queries -> SMILES keys, shared sources, key mask (P5 | P7 | P12 shape)
+    (12, 5, 2, 128, 54, False, False),      # SMILES queries -> property keys: two 64-row panels per sequence
+    (12, 6, 3, 54, 128, True, False),       # packed key/value sources (kv_row0 / kv_len)
+    (12, 5, 2, 128, 54, True, False),       # packed query rows (q_row0 / q_len), ragged panels
+    (12, 6, 3, 54, 128, False, True),       # both dropouts: the masks of spmm_attn_fwd / spmm_ln_fwd
+    (12, 4, 4, 128, 54, True, True),
+    (2, 5, 2, 40, 24, False, False),        # H = 128 (the tiny configuration), one head pair, one key tile
+    (4, 3, 3, 70, 90, True, True),          # H = 256, three key tiles
+])
+def test_fused_cross_attention_block(ops, nH, nseq, U, Lq, Lkv, packed, drop):
+    """spmm_xattn_fwd (ONE launch: attention core + output projection + dropout + residual + LayerNorm) against (a) the composite
+    it replaces -- same kernels' dropout masks, so y / z / ctx / lse / mean / rstd must agree to bf16 rounding of the intermediate
+    x (the fused kernel keeps it in fp32) -- and (b) plain fp32 torch of xbert.py:305-354 + :369-373 (dropout off)."""
+    H = nH * 64
+    g = torch.Generator().manual_seed(nseq * 7 + Lq)
+    idx = torch.randint(0, U, (nseq,), generator=g); idx[:U] = torch.arange(U)
+    i32 = lambda t: t.to(torch.int32).cuda()
+    qlen = torch.randint(3, Lq + 1, (nseq,), generator=g); qlen[0] = Lq
+    kvlen = torch.randint(2, Lkv + 1, (U,), generator=g); kvlen[0] = Lkv
+    if packed:
+        q_row0 = torch.cumsum(qlen, 0) - qlen
+        kv_row0 = torch.cumsum(kvlen, 0) - kvlen
+        M, Mkv = int(qlen.sum()), int(kvlen.sum())
+        lay = dict(q_row0=i32(q_row0), q_len=i32(qlen), kv_row0=i32(kv_row0), kv_len=i32(kvlen), kmask=None, kv_seq=i32(idx))
+    else:
+        M, Mkv = nseq * Lq, U * Lkv
+        kmask = (torch.rand(nseq, Lkv, generator=g) > 0.25).int(); kmask[:, 0] = 1
+        lay = dict(kmask=kmask.cuda(), kv_seq=i32(idx))
+    Q = rnd(M, H, seed=60, scale=1.5)
+    KV = rnd(Mkv, 2 * H, seed=61)
+    R = rnd(M, H, seed=62)
+    Wo = rnd(H, H, seed=63, scale=0.04)
+    bo = torch.randn(H, generator=g).cuda() * 0.1
+    gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).cuda()
+    beta = (0.1 * torch.randn(H, generator=g)).cuda()
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    pa, ph = (0.1, 0.1) if drop else (0.0, 0.0)
+    row_base, eps = 1000, 1e-12
+    ref = _xattn_composite(ops, Q, KV[:, :H], KV[:, H:], Wo, bo, R, gamma, beta, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, eps=eps, pa=pa, ph=ph,
+                           seed=seed, salt_a=11, salt_h=22, row_base=row_base, **lay)
+    WoF = ops.xattn_pack_wo(Wo)
+    out = {k: torch.full_like(v, float("nan")) for k, v in ref.items()}
+    ops.xattn_fwd(Q, KV[:, :H], KV[:, H:], WoF, bo, R, gamma, beta, out["y"], nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, eps=eps, Z=out["z"],
+                  mean=out["mean"], rstd=out["rstd"], CTX=out["ctx"], lse=out["lse"], attn_dropout_p=pa, salt_a=11, hidden_dropout_p=ph,
+                  salt_h=22, seed=seed, row_base=row_base, **lay)
+    torch.cuda.synchronize()
+    if packed:                                                     # lse keeps the dense [nseq, nH, Lq] indexing: compare the valid positions
+        valid = (torch.arange(Lq)[None, :] < qlen[:, None]).cuda()
+        assert torch.equal(out["lse"].transpose(1, 2)[valid], ref["lse"].transpose(1, 2)[valid])
+    else:
+        assert torch.equal(out["lse"], ref["lse"])
+    assert torch.equal(out["ctx"], ref["ctx"])                   # the same arithmetic, MFMA for MFMA
+    # x is rounded to bf16 between GEMM and LayerNorm in the composite only: |dz| <= 2^-8 |x| (x up to ~4 here), LayerNorm divides by ~1.5
+    close(out["z"], ref["z"], atol=4e-2, rtol=1e-2, name="z")
+    close(out["y"], ref["y"], atol=4e-2, rtol=1e-2, name="y")
+    close(out["mean"], ref["mean"], atol=2e-3, rtol=1e-3, name="mean")
+    close(out["rstd"], ref["rstd"], atol=0, rtol=4e-3, name="rstd")
+    if drop:         # (a different dropout mask in either place would move ~10 % of the elements by O(1): the bounds above pin the masks)
+        return
+    # (b) fp32 torch
+    qs = torch.cumsum(qlen, 0) - qlen if packed else torch.arange(nseq) * Lq
+    ks = torch.cumsum(kvlen, 0) - kvlen if packed else torch.arange(U) * Lkv
+    Qf, KVf, Rf, Wf = Q.float(), KV.float(), R.float(), Wo.float()
+    for s_ in range(nseq):
+        lq = int(qlen[s_]) if packed else Lq
+        u = int(idx[s_]); lk = int(kvlen[u]) if packed else Lkv
+        q = Qf[int(qs[s_]):int(qs[s_]) + lq].view(lq, nH, 64).transpose(0, 1)
+        kv = KVf[int(ks[u]):int(ks[u]) + lk]
+        k = kv[:, :H].view(lk, nH, 64).transpose(0, 1); v = kv[:, H:].view(lk, nH, 64).transpose(0, 1)
+        sc = q @ k.transpose(1, 2) / 8.0
+        if not packed:
+            sc = sc + (1.0 - lay["kmask"][s_].float())[None, None, :] * torch.finfo(torch.float32).min
+        c = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(lq, H)
+        zz = c @ Wf.t() + bo + Rf[int(qs[s_]):int(qs[s_]) + lq]
+        yy = torch.nn.functional.layer_norm(zz, (H,), gamma, beta, eps)
+        close(out["y"][int(qs[s_]):int(qs[s_]) + lq], yy, atol=6e-2, rtol=2e-2, name=f"y vs fp32 torch, sequence {s_}")
+
+
 @pytest.mark.parametrize("is_cross,shared", [(False, False), (True, False), (True, True)])
 def test_attention_packed_variable_length_layout(ops, is_cross, shared):
     """Packed rows (q_row0/q_len, kv_row0/kv_len) give bit-identical O, LSE, dQ, dK, dV on the valid rows to the dense
