@@ -7,7 +7,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "spmm_hip.h")
-LIB_PATH = os.path.join(_HERE, "libspmm_hip.so")
+LIB_PATH = os.environ.get("SPMM_HIP_LIB") or os.path.join(_HERE, "libspmm_hip.so")      # (override: instrumented builds of tools/)
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64,
        "spmm_stream_t": ctypes.c_void_p, "void": None}

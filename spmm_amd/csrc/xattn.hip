@@ -28,6 +28,7 @@
 //
 // All LDS accesses made while a DMA is in flight are inline asm: a compiler-visible LDS access (or __syncthreads) would make the
 // compiler's waitcnt pass drain the DMA first.
+#include <type_traits>
 #include "common.h"
 #include "attn_tiles.h"
 #include "../../include/spmm_hip.h"
@@ -61,56 +62,81 @@ struct XattnP {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define XA_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define XA_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define XA_SB() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
-
-// four / one 16-byte LDS reads, no wait (the caller waits with XA_LGKM0 and fences with XA_SB before using the registers)
-__device__ __forceinline__ void lds_rd4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, bf16x8 (&d)[4]) {
-  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
-               : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
-}
-template <typename T>
-__device__ __forceinline__ void lds_rd1(unsigned a, T& d) {
-  asm volatile("ds_read_b128 %0, %1" : "=&v"(d) : "v"(a) : "memory");
-}
-__device__ __forceinline__ void lds_wr8(unsigned a, bf16x4 v) { asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(v) : "memory"); }
-
-// the transpose reads of ld_tr2x2 (attn_tiles.h) without the wait: A operands V^T for two 16-row k-blocks
-__device__ __forceinline__ void tr_issue(const char* tile, int rb, int lane, bf16x4 (&r)[8]) {
-  const int i16 = lane & 15, j = lane >> 4;
-  const int row0 = rb + 4 * (j >> 1) + (i16 >> 2);
-  const int col = (j & 1) * 16 + (i16 & 3) * 4;
-  unsigned a[8];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    a[b * 4 + 0] = lds_addr(tile + swz(row0 + 16 * b, col >> 3) + (col & 7) * 2);
-    a[b * 4 + 1] = lds_addr(tile + swz(row0 + 16 * b + 8, col >> 3) + (col & 7) * 2);
-    a[b * 4 + 2] = lds_addr(tile + swz(row0 + 16 * b, (col + 32) >> 3) + (col & 7) * 2);
-    a[b * 4 + 3] = lds_addr(tile + swz(row0 + 16 * b + 8, (col + 32) >> 3) + (col & 7) * 2);
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
   }
-  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
-               "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
-               : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+}
+
+// Inline-asm memory operations: the compiler's waitcnt pass neither sees them nor waits for a pending LDS-DMA because of them;
+// the caller places the waits (XA_LGKM0 / XA_VM) and fences the uses with XA_SB.
+template <int OFF, typename T>
+__device__ __forceinline__ void ds_rd(T& d, uint32_t addr) {                   // 16-byte LDS read
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void ds_rd_tr(bf16x4& d, uint32_t addr) {           // transposing 8-byte LDS read
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void ds_wr8(uint32_t addr, bf16x4 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// LDS-DMA of 16 bytes per lane: SGPR base + 32-bit VGPR byte offset -> wave-uniform LDS destination (M0) + lane * 16
+__device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+// asynchronous 16-byte global load into registers: SGPR base + VGPR byte offset + immediate
+template <int IMM>
+__device__ __forceinline__ void gl_ld16(bf16x8& d, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
 }
 
 // LDS image of a [64][H] bf16 panel (residual in, z / y out): 16-byte chunk c16 of row r sits at slot r * C16 + (c16 ^ (r & 15)).
 template <int C16>
 __device__ __forceinline__ int pslot(int row, int c16) { return row * C16 + (c16 ^ (row & 15)); }
 
+template <int NT, int NCT>
+struct XaLds {
+  static constexpr int H = 128 * NCT;
+  static constexpr int KVT = NT * 32 * ROWB;          // one [NT*32][64] head tile
+  static constexpr int KVBUF = 4 * KVT;               // K(h0) V(h0) K(h1) V(h1)
+  static constexpr int PANEL = 64 * H * 2;            // residual / z / y image
+  static constexpr int R0 = 2 * KVBUF > PANEL ? 2 * KVBUF : PANEL;
+  static constexpr int O_CTX = R0;                    // [64][128] bf16 context panel of the current head pair
+  static constexpr int O_MB = O_CTX + 64 * 256;       // additive score bias per key (128 floats)
+  static constexpr int O_RED = O_MB + 128 * 4;        // [2][4][64] row partial sums
+  static constexpr int O_VEC = O_RED + 512 * 4;       // bias | gamma | beta, fp32 [3][H]
+  static constexpr int TOTAL = O_VEC + 3 * H * 4;
+};
+
+// tools/ only (make XA_PROFILE=1): per-phase s_memtime stamps of wave 0 go to the LSE buffer instead of the log-sum-exp values
+#ifdef XA_PROFILE
+#define XA_STAMP(K) do { if (prof && tid == 0) prof[K] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XA_STAMP(K) do { } while (0)
+#endif
+
 template <int NT, int NCT>   // NT = ceil(Lkv / 32) key tiles; H = 128 * NCT
 __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
+  using L = XaLds<NT, NCT>;
+#ifdef XA_PROFILE
+  unsigned long long* prof = p.LSE ? (unsigned long long*)p.LSE + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  p.LSE = nullptr;
+  { const int tid = threadIdx.x; XA_STAMP(0); }
+#endif
   constexpr int H = 128 * NCT, NS = NCT, WN = 32 * NCT, C16 = H / 8;
-  constexpr int KVT = NT * 32 * ROWB;            // one [NT*32][64] head tile
-  constexpr int KVBUF = 4 * KVT;                 // K(h0) V(h0) K(h1) V(h1)
-  constexpr int PANEL = 64 * H * 2;
-  constexpr int R0 = 2 * KVBUF > PANEL ? 2 * KVBUF : PANEL;
+  constexpr int KVT = L::KVT, KVBUF = L::KVBUF;
+  constexpr int NF = 8 * NCT;                    // Wo fragments per wave and step (1 KiB each)
+  constexpr int D = NF < 12 ? NF : 12;           // ... of which D are in flight
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kvb = smem;                              // two K/V buffers; later the residual / z / y panel image
-  char* ctxs = smem + R0;                        // [64][128] bf16 context panel of the current head pair
-  float* mb = (float*)(ctxs + 64 * 256);         // additive score bias per key
-  float* red = mb + 128;                         // [2][4][64] row partial sums
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+  char* kvb = smem;
+  float* mb = (float*)(smem + L::O_MB);
+  float* red = (float*)(smem + L::O_RED);
+  float* vec = (float*)(smem + L::O_VEC);
 
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,6 +154,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
   const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
   for (int j = tid; j < 128; j += 256)
     mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
+  for (int j = tid; j < H; j += 256) { vec[j] = p.bo[j]; vec[H + j] = p.gamma[j]; vec[2 * H + j] = p.beta[j]; }
 
   bf16x8 qn[4];                                  // Q fragments of the NEXT step (B operand: row = lane&31, d = (kk*2+g)*8 ..)
   {
@@ -136,21 +163,57 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     for (int kk = 0; kk < 4; ++kk) qn[kk] = *(const bf16x8*)(Qg + (kk * 2 + g) * 8);
   }
   asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]));      // the loads are waited for HERE, before any DMA is in flight
-  __syncthreads();                               // mb visible (no DMA pending yet: a plain barrier)
+  __syncthreads();                               // mb / vec visible (no DMA pending yet: a plain barrier)
 
-  const bf16* Kg = p.K + kvrow * p.ldk;
-  const bf16* Vg = p.V + kvrow * p.ldv;
+  // ---- K/V staging: lane-linear LDS image, swizzle on the source chunk (attn_tiles.h stage_head), as SGPR-base DMA
+  const char* Kg = (const char*)(p.K + kvrow * p.ldk);
+  const char* Vg = (const char*)(p.V + kvrow * p.ldv);
+  uint32_t koff[NT], voff[NT];
+  {
+    const int lc = (tid & 7) ^ frot(tid >> 3);   // frot(row + 32 it) == frot(row)
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int row = (tid >> 3) + 32 * it;
+      const int grow = row < Lkv ? row : Lkv - 1;
+      koff[it] = (uint32_t)((grow * p.ldk + lc * 8) * 2);
+      voff[it] = (uint32_t)((grow * p.ldv + lc * 8) * 2);
+    }
+  }
   auto stage_pair = [&](int s, int b) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      stage_head(Kg + (2 * s + hh) * HD, p.ldk, Lkv, kvb + b * KVBUF + (2 * hh) * KVT, tid, 256, NT * 32);
-      stage_head(Vg + (2 * s + hh) * HD, p.ldv, Lkv, kvb + b * KVBUF + (2 * hh + 1) * KVT, tid, 256, NT * 32);
+      const char* sk = Kg + (2 * s + hh) * (HD * 2);
+      const char* sv = Vg + (2 * s + hh) * (HD * 2);
+      const uint32_t dk = lds0 + b * KVBUF + (2 * hh) * KVT + wave * 1024;
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        glds16(koff[it], sk, dk + it * 4096);
+        glds16(voff[it], sv, dk + KVT + it * 4096);
+      }
     }
   };
   stage_pair(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XA_VM(0);
   __builtin_amdgcn_s_barrier();
   XA_SB();
+  XA_STAMP(1);
+
+  // ---- loop-invariant LDS address parts of the attention core
+  const int fr = frot(l31);
+  uint32_t kb[4], vb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) kb[kk] = (uint32_t)(l31 * ROWB + (((kk * 2 + g) ^ fr) << 4));
+  {
+    const int i16 = lane & 15, j = lane >> 4;
+    const int row0 = 4 * (j >> 1) + (i16 >> 2);
+    const int col = (j & 1) * 16 + (i16 & 3) * 4;
+    vb[0] = (uint32_t)(swz(row0, col >> 3) + (col & 7) * 2);
+    vb[1] = (uint32_t)(swz(row0 + 8, col >> 3) + (col & 7) * 2);
+    vb[2] = (uint32_t)(swz(row0, (col + 32) >> 3) + (col & 7) * 2);
+    vb[3] = (uint32_t)(swz(row0 + 8, (col + 32) >> 3) + (col & 7) * 2);
+  }
+  const uint32_t mba = lds0 + L::O_MB + 16 * g;
+  const uint32_t cva = lds0 + L::O_CTX + (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);      // context panel, row-major reader
 
   f32x16 acc[2][NCT];
 #pragma unroll
@@ -159,9 +222,10 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = zero16();
 
   const uint64_t seed_a = p.drop_a16 ? seed_mix(p.seed_ptr, p.salt_a) : 0;
+  const uint32_t wvo = lane * 16;
 
 #pragma unroll 1
-  for (int s = 0; s < NS; ++s) {                                     // (a real loop: unrolled, its six bodies spill)
+  for (int s = 0; s < NS; ++s) {                                     // (a real loop: unrolled, its bodies spill)
     const int cur = s & 1;
     const int h = 2 * s + hsel;
     if (s + 1 < NS) stage_pair(s + 1, cur ^ 1);                      // (a) next pair's K/V: in flight under the attention core
@@ -170,35 +234,39 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
-    const char* Ks = kvb + cur * KVBUF + (2 * hsel) * KVT;
-    const char* Vs = Ks + KVT;
+    const uint32_t kt = lds0 + cur * KVBUF + (2 * hsel) * KVT;
+    uint32_t ka[4], va[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ka[i] = kb[i] + kt; va[i] = vb[i] + kt + KVT; }
     f32x16 st[NT];
     {
       bf16x8 kf[2][4];
-      lds_rd4(lds_addr(Ks + swz(l31, g)), lds_addr(Ks + swz(l31, 2 + g)), lds_addr(Ks + swz(l31, 4 + g)), lds_addr(Ks + swz(l31, 6 + g)), kf[0]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int kk = 0; kk < 4; ++kk) ds_rd<0>(kf[0][kk], ka[kk]);
+      static_for<NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
         XA_LGKM0();
         XA_SB();
-        if (t + 1 < NT) {
-          const int r = (t + 1) * 32 + l31;
-          lds_rd4(lds_addr(Ks + swz(r, g)), lds_addr(Ks + swz(r, 2 + g)), lds_addr(Ks + swz(r, 4 + g)), lds_addr(Ks + swz(r, 6 + g)), kf[(t + 1) & 1]);
+        if constexpr (t + 1 < NT) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ds_rd<(t + 1) * 4096>(kf[(t + 1) & 1][kk], ka[kk]);
         }
         st[t] = zero16();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(kf[t & 1][kk], qf[kk], st[t]);
         XA_SB();
-      }
+      });
     }
     // V^T fragments of key tile 0 start now and land under the softmax arithmetic
     bf16x4 vr[2][8];
-    tr_issue(Vs, 0, lane, vr[0]);
+    ds_rd_tr<0>(vr[0][0], va[0]); ds_rd_tr<0>(vr[0][1], va[1]); ds_rd_tr<0>(vr[0][2], va[2]); ds_rd_tr<0>(vr[0][3], va[3]);
+    ds_rd_tr<2048>(vr[0][4], va[0]); ds_rd_tr<2048>(vr[0][5], va[1]); ds_rd_tr<2048>(vr[0][6], va[2]); ds_rd_tr<2048>(vr[0][7], va[3]);
     float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    static_for<NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
       f32x4 bias[4];
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) lds_rd1(lds_addr(mb + t * 32 + 8 * gq + 4 * g), bias[gq]);
+      ds_rd<(t * 32 + 0) * 4>(bias[0], mba); ds_rd<(t * 32 + 8) * 4>(bias[1], mba);
+      ds_rd<(t * 32 + 16) * 4>(bias[2], mba); ds_rd<(t * 32 + 24) * 4>(bias[3], mba);
       XA_LGKM0();
       XA_SB();
 #pragma unroll
@@ -209,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
           st[t][gq * 4 + j] = sc;
           mx = fmaxf(mx, sc);
         }
-    }
+    });
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
@@ -239,52 +307,52 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
         }
     }
     f32x16 ot[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    static_for<NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
       const bf16x8 pf0 = pack8(st[t], 0), pf1 = pack8(st[t], 1);
       XA_LGKM0();
       XA_SB();
-      if (t + 1 < NT) tr_issue(Vs, (t + 1) * 32, lane, vr[(t + 1) & 1]);
+      if constexpr (t + 1 < NT) {
+        constexpr int o = (t + 1) * 4096;
+        bf16x4(&n)[8] = vr[(t + 1) & 1];
+        ds_rd_tr<o>(n[0], va[0]); ds_rd_tr<o>(n[1], va[1]); ds_rd_tr<o>(n[2], va[2]); ds_rd_tr<o>(n[3], va[3]);
+        ds_rd_tr<o + 2048>(n[4], va[0]); ds_rd_tr<o + 2048>(n[5], va[1]); ds_rd_tr<o + 2048>(n[6], va[2]); ds_rd_tr<o + 2048>(n[7], va[3]);
+      }
       const bf16x4(&v)[8] = vr[t & 1];
       ot[0] = MFMA32(join8(v[0], v[1]), pf0, ot[0]);
       ot[1] = MFMA32(join8(v[2], v[3]), pf0, ot[1]);
       ot[0] = MFMA32(join8(v[4], v[5]), pf1, ot[0]);
       ot[1] = MFMA32(join8(v[6], v[7]), pf1, ot[1]);
       XA_SB();
-    }
+    });
     {
       const float osc = p.drop_a16 ? inv * p.scale_a : inv;
-      const unsigned rowb = lds_addr(ctxs + myq * 256) + g * 8;
+      int x = myq & 15;
+      asm volatile("" : "+v"(x));                                    // (recomputed per step: eight hoisted addresses would stay live across the loop)
+      const uint32_t rowb = lds0 + L::O_CTX + myq * 256 + g * 8;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int ch = hsel * 8 + dt * 4 + gq;                      // 16-B chunk of the [64][128] panel: d = dt*32 + 8*gq + 4*g ..
-          lds_wr8(rowb + ((ch ^ (myq & 15)) << 4), to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc,
-                                                             ot[dt][gq * 4 + 3] * osc));
+          ds_wr8(rowb + ((ch ^ x) << 4), to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc, ot[dt][gq * 4 + 3] * osc));
         }
     }
     XA_LGKM0();
     __builtin_amdgcn_s_barrier();                                    // barrier A: the context panel of this pair is complete
     XA_SB();
+    XA_STAMP(2 + 2 * s);
     // ------------------------------------------------------------------ (c) output projection, K slice [128 s, 128 s + 128)
     if (p.CTX) {                                                     // the panel leaves row-major, 16 B per lane, 256 B per row
       u32x4 cv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-        lds_rd1(lds_addr(ctxs + row * 256) + ((ch ^ (row & 15)) << 4), cv[i]);
-      }
+      ds_rd<0>(cv[0], cva); ds_rd<4096>(cv[1], cva); ds_rd<8192>(cv[2], cva); ds_rd<12288>(cv[3], cva);
       XA_LGKM0();
       XA_SB();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-        if (row < nvalid) *(u32x4*)(p.CTX + (qrow + row) * p.ldc + s * 128 + ch * 8) = cv[i];
+        const int row = (tid >> 4) + 16 * i;
+        if (row < nvalid) *(u32x4*)(p.CTX + (qrow + row) * p.ldc + s * 128 + (tid & 15) * 8) = cv[i];
       }
-    } else {
-      XA_LGKM0();
-      XA_SB();
     }
     if (s + 1 < NS) {                                                // Q fragments of the next head (ordinary loads: used next step)
       const bf16* Qg = p.Q + (qrow + myqc) * p.ldq + (h + 2) * HD;
@@ -294,71 +362,84 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     if (s == NS - 1) {
       // K/V buffers are free from here on (barrier A): the residual panel streams into them under the last projection step.
       // Rows past the sequence re-read its last valid row (finite, never stored).
-      for (int id = tid; id < 64 * C16; id += 256) {
+      const char* rg = (const char*)(p.R + qrow * p.ldr);
+      for (int i = 0; i < 64 * C16 / 256; ++i) {
+        const int id = tid + 256 * i;
         const int row = id / C16, c16 = (id % C16) ^ (row & 15);
         const int rr = row < nvalid ? row : nvalid - 1;
-        const bf16* gsrc = p.R + (qrow + rr) * p.ldr + c16 * 8;
-        const int wave_base = __builtin_amdgcn_readfirstlane((id & ~63) * 16);
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)(kvb + wave_base), 16, 0, 0);
+        glds16((uint32_t)((rr * p.ldr + c16 * 8) * 2), rg, lds0 + wave * 1024 + i * 4096);
       }
     }
     {
-      // B operands: row = a*32 + l31, k = g*64 + kk*8 .. (head g of the pair), four k-steps at a time (32 registers instead of 64)
-      const bf16x8* wb = (const bf16x8*)p.WoF + ((long)(s * 4 + wave) * NCT * 8) * 64 + lane;
+      // A operands from the fragment-ordered image, D x 1 KiB in flight per wave: fragment j = (kh*NCT + ct)*4 + kk feeds two MFMAs
+      // (row tiles 0 / 1); B operands: row = a*32 + l31, k = g*64 + kh*32 + kk*8 .. (head g of the pair) from the context panel.
+      const char* wbase = (const char*)p.WoF + ((long)(s * 4 + wave) * NF) * 1024;
+      bf16x8 ring[D];
+      auto issue = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int kh = j / (NCT * 4), ct = (j / 4) % NCT, kk = j % 4;
+        gl_ld16<kk * 1024>(ring[j % D], wvo, wbase + (ct * 2 + kh) * 4096);
+      };
+      static_for<D>(issue);
+      int x = l31 & 15;
+      asm volatile("" : "+v"(x));
+      const uint32_t cfb = lds0 + L::O_CTX + l31 * 256;
+      bf16x8 cf[2][4];
+      auto load_cf = [&](int kh) {
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        bf16x8 cf[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int row = a * 32 + l31;
-          const unsigned rb2 = lds_addr(ctxs + row * 256);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) lds_rd1(rb2 + (((g * 8 + kh * 4 + kk) ^ (row & 15)) << 4), cf[a][kk]);
+        for (int kk = 0; kk < 4; ++kk) {
+          const uint32_t a0 = cfb + (((g * 8 + kh * 4 + kk) ^ x) << 4);
+          ds_rd<0>(cf[0][kk], a0);
+          ds_rd<8192>(cf[1][kk], a0);
         }
         XA_LGKM0();
         XA_SB();
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          bf16x8 wf[4];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) wf[kk] = wb[(ct * 8 + kh * 4 + kk) * 64];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            acc[0][ct] = MFMA32(wf[kk], cf[0][kk], acc[0][ct]);
-            acc[1][ct] = MFMA32(wf[kk], cf[1][kk], acc[1][ct]);
-          }
-        }
-      }
+      };
+      load_cf(0);
+      static_for<NF>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int ct = (j / 4) % NCT, kk = j % 4;
+        if constexpr (j == NCT * 4) load_cf(1);
+        constexpr int younger = NF - 1 - j < D - 1 ? NF - 1 - j : D - 1;
+        XA_VM(younger);
+        XA_SB();
+        acc[0][ct] = MFMA32(ring[j % D], cf[0][kk], acc[0][ct]);
+        acc[1][ct] = MFMA32(ring[j % D], cf[1][kk], acc[1][ct]);
+        XA_SB();
+        if constexpr (j + D < NF) issue(std::integral_constant<int, j + D>{});
+      });
     }
     if (s + 1 < NS) asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]));      // waited for before the next DMA is issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's share of the next pair's K/V (or the residual) has landed
+    XA_VM(0);                                                        // this wave's share of the next pair's K/V (or the residual) has landed
     XA_LGKM0();
     __builtin_amdgcn_s_barrier();                                    // barrier B
     XA_SB();
+    XA_STAMP(3 + 2 * s);
   }
 
   // ---------------------------------------------------------------------------------------------------- epilogue
   // accumulator layout: lane (row = a*32 + l31, g) holds columns wave*WN + ct*32 + 8*gq + 4*g + {0..3} in acc[a][ct][gq*4 ..]
   const char* rs = kvb;                                              // residual image; z and then y overwrite it in place
   const uint64_t seed_h = p.drop_h16 ? seed_mix(p.seed_ptr, p.salt_h) : 0;
+  const bool hdrop = p.drop_h16 != 0;
   float rsum[2] = {0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int row = a * 32 + l31;
-    const uint32_t rowkey = p.drop_h16 ? drop_rowkey(seed_h, (uint64_t)(p.row_base + qrow + row)) : 0u;
+    const uint32_t rowkey = hdrop ? drop_rowkey(seed_h, (uint64_t)(p.row_base + qrow + row)) : 0u;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
-        const f32x4 b4 = *(const f32x4*)(p.bo + c);
+        const f32x4 b4 = *(const f32x4*)(vec + c);
         const bf16x4 r4 = *(const bf16x4*)(rs + pslot<C16>(row, c >> 3) * 16 + g * 8);
         bool keep[4] = {true, true, true, true};
-        if (p.drop_h16) drop_keep4(rowkey, c, p.drop_h16, keep);
+        if (hdrop) drop_keep4(rowkey, c, p.drop_h16, keep);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = acc[a][ct][gq * 4 + j] + b4[j];
-          if (p.drop_h16) v = keep[j] ? v * p.scale_h : 0.f;
+          v = hdrop ? (keep[j] ? v * p.scale_h : 0.f) : v;
           v += (float)r4[j];
           acc[a][ct][gq * 4 + j] = v;
           rsum[a] += v;
@@ -371,6 +452,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     if (g == 0) red[wave * 64 + a * 32 + l31] = rsum[a];
   }
   __syncthreads();
+  XA_STAMP(20);
   float mean[2], rstd[2], rss[2] = {0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -406,6 +488,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     if (!(var + p.eps > 0.f)) rstd[a] = 0.f;
     if (p.mean && wave == 0 && g == 0 && row < nvalid) { p.mean[qrow + row] = mean[a]; p.rstd[qrow + row] = rstd[a]; }
   }
+  XA_STAMP(21);
   if (p.Z) {
     for (int id = tid; id < 64 * C16; id += 256) {
       const int row = id / C16, c16 = id % C16;
@@ -421,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
-        const f32x4 gm = *(const f32x4*)(p.gamma + c), bt = *(const f32x4*)(p.beta + c);
+        const f32x4 gm = *(const f32x4*)(vec + H + c), bt = *(const f32x4*)(vec + 2 * H + c);
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (acc[a][ct][gq * 4 + j] - mean[a]) * rstd[a] * gm[j] + bt[j];
@@ -429,10 +512,12 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
       }
   }
   __syncthreads();
+  XA_STAMP(22);
   for (int id = tid; id < 64 * C16; id += 256) {
     const int row = id / C16, c16 = id % C16;
     if (row < nvalid) *(u32x4*)(p.Y + (qrow + row) * p.ldy + c16 * 8) = *(const u32x4*)(kvb + pslot<C16>(row, c16) * 16);
   }
+  XA_STAMP(23);
 }
 
 // Wo [H, H] bf16 row-major ([out, in]) -> fragment order: element e of the 16-byte piece ((s*4 + w)*NCT + ct)*8 + kk of lane l is
@@ -455,10 +540,7 @@ __global__ void xattn_pack_wo_kernel(const bf16* __restrict__ W, long ldw, bf16x
 }
 
 template <int NT, int NCT>
-constexpr int xattn_lds() {
-  constexpr int H = 128 * NCT, KVBUF = 4 * NT * 32 * ROWB, PANEL = 64 * H * 2;
-  return (2 * KVBUF > PANEL ? 2 * KVBUF : PANEL) + 64 * 256 + 128 * 4 + 512 * 4;
-}
+constexpr int xattn_lds() { return XaLds<NT, NCT>::TOTAL; }
 
 template <int NT, int NCT>
 int launch_xattn(const XattnP& p, dim3 grid, hipStream_t stream) {

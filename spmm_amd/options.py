@@ -43,8 +43,9 @@ class EngineOptions:
     grad_wire: str = "fp32"       # "fp32": all-reduce on the arena; "bf16": cast + reduce-scatter + all-gather (half the link bytes)
     nt_under_comm: str = "tiles"  # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile) or "persistent"
     force_dist: bool = False      # run the N>1 code path with a one-rank process group (tests on a one-GPU box)
-    probe_streams: bool = True    # at start-up of a data-parallel run, check that RCCL's stream and the compute streams sit on
-    #                               different hardware queues and re-draw a compute stream that does not (spmm_amd/streams.py)
+    probe_streams: bool = False   # diagnostic: at start-up of a data-parallel run, check that RCCL's stream and the compute streams sit on
+    #                               different hardware queues and re-draw one that does not (spmm_amd/streams.py: the probe's own
+    #                               streams change the queue order, and some orders cost 20 ms per step -- off by default)
 
     @classmethod
     def from_env(cls, **overrides) -> "EngineOptions":

@@ -4,9 +4,15 @@ HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; be
 share a queue SERIALISE.  Which queue a stream gets depends on how many streams the process created before it, so every model of a
 process draws its side streams from this one pool (two models = the same three streams, not six) in a fixed order: the names below.
 A data-parallel run adds RCCL's internal stream (the one `async_op=True` collectives really run on), which this package cannot
-create or see -- `place_beside_collectives` therefore PROBES: a long sleep kernel on a compute stream, a tiny collective issued from
+create or see -- `place_beside_collectives` PROBES it: a long sleep kernel on a compute stream, a tiny collective issued from
 an idle stream, and host-side polling of both completions; a collective that only completes after the sleep shares the compute
-stream's queue, and that compute stream is re-drawn (at most a few times) until the probe passes."""
+stream's queue, and that compute stream is re-drawn (at most a few times) until the probe passes.
+
+The probe is a DIAGNOSTIC (EngineOptions.probe_streams, off by default).  Measured with a one-rank RCCL group (profiles/
+r03_probe_variants.txt): the streams the probe itself touches change the order in which streams receive their hardware queues,
+and some orders -- not explained by queue sharing: the probe reports every pair independent in them -- run the whole step at
+80 ms instead of 60-61.  The order the product produces by itself (first collective = the start-up broadcast, then side0, side1)
+is among the fast ones, so the product leaves it alone."""
 from __future__ import annotations
 
 import time
@@ -87,31 +93,10 @@ def place_beside_collectives(device, names=("side0", "side1", "wgrad"), max_redr
     queue with the stream RCCL runs asynchronous collectives on.  Returns {stream name: "ok" | "redrawn xN" | "COLLIDES"}; the
     current stream cannot be re-drawn, a collision there is reported (and printed once)."""
     import torch.distributed as dist
-    import os
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    var = os.environ.get("SPMM_PROBE_VARIANT", "")      # TEMPORARY experiment switch
-    if var == "wgrad_only":                              # no probe: only create + touch the wgrad stream
-        with torch.cuda.stream(get(idx, "wgrad")):
-            torch.zeros(8, device=f"cuda:{idx}").add_(1.0)
-        torch.cuda.synchronize(); return {}
-    if var == "early_rccl":                              # no probe: only an early collective (RCCL's stream exists before the side streams)
-        dist.all_reduce(torch.zeros(256, device=f"cuda:{idx}")); torch.cuda.synchronize(); return {}
-    if var == "sleep_only":
-        for n in ("side0", "side1"):
-            with torch.cuda.stream(get(idx, n)):
-                torch.cuda._sleep(16000000)
-        torch.cuda.synchronize(); return {}
-    if var == "sides_first":                             # touch side0/side1 first, then an early collective
-        for n in ("side0", "side1"):
-            with torch.cuda.stream(get(idx, n)):
-                torch.zeros(8, device=f"cuda:{idx}").add_(1.0)
-        torch.cuda.synchronize()
-        dist.all_reduce(torch.zeros(256, device=f"cuda:{idx}")); torch.cuda.synchronize(); return {}
-    if var == "no_wgrad":
-        names = ("side0", "side1")
     t = torch.zeros(256, device=f"cuda:{idx}")
-    idle = torch.cuda.current_stream(idx) if var == "no_idle" else torch.cuda.Stream(device=idx)   # the collective's implicit dependency: a stream with nothing on it
+    idle = torch.cuda.Stream(device=idx)             # the collective's implicit dependency: a stream with nothing on it
 
     def issue():
         with torch.cuda.stream(idle):

@@ -6,9 +6,9 @@ import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('$tag', d['step_ms']['median'], d.get('stream_placement'))"; }
-p=29800
-run plain "" SPMM_FORCE_DIST=0
-for v in "" wgrad_only early_rccl sleep_only sides_first no_wgrad no_idle; do
+p=29900
+for v in measure_after measure_after; do
   p=$((p+1)); run "probe_$v" "" SPMM_FORCE_DIST=1 SPMM_PROBE_VARIANT=$v MASTER_PORT=$p
 done
-p=$((p+1)); run noprobe "" SPMM_FORCE_DIST=1 SPMM_PROBE_STREAMS=0 MASTER_PORT=$p
+p=$((p+1)); run "noov" "" SPMM_FORCE_DIST=1 SPMM_PROBE_STREAMS=0 SPMM_GRAD_OVERLAP=0 MASTER_PORT=$p
+p=$((p+1)); run "probe_noov" "" SPMM_FORCE_DIST=1 SPMM_GRAD_OVERLAP=0 MASTER_PORT=$p
