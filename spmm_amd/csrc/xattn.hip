@@ -88,10 +88,24 @@ __device__ __forceinline__ void ds_wr8(uint32_t addr, bf16x4 v) { asm volatile("
 __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
+// stores in the same SGPR-base form (a 64-bit per-lane pointer kept live across the loop gets spilled, and every reload of it is
+// a vmcnt(0) that drains the prefetch ring)
+__device__ __forceinline__ void gl_st16(uint32_t voff, const void* sbase, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gl_st4(uint32_t voff, const void* sbase, float v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 // asynchronous 16-byte global load into registers: SGPR base + VGPR byte offset + immediate
 template <int IMM>
 __device__ __forceinline__ void gl_ld16(bf16x8& d, uint32_t voff, const void* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+// ... into ACCUMULATOR registers (gfx950: one 512-entry file, loads may target either half, MFMA reads A operands from either): the
+// prefetch ring lives beside the 192 accumulators and leaves the 256 architectural VGPRs to the attention core
+template <int IMM>
+__device__ __forceinline__ void gl_ld16a(bf16x8& d, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&a"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
 }
 
 // LDS image of a [64][H] bf16 panel (residual in, z / y out): 16-byte chunk c16 of row r sits at slot r * C16 + (c16 ^ (r & 15)).
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
   constexpr int H = 128 * NCT, NS = NCT, WN = 32 * NCT, C16 = H / 8;
   constexpr int KVT = L::KVT, KVBUF = L::KVBUF;
   constexpr int NF = 8 * NCT;                    // Wo fragments per wave and step (1 KiB each)
-  constexpr int D = NF < 12 ? NF : 12;           // ... of which D are in flight
+  constexpr int D = NF < 12 ? NF : 12;           // ... of which D are in flight, in ACCUMULATOR registers (16 spill inside the loop: every reload drains the DMA)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
   char* kvb = smem;
@@ -156,14 +170,17 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
   for (int j = tid; j < H; j += 256) { vec[j] = p.bo[j]; vec[H + j] = p.gamma[j]; vec[2 * H + j] = p.beta[j]; }
 
-  bf16x8 qn[4];                                  // Q fragments of the NEXT step (B operand: row = lane&31, d = (kk*2+g)*8 ..)
-  {
-    const bf16* Qg = p.Q + (qrow + myqc) * p.ldq + hsel * HD;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qn[kk] = *(const bf16x8*)(Qg + (kk * 2 + g) * 8);
-  }
-  asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]));      // the loads are waited for HERE, before any DMA is in flight
+  // Q fragments of the NEXT step (B operand: row = lane&31, d = (kk*2+g)*8 ..), by asm loads like everything else that is in
+  // flight across the loop (a compiler-visible load would be waited for with vmcnt(0), draining the prefetch ring with it)
+  bf16x8 qn[4];
+  const char* Qb = (const char*)(p.Q + qrow * p.ldq + hsel * HD);
+  const uint32_t qvo = (uint32_t)((myqc * p.ldq) * 2 + g * 16);
+  auto load_q = [&](int s) {
+    const char* qb = Qb + s * (2 * HD * 2);
+    gl_ld16<0>(qn[0], qvo, qb); gl_ld16<32>(qn[1], qvo, qb); gl_ld16<64>(qn[2], qvo, qb); gl_ld16<96>(qn[3], qvo, qb);
+  };
   __syncthreads();                               // mb / vec visible (no DMA pending yet: a plain barrier)
+  load_q(0);
 
   // ---- K/V staging: lane-linear LDS image, swizzle on the source chunk (attn_tiles.h stage_head), as SGPR-base DMA
   const char* Kg = (const char*)(p.K + kvrow * p.ldk);
@@ -193,6 +210,18 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     }
   };
   stage_pair(0, 0);
+  // Wo fragment ring: A operands from the fragment-ordered image, D x 1 KiB in flight per wave.  Fragment j = (kh*NCT + ct)*4 + kk of a
+  // step feeds two MFMAs (row tiles 0 / 1).  The first D fragments of a step are issued right after the attention core's last MFMA
+  // (they land under the context-panel exchange).  They are NOT carried across the loop's back edge: an asm-loaded register
+  // that the compiler copies before its data has landed (phi copies) holds garbage -- seen with D = 12, tests caught it.
+  bf16x8 ring[D];
+  const uint32_t wvo = lane * 16;
+  const char* Wb = (const char*)p.WoF + (long)wave * NF * 1024;
+  auto issue = [&](auto jc, const char* wbase) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int kh = j / (NCT * 4), ct = (j / 4) % NCT, kk = j % 4;
+    gl_ld16<kk * 1024>(ring[j % D], wvo, wbase + (ct * 2 + kh) * 4096);
+  };
   XA_VM(0);
   __builtin_amdgcn_s_barrier();
   XA_SB();
@@ -221,8 +250,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = zero16();
 
-  const uint64_t seed_a = p.drop_a16 ? seed_mix(p.seed_ptr, p.salt_a) : 0;
-  const uint32_t wvo = lane * 16;
+  uint64_t seed_a = p.drop_a16 ? seed_mix(p.seed_ptr, p.salt_a) : 0;
+  seed_a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(seed_a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_a);   // scalar registers
 
 #pragma unroll 1
   for (int s = 0; s < NS; ++s) {                                     // (a real loop: unrolled, its bodies spill)
@@ -234,6 +263,9 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));      // (real copies: qn is reloaded right away)
+    if (s + 1 < NS) load_q(s + 1);
+    XA_SB();
     const uint32_t kt = lds0 + cur * KVBUF + (2 * hsel) * KVT;
     uint32_t ka[4], va[4];
 #pragma unroll
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
     const int qpos = r0p + myq;                                      // position inside the sequence
-    if (p.LSE && myq < nvalid && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + qpos] = mx * LN2 + __logf(sum);
+    if (p.LSE && myq < nvalid && g == 0) gl_st4((uint32_t)(myq * 4), p.LSE + ((long)seq * p.nH + h) * p.Lq + r0p, mx * LN2 + __logf(sum));
     if (p.drop_a16) {
       const uint32_t rowkey = drop_rowkey(seed_a, ((uint64_t)seq * p.nH + h) * p.Lq + qpos);
 #pragma unroll
@@ -325,6 +357,9 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
       ot[1] = MFMA32(join8(v[6], v[7]), pf1, ot[1]);
       XA_SB();
     });
+    const char* wbase = Wb + (long)s * (4 * NF * 1024);
+    static_for<D>([&](auto jc) { issue(jc, wbase); });
+    XA_SB();
     {
       const float osc = p.drop_a16 ? inv * p.scale_a : inv;
       int x = myq & 15;
@@ -343,44 +378,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     XA_SB();
     XA_STAMP(2 + 2 * s);
     // ------------------------------------------------------------------ (c) output projection, K slice [128 s, 128 s + 128)
-    if (p.CTX) {                                                     // the panel leaves row-major, 16 B per lane, 256 B per row
-      u32x4 cv[4];
-      ds_rd<0>(cv[0], cva); ds_rd<4096>(cv[1], cva); ds_rd<8192>(cv[2], cva); ds_rd<12288>(cv[3], cva);
-      XA_LGKM0();
-      XA_SB();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + 16 * i;
-        if (row < nvalid) *(u32x4*)(p.CTX + (qrow + row) * p.ldc + s * 128 + (tid & 15) * 8) = cv[i];
-      }
-    }
-    if (s + 1 < NS) {                                                // Q fragments of the next head (ordinary loads: used next step)
-      const bf16* Qg = p.Q + (qrow + myqc) * p.ldq + (h + 2) * HD;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qn[kk] = *(const bf16x8*)(Qg + (kk * 2 + g) * 8);
-    }
-    if (s == NS - 1) {
-      // K/V buffers are free from here on (barrier A): the residual panel streams into them under the last projection step.
-      // Rows past the sequence re-read its last valid row (finite, never stored).
-      const char* rg = (const char*)(p.R + qrow * p.ldr);
-      for (int i = 0; i < 64 * C16 / 256; ++i) {
-        const int id = tid + 256 * i;
-        const int row = id / C16, c16 = (id % C16) ^ (row & 15);
-        const int rr = row < nvalid ? row : nvalid - 1;
-        glds16((uint32_t)((rr * p.ldr + c16 * 8) * 2), rg, lds0 + wave * 1024 + i * 4096);
-      }
-    }
+    // B operands: row = a*32 + l31, k = g*64 + kh*32 + kk*8 .. (head g of the pair) from the context panel.
     {
-      // A operands from the fragment-ordered image, D x 1 KiB in flight per wave: fragment j = (kh*NCT + ct)*4 + kk feeds two MFMAs
-      // (row tiles 0 / 1); B operands: row = a*32 + l31, k = g*64 + kh*32 + kk*8 .. (head g of the pair) from the context panel.
-      const char* wbase = (const char*)p.WoF + ((long)(s * 4 + wave) * NF) * 1024;
-      bf16x8 ring[D];
-      auto issue = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int kh = j / (NCT * 4), ct = (j / 4) % NCT, kk = j % 4;
-        gl_ld16<kk * 1024>(ring[j % D], wvo, wbase + (ct * 2 + kh) * 4096);
-      };
-      static_for<D>(issue);
       int x = l31 & 15;
       asm volatile("" : "+v"(x));
       const uint32_t cfb = lds0 + L::O_CTX + l31 * 256;
@@ -401,16 +400,48 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
         constexpr int ct = (j / 4) % NCT, kk = j % 4;
         if constexpr (j == NCT * 4) load_cf(1);
         constexpr int younger = NF - 1 - j < D - 1 ? NF - 1 - j : D - 1;
-        XA_VM(younger);
+        // j == 0: everything older has to be in anyway -- the next pair's K/V (issued a whole attention core ago), the next Q
+        // fragments, this step's first D ring fragments; later waits count the ring fragments issued after the one needed
+        // (the context stores / the residual DMA below are younger too: they only make some waits stricter)
+        if constexpr (j == 0) XA_VM(0); else XA_VM(younger);
         XA_SB();
         acc[0][ct] = MFMA32(ring[j % D], cf[0][kk], acc[0][ct]);
         acc[1][ct] = MFMA32(ring[j % D], cf[1][kk], acc[1][ct]);
         XA_SB();
-        if constexpr (j + D < NF) issue(std::integral_constant<int, j + D>{});
+        if constexpr (j + D < NF) issue(std::integral_constant<int, j + D>{}, wbase);
+        if constexpr (j == 3) {
+          if (p.CTX) {                                               // the panel leaves row-major, 16 B per lane, 256 B per row
+            // (read HERE, not earlier: a register filled by an asynchronous asm read must not stay live across other asynchronous
+            // loads -- with the reads ahead of the fragment ring the first of the four came out clobbered)
+            u32x4 cv[4];
+            ds_rd<0>(cv[0], cva); ds_rd<4096>(cv[1], cva); ds_rd<8192>(cv[2], cva); ds_rd<12288>(cv[3], cva);
+            XA_LGKM0();
+            XA_SB();
+            const char* cb = (const char*)(p.CTX + qrow * p.ldc + s * 128);
+            int tl = tid;
+            asm volatile("" : "+v"(tl));                             // (offsets recomputed here: hoisted out of the loop they get spilled)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = (tl >> 4) + 16 * i;
+              if (row < nvalid) gl_st16((uint32_t)((row * p.ldc + (tl & 15) * 8) * 2), cb, cv[i]);
+            }
+          }
+          if (s == NS - 1) {
+            // K/V buffers are free from here on (barrier A): the residual panel streams into them under the last projection step.
+            // Rows past the sequence re-read its last valid row (finite, never stored).
+            const char* rg = (const char*)(p.R + qrow * p.ldr);
+            for (int i = 0; i < 64 * C16 / 256; ++i) {
+              const int id = tid + 256 * i;
+              const int row = id / C16, c16 = (id % C16) ^ (row & 15);
+              const int rr = row < nvalid ? row : nvalid - 1;
+              glds16((uint32_t)((rr * p.ldr + c16 * 8) * 2), rg, lds0 + wave * 1024 + i * 4096);
+            }
+          }
+          XA_SB();
+        }
       });
     }
-    if (s + 1 < NS) asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]));      // waited for before the next DMA is issued
-    XA_VM(0);                                                        // this wave's share of the next pair's K/V (or the residual) has landed
+    if (s == NS - 1) XA_VM(0);                                       // the residual panel has landed (this wave's share)
     XA_LGKM0();
     __builtin_amdgcn_s_barrier();                                    // barrier B
     XA_SB();

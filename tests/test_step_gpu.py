@@ -187,6 +187,13 @@ def test_fp8_ffn_forward_tracks_the_bf16_pipeline(env):
     print("bf16", out["bf16"], "fp8", out["fp8"], "diff", d)
     assert np.all(np.isfinite(out["fp8"])) and np.all(d < np.array([5e-3, 0.15, 3e-2, 1e-2])), d
     assert d.max() > 0                                           # the fp8 path really ran
+    # ... and against the fp32 CPU oracle (the parity yard-stick; the bf16 pipeline's own deviation at this shape is
+    # 6.4e-5 / 3.2e-3 / 4.1e-3 / 2.5e-3, LOSS_ATOL["full_depth_b8"]): stated fp8 tolerance = the sum of the two budgets
+    with torch.no_grad():
+        ref = np.array([float(x) for x in O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)])
+    do = np.abs(out["fp8"] - ref)
+    print("oracle", ref, "|fp8 - oracle|", do)
+    assert np.all(do < np.array([5e-3, 0.15, 3e-2, 1e-2]) + np.array(LOSS_ATOL["full_depth_b8"])), do
     # training: fused steps with the fp8 forward (bf16 backward on the saved activations) still descend
     sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20, 'cooldown_epochs': 0}
     tc = {'embed_dim': 256, 'temp': 0.07, 'queue_size': 1024, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
@@ -201,6 +208,49 @@ def test_fp8_ffn_forward_tracks_the_bf16_pipeline(env):
         last = sum(l)
     print("fp8-forward training: total loss", first, "->", last)
     assert last < first
+
+
+def test_fused_cross_attention_inside_the_step(env):
+    """EngineOptions.fused_xattn: the cross-attention blocks of every fusion layer as ONE launch each (csrc/xattn.hip) inside the real
+    step -- H=768, 2+2 layers, packed text rows, shared K/V sources, train mode with dropout.  Both forms draw the same dropout
+    masks, so losses and the whole gradient must agree with the composite's to rounding (the fused kernel keeps the dense output
+    in fp32 where the composite rounds it to bf16 before the LayerNorm), and the losses match the oracle within the usual budget
+    with dropout off."""
+    O, SPMM, *_ = env
+    from spmm_amd.options import EngineOptions
+    cfg, ocfg = _mid_cfg(env)
+    sd = O.init_state_dict(ocfg, seed=3)
+    B, Lt = 8, 48
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=21)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(1))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
+    sched = {'sched': 'cosine', 'lr': 5e-5, 'epochs': 30, 'min_lr': 1e-5, 'decay_rate': 1, 'warmup_lr': 5e-5, 'warmup_epochs': 20, 'cooldown_epochs': 0}
+    tc = {'embed_dim': 256, 'temp': 0.07, 'queue_size': 64, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
+          'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
+    res = {}
+    for fused in (False, True):
+        m = SPMM(config=tc, spmm_config=cfg, options=EngineOptions.from_env(fused_xattn=fused))
+        m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+        m.train()
+        m.engine.seed.fill_(777)
+        l = [float(x) for x in m.fused_step(*_cuda(prop, ids, mask), 0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))]
+        res[fused] = (np.array(l), m.store.grad.clone())
+        if fused:
+            m.eval()
+            with torch.no_grad():
+                got = np.array([float(x) for x in m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))])
+    print("composite", res[False][0], "fused", res[True][0])
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-3, atol=2e-3)
+    g0, g1 = res[False][1], res[True][1]
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    print("relative L2 difference of the whole gradient", rel)
+    assert rel < 2e-2
+    # (the eval forward above ran after one AdamW step at lr 5e-5: compare with the oracle on the UPDATED weights)
+    sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = np.array([float(x) for x in O.spmm_forward(sd2, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)])
+    print("fused eval", got, "oracle", ref)
+    assert_losses(got, ref, "h768_2layer")
 
 
 def test_full_depth_forward_matches_oracle(env):
