@@ -418,12 +418,12 @@ def main():
         eng = model.engine
         orig_blk = eng._attn_block_fwd
 
-        def blk(pfx, c, X, groups, save, cross):
+        def blk(pfx, c, X, groups, save, cross, X32=None):
             if not cross:
-                return orig_blk(pfx, c, X, groups, save, cross)
+                return orig_blk(pfx, c, X, groups, save, cross, X32=X32)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            r = orig_blk(pfx, c, X, groups, save, cross)
+            r = orig_blk(pfx, c, X, groups, save, cross, X32=X32)
             e1.record(stream)
             fl = sum(cross_attn_unit_flops(g.nseq, g.L, g.Lkv) for g in groups)
             ev["xattn"].append((e0, e1, (fl, cross_attn_executed_flops(groups, X.shape[0]))))

@@ -130,6 +130,11 @@ int spmm_segment_sum_bf16(const void* src, const int* start, const int* list, vo
 int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* zout, float* mean,
                 float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr, uint64_t salt,
                 spmm_stream_t stream);
+/* The same with the fp32 residual stream (EngineOptions.resid_fp32): res32 is read in fp32, the normalised row is
+ * written as bf16 (y: the MFMA operand of the next GEMM) AND fp32 (y32: the next residual / the loss heads' input; may be null). */
+int spmm_ln_fwd_r32(const void* x, const float* res32, const float* gamma, const float* beta, void* y, float* y32, void* zout,
+                    float* mean, float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr,
+                    uint64_t salt, spmm_stream_t stream);
 /* dz = dLN(dy + dy2); dx = dropout-mask(dz) when drop_on_dy == 0; drop_on_dy == 1 masks dy instead (embeddings);
  * dgamma/dbeta accumulate with atomics (may be null for frozen parameters); dxsum (optional) += column sums of dx,
  * i.e. the bias gradient of the dense layer whose output was normalised. */
@@ -202,11 +207,11 @@ int spmm_lm_loss(const float* logits, const float* logits_m, long ldl, const int
 /* itm_head + cross entropy SPMM_models.py:201-206 (forward and backward in one pass). */
 int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, int H, const float* W, const float* bias,
                   int n, int B, const float* gscale, float* losses, int loss_slot, float* logits_out, void* dxa, void* dxb,
-                  float* dW, float* db, int do_bwd, spmm_stream_t stream);
+                  float* dW, float* db, int do_bwd, int x_is_f32, spmm_stream_t stream);
 /* property_mtr_head final Linear(H,1) + masked MSE * 5 SPMM_models.py:251-256. */
 int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
                   int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
-                  float* dw, float* db, int do_bwd, spmm_stream_t stream);
+                  float* dw, float* db, int do_bwd, int x_is_f32, spmm_stream_t stream);
 /* ---- fp8 tier (BASELINE configs[4]; K6/K7 = xbert.py:434-451 with E4M3 operands, fp32 accumulation).
  * spmm_quant_rows_fp8: q[r][k] = e4m3(x[r][k] / scale[r]), scale[r] = max|x[r][:]| / 448; x bf16 or fp32.
  * spmm_gemm_nt_f8: C[M,N] (bf16) = epi((A8 W8^T) * sa[m] * sw[n] + bias) on the 8-phase 256x256 schedule with

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void lm_loss_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------- ITM head fwd+bwd (one wave per pair row)
 // vl[i] = [xa[rowa(i)] | xb[rowb(i)]] (bf16 rows of width H), logits = vl W^T + b (W [2, 2H] fp32), CE vs label
 // (1 for i < B else 0), mean over n = 3B rows.  Writes d xa / d xb rows (bf16) and accumulates dW, db.
-__global__ void itm_head_kernel(const bf16* __restrict__ xa, long stride_a, const bf16* __restrict__ xb, long stride_b, int H,
+template <typename TX>   // bf16, or float with the fp32 residual stream (EngineOptions.resid_fp32)
+__global__ void itm_head_kernel(const TX* __restrict__ xa, long stride_a, const TX* __restrict__ xb, long stride_b, int H,
                                 const float* __restrict__ W, const float* __restrict__ bias, int n, int B,
                                 const float* __restrict__ gscale, float* __restrict__ losses, int loss_slot,
                                 float* __restrict__ logits_out, bf16* __restrict__ dxa, bf16* __restrict__ dxb,
@@ -276,8 +277,8 @@ __global__ void itm_head_kernel(const bf16* __restrict__ xa, long stride_a, cons
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const bf16* a = xa + (long)i * stride_a;
-  const bf16* b = xb + (long)i * stride_b;
+  const TX* a = xa + (long)i * stride_a;
+  const TX* b = xb + (long)i * stride_b;
   float l0 = 0.f, l1 = 0.f;
   for (int c = lane; c < H; c += 64) {
     const float va = (float)a[c], vb = (float)b[c];
@@ -323,7 +324,8 @@ __global__ void count_keep_kernel(const float* __restrict__ mask, long n, int* _
 }
 // Workgroups stride over the rows; the loss, db and the H columns of dw are accumulated per wave in registers and leave as one
 // atomic per workgroup (per column): one atomic per ROW on the same addresses serialised the launch (~13 ns each).
-__global__ __launch_bounds__(256) void mpm_head_kernel(const bf16* __restrict__ h, int Lp, int H, const float* __restrict__ w, const float* __restrict__ bias,
+template <typename TX>
+__global__ __launch_bounds__(256) void mpm_head_kernel(const TX* __restrict__ h, int Lp, int H, const float* __restrict__ w, const float* __restrict__ bias,
                                 const float* __restrict__ target, const float* __restrict__ mask, int B, const int* __restrict__ n_keep,
                                 const float* __restrict__ gscale, float* __restrict__ losses, int loss_slot, float* __restrict__ pred_out,
                                 bf16* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db, int do_bwd) {
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void mpm_head_kernel(const bf16* __restrict__ 
   for (int i = 0; i < MAXC; ++i) dwacc[i] = 0.f;
   for (int r = blockIdx.x * 4 + wave; r < B * Lp; r += gridDim.x * 4) {   // r in [0, B*Lp)
     const int b = r / Lp, i = r - b * Lp;
-    const bf16* x = h + (long)r * H;
+    const TX* x = h + (long)r * H;
     bf16* d = dh ? dh + (long)r * H : nullptr;
     if (i == Lp - 1) {
       if (do_bwd && d) for (int c = lane; c < H; c += 64) d[c] = (bf16)0.f;
@@ -495,22 +497,31 @@ extern "C" int spmm_lm_loss(const float* logits, const float* logits_m, long ldl
 }
 extern "C" int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, int H, const float* W, const float* bias,
                              int n, int B, const float* gscale, float* losses, int loss_slot, float* logits_out, void* dxa, void* dxb,
-                             float* dW, float* db, int do_bwd, hipStream_t stream) {
+                             float* dW, float* db, int do_bwd, int x_is_f32, hipStream_t stream) {
   SPMM_CHECK_SHAPE(n > 0 && H > 0, "spmm_itm_head: n=%d H=%d", n, H);
   SPMM_CHECK_SHAPE(!do_bwd || (dxa && dxb && dW && db), "spmm_itm_head: backward outputs missing");
-  hipLaunchKernelGGL(itm_head_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16*)xa, stride_a, (const bf16*)xb, stride_b, H, W,
-                     bias, n, B, gscale, losses, loss_slot, logits_out, (bf16*)dxa, (bf16*)dxb, dW, db, do_bwd);
+  if (x_is_f32)
+    hipLaunchKernelGGL(itm_head_kernel<float>, dim3((n + 3) / 4), dim3(256), 0, stream, (const float*)xa, stride_a, (const float*)xb, stride_b, H, W,
+                       bias, n, B, gscale, losses, loss_slot, logits_out, (bf16*)dxa, (bf16*)dxb, dW, db, do_bwd);
+  else
+    hipLaunchKernelGGL(itm_head_kernel<bf16>, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16*)xa, stride_a, (const bf16*)xb, stride_b, H, W,
+                       bias, n, B, gscale, losses, loss_slot, logits_out, (bf16*)dxa, (bf16*)dxb, dW, db, do_bwd);
   SPMM_LAUNCH_CHECK("spmm_itm_head");
   return SPMM_OK;
 }
 extern "C" int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
                              int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
-                             float* dw, float* db, int do_bwd, hipStream_t stream) {
+                             float* dw, float* db, int do_bwd, int x_is_f32, hipStream_t stream) {
   SPMM_CHECK_SHAPE(B > 0 && Lp > 1 && H > 0 && H <= 1024, "spmm_mpm_head: B=%d Lp=%d H=%d (H <= 1024)", B, Lp, H);
   SPMM_CHECK_SHAPE(!do_bwd || (dh && dw && db), "spmm_mpm_head: backward outputs missing");
   hipLaunchKernelGGL(count_keep_kernel, dim3(1), dim3(256), 0, stream, mask, (long)B * (Lp - 1), n_keep_ws);
-  hipLaunchKernelGGL(mpm_head_kernel, dim3((B * Lp + 3) / 4 < 512 ? (B * Lp + 3) / 4 : 512), dim3(256), 0, stream, (const bf16*)h, Lp, H, w, bias, target, mask, B,
-                     n_keep_ws, gscale, losses, loss_slot, pred_out, (bf16*)dh, dw, db, do_bwd);
+  const dim3 mgrid((B * Lp + 3) / 4 < 512 ? (B * Lp + 3) / 4 : 512);
+  if (x_is_f32)
+    hipLaunchKernelGGL(mpm_head_kernel<float>, mgrid, dim3(256), 0, stream, (const float*)h, Lp, H, w, bias, target, mask, B, n_keep_ws, gscale, losses,
+                       loss_slot, pred_out, (bf16*)dh, dw, db, do_bwd);
+  else
+    hipLaunchKernelGGL(mpm_head_kernel<bf16>, mgrid, dim3(256), 0, stream, (const bf16*)h, Lp, H, w, bias, target, mask, B, n_keep_ws, gscale, losses,
+                       loss_slot, pred_out, (bf16*)dh, dw, db, do_bwd);
   SPMM_LAUNCH_CHECK("spmm_mpm_head");
   return SPMM_OK;
 }

@@ -120,6 +120,53 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
+// fp32 residual stream (EngineOptions.resid_fp32): the residual arrives in fp32 and the normalised row leaves twice -- bf16 for the
+// GEMMs that read it as an MFMA operand, fp32 for the next residual addition and the loss heads.  One wave per row, any H <= 1024.
+__device__ __forceinline__ void store_row_f32(float* __restrict__ p, int H, int lane, const RowVec& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) { f32x4 t = {r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]}; *(f32x4*)(p + c) = t; }
+  }
+}
+__global__ __launch_bounds__(256) void ln_fwd_r32_kernel(const bf16* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16* __restrict__ y, float* __restrict__ y32, bf16* __restrict__ zout,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o, long rows, int H, float eps,
+                                                         uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  RowVec z, r, o;
+  load_row_bf16(x + row * H, H, lane, z);
+  if (thresh16) {
+    const uint32_t rowkey = drop_rowkey(seed_mix(seed_ptr, salt), (uint64_t)row);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        bool k[4];
+        drop_keep4(rowkey, c, thresh16, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z.v[i][j] = k[j] ? z.v[i][j] * dscale : 0.f;
+      }
+    }
+  }
+  if (res) {
+    load_row_f32(res + row * H, H, lane, r);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z.v[i][j] += r.v[i][j];
+  }
+  float mean, rstd;
+  ln_apply(z, H, lane, gamma, beta, eps, mean, rstd, o);
+  store_row_bf16(y + row * H, H, lane, o);
+  if (y32) store_row_f32(y32 + row * H, H, lane, o);
+  if (zout) store_row_bf16(zout + row * H, H, lane, z);
+  if (mean_o && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
 // The same for H == 256 * NC (768, 1024, ...): a row is owned by HALF a wave (32 lanes x NC chunks of 16 bytes), so a wave
 // normalises two rows at once, every access is a full 16-byte lane access and there are no column guards.
 template <int NC>
@@ -673,6 +720,18 @@ extern "C" int spmm_ln_fwd(const void* x, const void* res, const float* gamma, c
                        (bf16*)y, (bf16*)zout, mean, rstd, rows, H, eps, th, ds, seed_ptr, salt);
 #undef LN_FWD16
   SPMM_LAUNCH_CHECK("spmm_ln_fwd");
+  return SPMM_OK;
+}
+
+extern "C" int spmm_ln_fwd_r32(const void* x, const float* res32, const float* gamma, const float* beta, void* y, float* y32, void* zout,
+                               float* mean, float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr,
+                               uint64_t salt, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_fwd_r32: rows=%ld H=%d (need H%%4==0, H<=1024)", rows, H);
+  SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_fwd_r32: dropout needs a device seed");
+  SPMM_CHECK_SHAPE((mean == nullptr) == (rstd == nullptr), "spmm_ln_fwd_r32: mean and rstd come together");
+  hipLaunchKernelGGL(ln_fwd_r32_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, res32, gamma, beta, (bf16*)y, y32,
+                     (bf16*)zout, mean, rstd, rows, H, eps, (uint32_t)(dropout_p * 65536.f + 0.5f), 1.f / (1.f - dropout_p), seed_ptr, salt);
+  SPMM_LAUNCH_CHECK("spmm_ln_fwd_r32");
   return SPMM_OK;
 }
 

@@ -129,6 +129,7 @@ class Engine:
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
         self.tape = None
+        self.last32 = None
         E, Q = cfg.embed_dim, cfg.queue_size
         self._bank = None          # queue GEMM shadows, sized on first use (depend on the local batch)
 
@@ -232,8 +233,19 @@ class Engine:
         return ops.attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, Lq=Lq, Lkv=Lkv, **kw)
 
     # ---------------------------------------------------------------------------------------- attention block
-    def _attn_block_fwd(self, pfx, c, X, groups, save, cross):
-        """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source."""
+    def _ln_res(self, x, X, X32, gamma, beta, y, **kw):
+        """y = LN(dropout(x) + residual): the residual is X (bf16) or, with the fp32 residual stream (EngineOptions.resid_fp32), X32;
+        returns the fp32 twin of y in that mode (None otherwise)."""
+        if X32 is None:
+            ops.ln_fwd(x, X, gamma, beta, y, **kw)
+            return None
+        y32 = self._new(*y.shape, dtype=torch.float32)
+        ops.ln_fwd_r32(x, X32, gamma, beta, y, y32=y32, **kw)
+        return y32
+
+    def _attn_block_fwd(self, pfx, c, X, groups, save, cross, X32=None):
+        """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source.
+        -> (y, tape entry, fp32 twin of y or None)."""
         P, H, nH, M = self.P, c.hidden_size, c.num_attention_heads, X.shape[0]
         pa, ph = self._p_attn(c), self._p_hidden(c)
         sv = {"X": X, "lse": [], "salt_a": [], "cross": cross}
@@ -260,7 +272,7 @@ class Engine:
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
             shared = {}                                          # K/V of a shared source: projected once per layer
-            fused = self.opt.fused_xattn and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
+            fused = self.opt.fused_xattn and X32 is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
             if fused:
                 # ONE launch per group for core + output projection + dropout + residual + LayerNorm (csrc/xattn.hip); the salts are
                 # drawn in the composite's order (every group's attention salt, then the hidden one): both forms draw the same masks
@@ -302,17 +314,17 @@ class Engine:
                 sv["salt_a"].append(salt)
             if fused:
                 sv.update(ctx=ctx, z=z, mean=mean, rstd=rstd, salt_h=salt_h)
-                return y, (sv if save else None)
+                return y, (sv if save else None), None
         x = self._new(M, H)
         ops.gemm_nt(ctx, P.wb(pfx + ".output.dense.weight"), x, bias=P.w(pfx + ".output.dense.bias"))
         y = self._new(M, H)
         mean = self._new(M, dtype=torch.float32) if save else None
         rstd = self._new(M, dtype=torch.float32) if save else None
         salt = self._next_salt()
-        ops.ln_fwd(x, X, P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y, zout=x if save else None,
-                   mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt)
+        y32 = self._ln_res(x, X, X32, P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y, zout=x if save else None,
+                           mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt)
         sv.update(ctx=ctx, z=x, mean=mean, rstd=rstd, salt_h=salt)
-        return y, (sv if save else None)
+        return y, (sv if save else None), y32
 
     def _attn_block_bwd(self, pfx, c, sv, dY, groups, dkv_acc):
         """-> dX (bf16).  Parameter gradients accumulate into the flat grad arena; cross-attention key/value source
@@ -378,13 +390,13 @@ class Engine:
         return dX
 
     # ------------------------------------------------------------------------------------------------- layers
-    def _layer_fwd(self, lp, c, has_cross, X, groups, save):
-        """BertLayer.forward xbert.py:469-534."""
+    def _layer_fwd(self, lp, c, has_cross, X, groups, save, X32=None):
+        """BertLayer.forward xbert.py:469-534.  -> (y, tape entry, fp32 twin of y or None)."""
         P, H, I, M = self.P, c.hidden_size, c.intermediate_size, X.shape[0]
-        a, sv1 = self._attn_block_fwd(lp + "attention", c, X, groups, save, cross=False)
+        a, sv1, a32 = self._attn_block_fwd(lp + "attention", c, X, groups, save, cross=False, X32=X32)
         sv2 = None
         if has_cross:
-            a, sv2 = self._attn_block_fwd(lp + "crossattention", c, a, groups, save, cross=True)
+            a, sv2, a32 = self._attn_block_fwd(lp + "crossattention", c, a, groups, save, cross=True, X32=a32)
         h = self._new(M, I)
         # backward needs only gelu'(pre-activation): the forward epilogue stores it (it shares the exponential with the erf) and the
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
@@ -408,10 +420,10 @@ class Engine:
         mean = self._new(M, dtype=torch.float32) if save else None
         rstd = self._new(M, dtype=torch.float32) if save else None
         salt = self._next_salt()
-        ops.ln_fwd(x, a, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
-                   mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
+        y32 = self._ln_res(x, a, a32, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
+                           mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
         sv = dict(att=sv1, cross=sv2, a=a, h=h, dact=dact, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
-        return y, sv
+        return y, sv, y32
 
     def _layer_bwd(self, lp, c, sv, dY, groups, dkv_acc):
         P, H, I, M = self.P, c.hidden_size, c.intermediate_size, dY.shape[0]
@@ -432,11 +444,14 @@ class Engine:
             da = self._attn_block_bwd(lp + "crossattention", c, sv["cross"], da, groups, dkv_acc)
         return self._attn_block_bwd(lp + "attention", c, sv["att"], da, groups, None)
 
-    def stack_fwd(self, pfx, c, layers, has_cross, X, groups, save):
+    def stack_fwd(self, pfx, c, layers, has_cross, X, groups, save, X32=None):
+        """-> (y, tape).  With X32 (the fp32 twin of X: EngineOptions.resid_fp32) the residual stream runs in fp32 and the fp32 twin of
+        y is left in `self.last32`."""
         tape = []
         for i in layers:
-            X, sv = self._layer_fwd(f"{pfx}encoder.layer.{i}.", c, has_cross and i >= c.fusion_layer, X, groups, save)
+            X, sv, X32 = self._layer_fwd(f"{pfx}encoder.layer.{i}.", c, has_cross and i >= c.fusion_layer, X, groups, save, X32=X32)
             tape.append(sv)
+        self.last32 = X32
         return X, tape
 
     def stack_bwd(self, pfx, c, layers, tape, dY, groups, dkv_acc=None):
@@ -552,16 +567,21 @@ class Engine:
         return (dz.float() * (cdf + x * pdf)).to(BF)
 
     # ---------------------------------------------------------------------------------------------- features
-    def _feat_fwd(self, proj, X, L, B, save, cls_rows=None):
+    def _feat_fwd(self, proj, X, L, B, save, cls_rows=None, X32=None):
         """normalize(proj(X[:, 0, :])) SPMM_models.py:92,95,101,105 -> (feat f32 [B,E], tape).  cls_rows (int64 [B]): rows of
-        the first token of every sequence when X is packed."""
+        the first token of every sequence when X is packed.  X32 (fp32 residual stream): the projection reads the fp32 rows with
+        fp32 weights (spmm_rows_linear) instead of the bf16 MFMA GEMM."""
         P, E, H = self.P, self.cfg.embed_dim, self.cfg.text.hidden_size
         if cls_rows is not None:
             cls = X.index_select(0, cls_rows)
         else:
             cls = X.view(-1, L * H)[:B, :H]                 # strided CLS rows, row stride L*H
         raw = self._new(B, E, dtype=torch.float32)
-        ops.gemm_nt(cls, P.wb(proj + ".weight"), raw, bias=P.w(proj + ".bias"), epi=ops.EPI_F32)
+        if X32 is not None:
+            cls32 = X32.index_select(0, cls_rows) if cls_rows is not None else X32.view(-1, L * H)[:B, :H]
+            ops.rows_linear(cls32, P.w(proj + ".weight"), P.w(proj + ".bias"), raw)
+        else:
+            ops.gemm_nt(cls, P.wb(proj + ".weight"), raw, bias=P.w(proj + ".bias"), epi=ops.EPI_F32)
         feat = self._new(B, E, dtype=torch.float32)
         nrm = self._new(B, dtype=torch.float32)
         return raw, feat, nrm, cls

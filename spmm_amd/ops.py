@@ -172,6 +172,16 @@ def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12
     return y
 
 
+def ln_fwd_r32(x, res32, gamma, beta, y, *, y32=None, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0):
+    """ln_fwd with the residual read in fp32 and the normalised row written as bf16 (y) and fp32 (y32)."""
+    rows, H = x.shape
+    assert res32 is None or res32.dtype == torch.float32
+    assert y32 is None or y32.dtype == torch.float32
+    _call("spmm_ln_fwd_r32", _p(x), _p(res32), _p(gamma), _p(beta), _p(y), _p(y32), _p(zout), _p(mean), _p(rstd), rows, H, float(eps),
+          float(dropout_p), _p(seed), salt, _st())
+    return y
+
+
 def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbeta=None, dropout_p=0.0, seed=None, salt=0,
            drop_on_dy=False, dxsum=None):
     rows, H = dy.shape
@@ -262,14 +272,15 @@ def lm_loss(logits, logits_m, ids, *, nseq, L, V, alpha, ws, losses, slot, dlogi
 def itm_head(xa, stride_a, xb, stride_b, H, W, bias, *, n, B, losses, slot, logits=None, dxa=None, dxb=None, dW=None,
              db=None, gscale=None):
     do_bwd = dxa is not None
+    assert xa.dtype == xb.dtype and xa.dtype in (BF16, torch.float32)
     _call("spmm_itm_head", _p(xa), stride_a, _p(xb), stride_b, H, _p(W), _p(bias), n, B, _p(gscale), _p(losses), slot,
-               _p(logits), _p(dxa), _p(dxb), _p(dW), _p(db), int(do_bwd), _st())
+               _p(logits), _p(dxa), _p(dxb), _p(dW), _p(db), int(do_bwd), int(xa.dtype == torch.float32), _st())
 
 
 def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None, dh=None, dw=None, db=None, gscale=None):
     do_bwd = dh is not None
     _call("spmm_mpm_head", _p(h), Lp, H, _p(w), _p(bias), _p(target), _p(mask), B, _p(ws), _p(gscale), _p(losses), slot,
-               _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), _st())
+               _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), int(h.dtype == torch.float32), _st())
 
 
 def quant_rows_fp8(x, q=None, scale=None):

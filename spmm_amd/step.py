@@ -80,19 +80,27 @@ class PretrainStep(Engine):
             self.nan_flag.bitwise_or_(self.hint_bad)
         M = pk["M"] if pk else B * Lt
         ids2 = torch.cat([ids32, ids32])
+        # fp32 residual stream (EngineOptions.resid_fp32): every hidden state travels as a bf16 tensor (GEMM operand) and
+        # its fp32 twin (residual additions, loss-head inputs); `f32(t)` starts a twin, the *_32 names below mirror every regrouping
+        r32 = self.opt.resid_fp32 and aux is None
+        f32 = (lambda t: t.float()) if r32 else (lambda t: None)
         side = self._fork()
         with self._on(side):
             x2, esv2 = self.embed_text("text_encoder.bert.", ct, ids2, 2 * B, Lt, save)
+            x2_32 = f32(x2)
             # P2 (and P4, P6, P8) feed only position 0 of their outputs to a loss (:95, :105, :201), and a padding token is
             # never attended as a key, so its rows influence nothing: those passes run on the packed valid rows.  The
             # student's LM pass (P10) keeps every row -- its loss counts the padding targets (:233).
             if pk:
                 x2 = torch.cat([x2[:B * Lt].index_select(0, pk["rows"]), x2[B * Lt:]])
+                if r32:
+                    x2_32 = torch.cat([x2_32[:B * Lt].index_select(0, pk["rows"]), x2_32[B * Lt:]])
                 g2 = [Group(0, B, Lt, None, B, q_row0=pk["row0"], q_len=pk["len"], nrows=M), Group(M, B, Lt, mask32, 0)]
             else:
                 g2 = [Group(0, 2 * B, Lt, torch.cat([mask32, mask32]), B)]
-            y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save)
+            y2, tape2 = self.stack_fwd("text_encoder.bert.", ct, range(0, f), True, x2, g2, save, X32=x2_32)
             text_embeds, hidden10 = y2[:M], y2[M:]
+            text_embeds_32, hidden10_32 = (self.last32[:M], self.last32[M:]) if r32 else (None, None)
         side_m = self._fork(1)
         ema_done = None
         with self._on(side_m):
@@ -105,24 +113,30 @@ class PretrainStep(Engine):
                 ema_done.record(side_m)
             # momentum text branch (:104-105, :215-222), no tape
             x4, _ = self.embed_text("text_encoder_m.bert.", ct, ids2, 2 * B, Lt, False)
+            x4_32 = f32(x4)
             if pk:
                 # The teacher's LM logits are read only where the label is a real token (:236-237), and a causal position
                 # sees nothing to its right: P9 (unlike P10) is packed too.
                 x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:].index_select(0, pk["rows"])])
+                if r32:
+                    x4_32 = torch.cat([x4_32[:B * Lt].index_select(0, pk["rows"]), x4_32[B * Lt:].index_select(0, pk["rows"])])
                 g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
             else:
                 g4 = g2
-            y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False)
+            y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False, X32=x4_32)
             text_embeds_m, hidden9 = y4[:M], y4[M:]
+            text_embeds_m_32, hidden9_32 = (self.last32[:M], self.last32[M:]) if r32 else (None, None)
         x1, esv1 = self.embed_pv("property_encoder.", cp, prop, mpm_mask, 2 * B, B, save)
         g1 = [Group(0, 2 * B, Lp, None, B)]
-        y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save)
+        y1, tape1 = self.stack_fwd("property_encoder.", cp, range(cp.num_hidden_layers), False, x1, g1, save, X32=f32(x1))
         prop_embeds, prop_embeds_causal = y1[:B * Lp], y1[B * Lp:]
+        prop_embeds_32, prop_embeds_causal_32 = (self.last32[:B * Lp], self.last32[B * Lp:]) if r32 else (None, None)
         if ema_done is not None:
             torch.cuda.current_stream().wait_event(ema_done)
         x3, _ = self.embed_pv("property_encoder_m.", cp, prop, mpm_mask, B, B, False)
         prop_embeds_m, _ = self.stack_fwd("property_encoder_m.", cp, range(cp.num_hidden_layers), False, x3,
-                                          [Group(0, B, Lp, None, B)], False)
+                                          [Group(0, B, Lp, None, B)], False, X32=f32(x3))
+        prop_embeds_m_32 = self.last32 if r32 else None
         self._join(side)
         self._join(side_m)
         if pk:
@@ -133,7 +147,7 @@ class PretrainStep(Engine):
         # the side stream underneath the features / ITA / S6 work below.
         side5 = self._fork()
         with self._on(side5):
-            y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False)
+            y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False, X32=hidden9_32)
             logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
             if pk:                                               # the loss kernel indexes [B, Lt, V]
                 logits_m = torch.zeros(B * Lt, logits_m.shape[1], dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
@@ -143,11 +157,13 @@ class PretrainStep(Engine):
         J, Jp = bank["J"], bank["Jp"]
         A3 = self._new(4 * B, 3 * E)
         feats = {}
+        twins = {"property_proj": prop_embeds_32, "text_proj": text_embeds_32, "property_proj_m": prop_embeds_m_32, "text_proj_m": text_embeds_m_32}
         for k, (proj, X, L, w3, qT) in enumerate((("property_proj", prop_embeds, Lp, None, None),
                                                   ("text_proj", text_embeds, Lt, None, None),
                                                   ("property_proj_m", prop_embeds_m, Lp, *bank["prop"]),
                                                   ("text_proj_m", text_embeds_m, Lt, *bank["text"]))):
-            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save, cls_rows=pk["row0_64"] if (pk and proj.startswith("text_proj")) else None)
+            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save, cls_rows=pk["row0_64"] if (pk and proj.startswith("text_proj")) else None,
+                                                 X32=twins[proj])
             ops.l2norm_fwd(raw, feat, nrm, a3=A3[k * B:(k + 1) * B], w3=None if w3 is None else w3[:B], yT=qT)
             feats[proj] = (feat, nrm, cls)
         S_text = self._new(4 * B, J, dtype=torch.float32)     # rows: i2t | t2t | i2t_m | t2t_m
@@ -180,6 +196,9 @@ class PretrainStep(Engine):
         ar = torch.arange(B, dtype=torch.int64, device=self.dev)
         mask_neg = mask32.index_select(0, neg[B:])
         qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
+        if r32:
+            pe32 = prop_embeds_32.view(B, Lp * H)
+            qpv_32 = torch.cat([pe32, pe32.index_select(0, neg[:B]), pe32, prop_embeds_causal_32.view(B, Lp * H)]).view(4 * B * Lp, H)
         src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp)
         if pk:
             src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"])
@@ -192,6 +211,9 @@ class PretrainStep(Engine):
             Mn = B * Lt
             te_neg = torch.cat([text_embeds, self._zeros(1, H)]).index_select(0, neg_rows)
             qtext = torch.cat([text_embeds, text_embeds, te_neg, hidden10])
+            if r32:
+                te_neg_32 = torch.cat([text_embeds_32, self._zeros(1, H, dtype=torch.float32)]).index_select(0, neg_rows)
+                qtext_32 = torch.cat([text_embeds_32, text_embeds_32, te_neg_32, hidden10_32])
             gt = [Group(r0, 2 * B, Lt, None, 2 * B, q_row0=torch.cat([pk["row0"], pk["row0"] + M]), q_len=torch.cat([pk["len"], pk["len"]]),
                         nrows=2 * M).attend(src_pv, torch.cat([ar, neg[:B]])),
                   Group(r0 + 2 * M, 2 * B, Lt, torch.cat([mask_neg, mask32]), B).attend(src_pv, torch.cat([ar, ar]))]
@@ -202,6 +224,9 @@ class PretrainStep(Engine):
             te = text_embeds.view(B, Lt * H)
             te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
             qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
+            if r32:
+                te32 = text_embeds_32.view(B, Lt * H)
+                qtext_32 = torch.cat([te32, te32, te32.index_select(0, neg[B:]), hidden10_32.view(B, Lt * H)]).view(4 * B * Lt, H)
             kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
             gt = [Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B).attend(src_pv, torch.cat([ar, neg[:B], ar, ar]))]
             neg_rows, cls_text, Mn = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt, B * Lt
@@ -209,13 +234,15 @@ class PretrainStep(Engine):
         g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv_mask=kvmask_qpv).attend(src_text, torch.cat([ar, ar, neg[B:], ar]))] + gt
         src_text.finalize()
         src_pv.finalize()
-        y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save)
+        y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save, X32=torch.cat([qpv_32, qtext_32]) if r32 else None)
         ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
+        # the loss heads read the fp32 twins in that mode (forward and backward: the tape keeps what the forward read)
+        ypv_h, ytext_h = (self.last32[:4 * B * Lp], self.last32[4 * B * Lp:]) if r32 else (ypv, ytext)
 
         # ---- ITM head (:199-206) on the position-0 rows of the first 3B sequences of both halves
         vl_logits = self._new(3 * B, 2, dtype=torch.float32) if aux is not None else None
-        itm_text = ytext.index_select(0, cls_text)
-        ops.itm_head(ypv, Lp * H, itm_text, H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
+        itm_text = ytext_h.index_select(0, cls_text)
+        ops.itm_head(ypv_h, Lp * H, itm_text, H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
                      slot=LOSS_ITM, logits=vl_logits)
 
         # ---- queue (:208, :272-286)
@@ -244,10 +271,16 @@ class PretrainStep(Engine):
         ops.gemm_nt(hp12, P.wb("property_mtr_head.0.weight"), mt, bias=P.w("property_mtr_head.0.bias"), epi=ops.EPI_GELU, C2=mpre)
         mln = self._new(B * Lp, H)
         mmean, mrstd = self._new(B * Lp, dtype=torch.float32), self._new(B * Lp, dtype=torch.float32)
-        ops.ln_fwd(mt, None, P.w("property_mtr_head.2.weight"), P.w("property_mtr_head.2.bias"), mln, zout=mt, mean=mmean, rstd=mrstd,
-                   eps=ct.layer_norm_eps)
+        if r32:
+            mln_h = self._new(B * Lp, H, dtype=torch.float32)
+            ops.ln_fwd_r32(mt, None, P.w("property_mtr_head.2.weight"), P.w("property_mtr_head.2.bias"), mln, y32=mln_h, zout=mt, mean=mmean,
+                           rstd=mrstd, eps=ct.layer_norm_eps)
+        else:
+            mln_h = mln
+            ops.ln_fwd(mt, None, P.w("property_mtr_head.2.weight"), P.w("property_mtr_head.2.bias"), mln, zout=mt, mean=mmean, rstd=mrstd,
+                       eps=ct.layer_norm_eps)
         pred = self._new(B, cfg.n_props, dtype=torch.float32) if aux is not None else None
-        ops.mpm_head(mln, Lp, H, P.w("property_mtr_head.3.weight"), P.w("property_mtr_head.3.bias"), prop, mpm_mask, B=B,
+        ops.mpm_head(mln_h, Lp, H, P.w("property_mtr_head.3.weight"), P.w("property_mtr_head.3.bias"), prop, mpm_mask, B=B,
                      ws=self.icount[1:2], losses=self.losses, slot=LOSS_MPM, pred=pred)
 
         if aux is not None:
@@ -260,8 +293,8 @@ class PretrainStep(Engine):
         if save:
             self.tape = dict(B=B, Lt=Lt, pk=pk, M=M, Mn=Mn, src_text=src_text, src_pv=src_pv, neg_rows=neg_rows, cls_text=cls_text, itm_text=itm_text,
                              prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
-                             esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv,
-                             ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln,
+                             esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv_h,
+                             ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln_h,
                              mmean=mmean, mrstd=mrstd)
         return self.losses[:4]
 
