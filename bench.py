@@ -376,6 +376,7 @@ def main():
             return w
 
         gemm_bytes = [0.0]
+        shape_log = []
 
         def gemm_flops(A, W, C, **k):
             M, N, K = A.shape[0], W.shape[0], (k.get("K") or A.shape[1])
@@ -385,6 +386,7 @@ def main():
                 if k.get(name) is not None:
                     b += M * N * k[name].element_size()
             gemm_bytes[0] += b
+            shape_log.append((M, N, K, int(k.get("epi", 0)), C.dtype == torch.float32))
             return 2.0 * M * N * K
 
         model.engine.multi_stream = False     # per-launch events need one stream; concurrency would also smear the durations
@@ -461,6 +463,15 @@ def main():
                 "avg_launch_us_raw": round(raw_ms * 1e3 / n_launch, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                 "measured": f"HIP events around every launch, {nsteps} instrumented single-stream steps after the timed region; each interval "
                             "minus the calibrated event-pair overhead (2 I1 - I2 around one / two minimal kernels), which the rocprofv3 kernel trace does not contain"}
+        # per-shape table of the same launches (where the family's time goes inside the step): M bucketed to 1 k rows
+        by_shape = {}
+        for (a, b, _), (M_, N_, K_, epi_, f32_) in zip(ev["gemm"], shape_log):
+            key = (round(M_ / 1024) * 1024 if M_ >= 2048 else M_, N_, K_, epi_, f32_)
+            t_, f_, n_ = by_shape.get(key, (0.0, 0.0, 0))
+            by_shape[key] = (t_ + a.elapsed_time(b) - ev_overhead_ms, f_ + 2.0 * M_ * N_ * K_, n_ + 1)
+        roof["shapes"] = [{"M~": k[0], "N": k[1], "K": k[2], "epi": k[3], "f32_out": k[4], "launches_per_step": v[2] // nsteps,
+                           "ms_per_step": round(v[0] / nsteps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else None}
+                          for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:16]]
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_nt_gemm.json")

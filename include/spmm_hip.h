@@ -76,6 +76,12 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
 int spmm_gemm_tn_splits(int M, int N, int K, int kernel);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
                  long ldc, float* workspace, int kernel, spmm_stream_t stream);
+/* All the weight-gradient problems of a layer (up to 8) in ONE launch + one slab reduction: C_i[N_i,K_i] += alpha * A_i[M_i,N_i]^T B_i[M_i,K_i].
+ * Arrays of n entries; a problem is eligible when spmm_gemm_tn_group_ok says so; workspace: spmm_gemm_tn_group_workspace(...) floats. */
+int spmm_gemm_tn_group_ok(int M, int N, int K);
+long spmm_gemm_tn_group_workspace(int n, const int* M, const int* N, const int* K);
+int spmm_gemm_tn_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, const int* M, const int* N,
+                       const int* K, float* const* C, const long* ldc, float alpha, float* workspace, spmm_stream_t stream);
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.

@@ -125,7 +125,7 @@ class Engine:
         # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
         self.multi_stream = self.opt.multi_stream
         self.wgrad_async = self.opt.wgrad_stream and self.multi_stream
-        self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
+        self._wg_stream, self._wg_pending, self._wg_keep, self._wg_group = None, False, [], []
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
         self.tape = None
@@ -136,6 +136,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ helpers
     def _fork(self, which: int = 0):
         """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
+        self._wgrad_flush()                              # (collected weight gradients belong to the stream they were recorded on)
         if not self.multi_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
         side = streams.get(self.dev, f"side{which}")        # process-wide: every model of a process shares the same streams
@@ -146,6 +147,8 @@ class Engine:
 
     def _join(self, side):
         if side is not None:
+            with torch.cuda.stream(side):
+                self._wgrad_flush()
             ev = torch.cuda.Event()
             ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
@@ -180,10 +183,21 @@ class Engine:
         tails of small-M GEMMs).  All weight gradients share ONE such stream (accumulations into the same tensor stay ordered);
         `wgrad_join()` makes the current stream wait for it (before a layer's gradient exchange, before the optimiser)."""
         ws = None if inline else self._wgrad_side()
+        C = gW.view(dY.shape[1], X.shape[1])
+        # grouped mode (EngineOptions.grouped_wgrad): the matrix product waits for the layer's other weight gradients and leaves with
+        # them in ONE launch (_wgrad_flush, at the end of the layer); the bias column sums go out at once as before
+        group = self.opt.grouped_wgrad and not inline and ops.gemm_tn_group_ok(dY.shape[0], dY.shape[1], X.shape[1])
+        if group:
+            if any(c.data_ptr() == C.data_ptr() for _, _, c in self._wg_group) or len(self._wg_group) == 8:
+                self._wgrad_flush()                      # (two problems of one launch must not accumulate into the same tensor)
+            self._wg_group.append((dY, X, C))
         if ws is None:
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
+            if not group:
+                ops.gemm_tn(dY, X, C)
+            return
+        if group and gb is None:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -191,10 +205,29 @@ class Engine:
         with torch.cuda.stream(ws):
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            ops.gemm_tn(dY, X, gW.view(dY.shape[1], X.shape[1]))
+            if not group:
+                ops.gemm_tn(dY, X, C)
         # The operands must outlive the side stream's use of them.  They are simply kept referenced until the next join
         # (`record_stream` on ~100 tensors per step makes the caching allocator poll events on every allocation).
         self._wg_keep.append((dY, X))
+        self._wg_pending = True
+
+    def _wgrad_flush(self):
+        """Launch the weight-gradient products collected since the last flush as one grouped launch (on the weight-gradient stream
+        when there is one, behind an event on the current stream)."""
+        probs, self._wg_group = self._wg_group, []
+        if not probs:
+            return
+        ws = self._wgrad_side()
+        run = (lambda: ops.gemm_tn_group(probs)) if len(probs) > 1 else (lambda: ops.gemm_tn(*probs[0]))
+        if ws is None:
+            return run()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            run()
+        self._wg_keep.append(probs)
         self._wg_pending = True
 
     def _wgrad_side(self):
@@ -205,6 +238,7 @@ class Engine:
 
     def wgrad_join(self, release: bool = False):
         """The current stream waits for every weight-gradient launch issued so far."""
+        self._wgrad_flush()
         if self._wg_stream is not None and self._wg_pending:
             ev = torch.cuda.Event()
             ev.record(self._wg_stream)
@@ -457,6 +491,7 @@ class Engine:
     def stack_bwd(self, pfx, c, layers, tape, dY, groups, dkv_acc=None):
         for i, sv in zip(reversed(list(layers)), reversed(tape)):
             dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
+            self._wgrad_flush()                          # (grouped mode: this layer's weight gradients, one launch)
             if self.layer_done_cb is not None:           # this layer's gradients are final: data-parallel reduce may start
                 self._layer_done(f"{pfx}encoder.layer.{i}.")
         return dY
