@@ -474,12 +474,13 @@ def main():
                           for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:16]]
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_nt_gemm.json")
-        if os.path.exists(pmc_path):
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        pmc_path = next((os.path.join(pdir, f) for f in ("r03_pmc_nt_gemm.json", "r02_pmc_nt_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
+        if pmc_path:
             pmc = json.load(open(pmc_path))
             if pmc["workload"] == {"batch": B, "seq_len": Lt, "layers": nt, "queue": args.queue}:
                 roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
-                roof["traffic_note"] = ("bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r02_pmc_nt_gemm.json "
+                roof["traffic_note"] = (f"bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{os.path.basename(pmc_path)} "
                                         "(L2<->fabric requests, Infinity-Cache hits included)")
 
     flops = step_flops(B, Lt, n_text=nt, fusion=f, n_pv=npv, Q=args.queue)
