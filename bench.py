@@ -435,6 +435,15 @@ def main():
         for i in range(nsteps):
             one_step(i)
         torch.cuda.synchronize()
+        # ... and the same block as ONE launch per query group (csrc/xattn.hip, EngineOptions.fused_xattn): timed beside the composite
+        # whichever of the two the step uses by default
+        n_comp = len(ev["xattn"])
+        eng.opt = opts.replace(fused_xattn=not opts.fused_xattn)
+        for i in range(nsteps):
+            one_step(i)
+        torch.cuda.synchronize()
+        eng.opt = opts
+        ev_other, ev["xattn"] = ev["xattn"][n_comp:], ev["xattn"][:n_comp]
         eng._attn_block_fwd = orig_blk
         model.engine.multi_stream = opts.multi_stream
         model.engine.wgrad_async = opts.multi_stream and opts.wgrad_stream
@@ -447,6 +456,11 @@ def main():
                  "executed_tflops": round(x_exe / (x_ms * 1e-3) / 1e12, 1),
                  "executed_frac_of_bf16_peak": round(x_exe / (x_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                  "calls_per_step": len(ev["xattn"]) // nsteps, "ms_per_step": round(x_ms / nsteps, 3),
+                 "form": "fused row-panel kernel (csrc/xattn.hip) + Q and K/V projection GEMMs" if opts.fused_xattn else
+                         "composite: Q GEMM + K/V GEMM + attn_fwd per group + output GEMM + ln_fwd",
+                 "other_form_ms_per_step": round(sum(a.elapsed_time(b) for a, b, _ in ev_other) / nsteps, 3),
+                 "other_form_executed_frac_of_bf16_peak": round(sum(fl[1] for _, _, fl in ev_other) / (sum(a.elapsed_time(b) for a, b, _ in ev_other) * 1e-3)
+                                                                / 1e12 / PEAK_BF16_TFLOPS, 4),
                  "note": "algorithmic = the reference's work, nseq*(4H^2 Lq + 4H^2 Lkv + 4 Lq Lkv H) per query sequence; executed = what runs here "
                          "(K/V projected once per unique key/value source, packed rows); padded-tile waste excluded from both"}
         raw_ms = sum(a.elapsed_time(b) for a, b, _ in ev["gemm"])
