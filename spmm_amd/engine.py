@@ -434,7 +434,8 @@ class Engine:
         h = self._new(M, I)
         # backward needs only gelu'(pre-activation): the forward epilogue stores it (it shares the exponential with the erf) and the
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
-        dact = self._new(M, I) if save else None
+        u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN
+        dact = (self._new(M, I, dtype=torch.uint8) if u8 else self._new(M, I)) if save else None
         x = self._new(M, H)
         if self.fp8 and H % 256 == 0 and I % 256 == 0:
             # fp8 tier (BASELINE configs[4]): both FFN GEMMs of the forward read E4M3 operands with per-row scales (activations
@@ -448,7 +449,7 @@ class Engine:
             ops.gemm_nt_f8(h8, sh, w8, sw, x, bias=P.w(lp + "output.dense.bias"))
         else:
             ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"),
-                        epi=ops.EPI_GELU_DERIV if save else ops.EPI_GELU, C2=dact)
+                        epi=(ops.EPI_GELU_DERIV8 if u8 else ops.EPI_GELU_DERIV) if save else ops.EPI_GELU, C2=dact)
             ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x, bias=P.w(lp + "output.dense.bias"))
         y = self._new(M, H)
         mean = self._new(M, dtype=torch.float32) if save else None
@@ -469,8 +470,8 @@ class Engine:
                    seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"))
         self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
-        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre, epi=ops.EPI_MUL, G=sv["dact"],
-                    colsum=P.g(lp + "intermediate.dense.bias"))
+        ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre,
+                    epi=ops.EPI_MUL8 if sv["dact"].dtype == torch.uint8 else ops.EPI_MUL, G=sv["dact"], colsum=P.g(lp + "intermediate.dense.bias"))
         self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"))
         da = self._new(M, H)
         ops.gemm_nt(dpre, self._wT(lp + "intermediate.dense", P.w(lp + "intermediate.dense.weight")), da, R=dz)
