@@ -21,8 +21,9 @@ import time
 if os.environ.get("SPMM_DIST_BACKEND") != "gloo":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # Watchdog: a run still going after this many seconds dumps every thread's Python stack and EXITS NON-ZERO (never a re-exec, never a
-# silent hang of the driver's scaling run).  Default for N>1: 300 s -- 60 default steps take ~4 s, the rest is start-up.
-_wd = os.environ.get("SPMM_BENCH_WATCHDOG") or ("300" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
+# silent hang of the driver's scaling run).  Default for N>1: 600 s -- 60 default steps take ~4 s, the rest is start-up (the first
+# `import torch` of eight processes on a fresh box alone can take two minutes).
+_wd = os.environ.get("SPMM_BENCH_WATCHDOG") or ("600" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
 if _wd and float(_wd) > 0:
     import faulthandler
     faulthandler.dump_traceback_later(float(_wd), exit=True)
@@ -313,13 +314,26 @@ def main():
             return model.fused_step_graphed(prop, ids, mask, 0.4)
         return model.fused_step(prop, ids, mask, 0.4, grad_sync=sync, n_tokens=ntok)   # the data pipeline knows the token count (host mask sum)
 
-    def check_replicas(after):
+    replica_report = {}
+
+    def check_replicas(after, fatal):
+        """Every rank must hold the same parameters, momentum parameters, queues and pointer (there is no per-step buffer broadcast).
+        Collective on every rank; with fatal=False a divergence is REPORTED in the JSON line instead of ending the scaling run."""
         from spmm_amd.parallel import assert_replicas_identical
+        bad = []
         for t, what in ((model.store.flat, "student parameters"), (model.store.flat_m, "momentum parameters"),
                         (model.store.buffers["prop_queue"], "prop_queue"), (model.store.buffers["text_queue"], "text_queue"),
                         (model.store.buffers["queue_ptr"], "queue_ptr")):
-            assert_replicas_identical(t, what)
-        if rank == 0:
+            try:
+                assert_replicas_identical(t, what)
+            except RuntimeError:
+                if fatal:
+                    raise
+                bad.append(what)
+        flag = torch.tensor([len(bad)], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        replica_report[f"after_{after}_steps"] = "identical" if int(flag) == 0 else f"DIVERGED on some rank (this rank: {bad or 'none'})"
+        if rank == 0 and int(flag) == 0:
             print("replicas identical after", after, "steps; queue_ptr =", int(model.queue_ptr), flush=True)
 
     rccl_ranks = None
@@ -332,7 +346,7 @@ def main():
     for i in range(args.warmup):
         losses = one_step(i)
         if world > 1 and i == 1:         # replicas must agree from the start (no per-step buffer broadcast): checked after 2 steps, untimed
-            check_replicas(2)
+            check_replicas(2, fatal=args.check_replicas)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -516,6 +530,7 @@ def main():
     from spmm_amd import streams
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
+        out["replicas"] = replica_report
     if streams.log():
         out["stream_placement"] = streams.log()
     if rank == 0:
@@ -527,7 +542,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(16, Lt)
         print(json.dumps(out), flush=True)
     if args.check_replicas and world > 1:
-        check_replicas(args.warmup + args.steps)
+        check_replicas(args.warmup + args.steps, fatal=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
