@@ -423,6 +423,9 @@ def _xattn_composite(ops, Q, K, V, Wo, bo, R, gamma, beta, *, nseq, nH, Lq, Lkv,
     (12, 4, 4, 128, 54, True, True),
     (2, 5, 2, 40, 24, False, False),        # H = 128 (the tiny configuration), one head pair, one key tile
     (4, 3, 3, 70, 90, True, True),          # H = 256, three key tiles
+    (12, 1, 1, 1, 1, False, False),         # one query row, one key: every tile is padding but one element
+    (12, 3, 2, 65, 33, True, False),        # a second panel with a single valid row; 33 keys = one full tile + one key
+    (2, 7, 7, 128, 128, False, True),       # full 128 x 128 at H = 128, dropout
 ])
 def test_fused_cross_attention_block(ops, nH, nseq, U, Lq, Lkv, packed, drop):
     """spmm_xattn_fwd (ONE launch: attention core + output projection + dropout + residual + LayerNorm) against (a) the composite
@@ -432,8 +435,8 @@ def test_fused_cross_attention_block(ops, nH, nseq, U, Lq, Lkv, packed, drop):
     g = torch.Generator().manual_seed(nseq * 7 + Lq)
     idx = torch.randint(0, U, (nseq,), generator=g); idx[:U] = torch.arange(U)
     i32 = lambda t: t.to(torch.int32).cuda()
-    qlen = torch.randint(3, Lq + 1, (nseq,), generator=g); qlen[0] = Lq
-    kvlen = torch.randint(2, Lkv + 1, (U,), generator=g); kvlen[0] = Lkv
+    qlen = torch.randint(min(3, Lq), Lq + 1, (nseq,), generator=g); qlen[0] = Lq
+    kvlen = torch.randint(min(2, Lkv), Lkv + 1, (U,), generator=g); kvlen[0] = Lkv
     if packed:
         q_row0 = torch.cumsum(qlen, 0) - qlen
         kv_row0 = torch.cumsum(kvlen, 0) - kvlen
