@@ -55,6 +55,8 @@ struct AttnP {
 // ------------------------------------------------------------------------------------------ forward
 constexpr int FWD_LDS = 2 * TILE + 128 * 4;
 
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +64,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   // workgroups of the PV-query calls were held to 4 per CU by LDS alone)
   char* Ks = smem;
   char* Vs = smem + NT * 32 * ROWB;
-  float* mb = (float*)(smem + 2 * NT * 32 * ROWB);   // mask value per kv (1/0), -1 = padding
+  // (the bias vector sits behind the larger of the K/V tiles and the output transposition space: 4 KiB per wave)
+  const int tile_bytes = 2 * NT * 32 * ROWB > (int)blockDim.x * 64 ? 2 * NT * 32 * ROWB : (int)blockDim.x * 64;
+  float* mb = (float*)(smem + tile_bytes);            // mask value per kv (1/0), -1 = padding
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
@@ -155,17 +159,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     ot[0] = MFMA32(vf1[0], pf1, ot[0]);
     ot[1] = MFMA32(vf1[1], pf1, ot[1]);
   }
-  if (q < Lq) {
-    bf16* Og = p.O + (qrow + q) * p.ldo + h * HD;
+  // The context tile leaves through LDS as whole 128-byte rows (a head's 64 columns of a token), 16 bytes per lane, 8 rows per store
+  // instruction.  Straight from the accumulators a store instruction would write 32 rows x 16 bytes: the store path of a CU sustains
+  // 6-12 B/clk with such pieces against 37-45 with full lines (tools/store_bench.cpp), and the tile's stores were a large share of
+  // this kernel.  K and V are dead once every wave is past its last MFMA: each wave transposes through its own 4 KiB of their space.
+  __syncthreads();
+  {
+    char* T = smem + wave * 4096;
     const float osc = p.drop_thresh16 ? inv * p.drop_scale : inv;      // the dropped probabilities were only zeroed above: 1 / (1 - p) goes here
+    const int row = lane & 31;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int d = dt * 32 + 8 * gq + 4 * g;
-        *(bf16x4*)(Og + d) = to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc,
-                                       ot[dt][gq * 4 + 3] * osc);
-      }
+      for (int gq = 0; gq < 4; ++gq)        // d = dt*32 + 8*gq + 4*g ..+3  ->  16-byte chunk dt*4 + gq of the row, half g; chunk index XOR (row & 7)
+        *(bf16x4*)(T + row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3))) =
+            to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc, ot[dt][gq * 4 + 3] * osc);
+    // (same wave: LDS operations execute in order, no barrier between its writes and its reads)
+    const int r8 = lane >> 3, c = lane & 7;
+    bf16* Og = p.O + (qrow + wave * 32 + r8) * p.ldo + h * HD + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4s v = *(const u32x4s*)(T + (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4));
+      if (wave * 32 + r8 + 8 * i < Lq) *(u32x4s*)(Og + (long)(8 * i) * p.ldo) = v;
+    }
   }
 }
 
@@ -350,14 +366,22 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
           dq[1] = MFMA32(kf1[1], ds1, dq[1]);
         }
       }
-      if (q < Lq) {
-        bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD;
+      {
+        // No LDS is free here (Q and dO are read again in phase B), so the 8-byte pieces are widened in registers instead: lanes l
+        // and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands lane l the other half of the
+        // EVEN chunks and lane l + 32 the other half of the ODD ones: four 16-byte stores per lane instead of eight 8-byte ones.
+        bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD + 8 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq)
-            *(bf16x4*)(dQg + dt * 32 + 8 * gq + 4 * g) =
-                to_bf16x4(dq[dt][gq * 4] * qsc, dq[dt][gq * 4 + 1] * qsc, dq[dt][gq * 4 + 2] * qsc, dq[dt][gq * 4 + 3] * qsc);
+          for (int j = 0; j < 2; ++j) {
+            const int e = (2 * j) * 4, o = (2 * j + 1) * 4;
+            uint32_t e0 = pk2(dq[dt][e] * qsc, dq[dt][e + 1] * qsc), e1 = pk2(dq[dt][e + 2] * qsc, dq[dt][e + 3] * qsc);
+            uint32_t o0 = pk2(dq[dt][o] * qsc, dq[dt][o + 1] * qsc), o1 = pk2(dq[dt][o + 2] * qsc, dq[dt][o + 3] * qsc);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+            if (q < Lq) *(u32x4*)(dQg + dt * 32 + 16 * j) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
       }
     }
   }
@@ -409,17 +433,33 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         dk[0] = MFMA32(qf[0], dsf, dk[0]);
         dk[1] = MFMA32(qf[1], dsf, dk[1]);
       }
-    if (kv < Lkv) {
-      bf16* dKg = p.dK + (dkvrow + kv) * p.lddk + h * HD;
-      bf16* dVg = p.dV + (dkvrow + kv) * p.lddv + h * HD;
+  }
+  // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
+  // once all waves are past their last read, and the kv-wave w transposes through bytes [8192 w, 8192 w + 8192) of region X
+  // (X >= 2 NT x 4 KiB).
+  __syncthreads();
+  if (wave < NT) {
+    char* T = X + wave * 8192;
+    const int row = lane & 31;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int d = dt * 32 + 8 * gq + 4 * g;
-          *(bf16x4*)(dKg + d) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
-          *(bf16x4*)(dVg + d) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
-        }
+      for (int gq = 0; gq < 4; ++gq) {
+        const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
+        *(bf16x4*)(T + off) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
+        *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
+      }
+    const int r8 = lane >> 3, c = lane & 7;
+    bf16* dKg = p.dK + (dkvrow + wave * 32 + r8) * p.lddk + h * HD + c * 8;
+    bf16* dVg = p.dV + (dkvrow + wave * 32 + r8) * p.lddv + h * HD + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
+      const u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
+      if (wave * 32 + r8 + 8 * i < Lkv) {
+        *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
+        *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
+      }
     }
   }
 }
@@ -456,7 +496,8 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
   const int nt = (Lkv + 31) / 32, nw = (Lq + 31) / 32;
-  const size_t lds = (size_t)2 * (nt > 4 ? 4 : nt) * 32 * ROWB + 128 * 4;
+  const size_t kvb = (size_t)2 * (nt > 4 ? 4 : nt) * 32 * ROWB, trb = (size_t)nw * 4096;      // K/V tiles; output transposition space
+  const size_t lds = (kvb > trb ? kvb : trb) + 128 * 4;
   dim3 grid(nH, nseq), block(64 * nw);
   switch (nt) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, stream, p); break;
