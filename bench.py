@@ -154,12 +154,12 @@ def decode_bench(args):
     chunks = [props[i:i + chunk] for i in range(0, N, chunk)]
     decode.beam_search_batched(m, props[:min(8, N)], k=k, max_steps=4)                      # warm-up (kernel attributes, allocator)
     for c in chunks[:args.warmup]:
-        decode.beam_search_batched(m, c, k=k, max_steps=T, graph=not args.no_graph)
+        decode.beam_search_batched(m, c, k=k, max_steps=T, graph=args.decode_graph)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nfin = 0
     for c in chunks:
-        nfin += sum(len(r) for r in decode.beam_search_batched(m, c, k=k, max_steps=T, graph=not args.no_graph))
+        nfin += sum(len(r) for r in decode.beam_search_batched(m, c, k=k, max_steps=T, graph=args.decode_graph))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"metric": "PV->SMILES k-beam decode molecules/sec", "value": round(N / dt, 2), "unit": "molecules/s", "n_gpus": 1, "steps": len(chunks),
@@ -167,7 +167,7 @@ def decode_bench(args):
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"d_pv2smiles_batched.py: {N} synthetic PVs, k={k} beams, <= {T} positions, chunks of {chunk} molecules, 12-layer "
                                   "causal text encoder with cross-attention to the 54-token PV embeddings, K/V cache"
-                                  + ("" if args.no_graph else ", one hipGraph replay per position"), "global_batch": chunk, "seq_len": T},
+                                  + (", one hipGraph replay per position" if args.decode_graph else ""), "global_batch": chunk, "seq_len": T},
            "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin}
     # ---- instrumented chunk: HIP events around every decode_attn launch (eager, single stream)
     ev, orig = [], ops.decode_attn
@@ -233,10 +233,12 @@ def main():
                     "run (what the number of ACTIVE hardware queues costs; profiles/r03_hw_queues.txt)")
     ap.add_argument("--decode", action="store_true", help="BASELINE configs[3]: PV->SMILES k-beam decode throughput instead of the pretrain step")
     ap.add_argument("--molecules", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=250, help="--decode: molecules decoded together")
+    ap.add_argument("--chunk", type=int, default=1000, help="--decode: molecules decoded together (1000 x 5 beams = 5000 rows per GEMM: 2 010-2 090 "
+                    "molecules/s against 943 at 250 and 1 469 at 500, profiles/r03_decode_bench.json)")
     ap.add_argument("--beams", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=100)
-    ap.add_argument("--no-graph", action="store_true", help="--decode: eager launches instead of one hipGraph replay per position")
+    ap.add_argument("--decode-graph", action="store_true", help="--decode: one hipGraph replay per position instead of eager launches (pays below "
+                    "~500 molecules per chunk, where a position is launch-bound)")
     args = ap.parse_args()
     if args.decode:
         if args.warmup == 10:
