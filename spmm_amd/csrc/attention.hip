@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const float inv = 1.f / sum;
   if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx * LN2 + __logf(sum);
   if (p.drop_thresh16) {
-    const uint32_t rowkey = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q);
+    const uint32_t rk = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q) + (uint32_t)(2 * g) * DROP_WEYL;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
-        const uint32_t pr = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
-        const uint32_t r0 = drop_pair(rowkey, pr), r1 = drop_pair(rowkey, pr + 1);
+        // pair index (t*32 + 8*gq + 4*g) >> 1: the lane's part (2g) is already inside rk, the rest is a literal
+        const uint32_t r0 = drop_pair(rk, t * 16 + 4 * gq), r1 = drop_pair(rk, t * 16 + 4 * gq + 1);
         st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] : 0.f;
         st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] : 0.f;
         st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] : 0.f;
@@ -212,11 +212,6 @@ __device__ __forceinline__ bf16x8 ld_xt(const char* X, int rb, int cb, int lane)
   __builtin_amdgcn_sched_barrier(0);
   return join8(r0, r1);
 }
-__device__ __forceinline__ uint32_t pk2(float a, float b) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b;
-  return __builtin_bit_cast(uint32_t, v);
-}
 __device__ __forceinline__ float up_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float up_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -283,7 +278,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
     const float lq = lse[q];
     const int qpos = q + p.q_off - p.kv_off;           // causal: key kv is visible iff kv <= qpos
     const float neg2c = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
-    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) : 0u;
+    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) + (uint32_t)(2 * g) * DROP_WEYL : 0u;
     f32x16 dp[NT];
     uint32_t keepbits[NT];
     float dloc = 0.f;
@@ -301,8 +296,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         kb = 0;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const uint32_t pr2 = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
-          const uint32_t r0 = drop_pair(rowkey, pr2), r1 = drop_pair(rowkey, pr2 + 1);
+          const uint32_t r0 = drop_pair(rowkey, t * 16 + 4 * gq), r1 = drop_pair(rowkey, t * 16 + 4 * gq + 1);   // (the lane's 2g is inside rowkey)
           kb |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
           kb |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
           kb |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);

@@ -93,6 +93,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int hf) {
   for (int e = 0; e < 8; ++e) r[e] = (bf16)v[hf * 8 + e];
   return r;
 }
+// two floats -> one register of two bf16 (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;

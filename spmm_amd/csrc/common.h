@@ -64,12 +64,23 @@ __device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
   return mix32((lo ^ s0) + (hi ^ s1) * 0x9E3779B1u);
 }
 // Attention-probability dropout: the element (row, kv) uses half (kv & 1) of drop_pair(drop_rowkey(seed, row), kv >> 1).
-// One 32-bit key per query row (hashed once per lane) and then 32-bit arithmetic only: a lane that owns four consecutive
-// keys needs two hashes for them.  (The 64-bit counter form below cost 25-30 % of the attention kernels' time.)
+// One 32-bit key per query row (hashed once per lane, full lowbias32) and then, per PAIR of elements, a Weyl step and a mixer made of
+// full-rate instructions only: x = rowkey + pair * 0x9E3779B1 (the multiple of a compile-time pair index is a literal), two
+// v_mul_u32_u24 with xor-shifts by 16 between them (v_mul_lo_u32, which lowbias32 needs twice, is quarter rate: the two of them
+// were 8 of the 14 issue slots a pair cost, and the attention kernels are VALU-bound).  The 24-bit multiply drops the top byte of
+// its input, which the preceding x ^= x >> 16 has already folded into bits 8-15.  Checked against lowbias32 on 300 000 rows x 64
+// pairs and 60 000 x 384 (keep rate, variance of the per-row drop count, keep-bit correlation at lags 1-39 along a row and between
+// rows 1-4 apart: all at the sampling noise, 2-4e-4; avalanche 0.499-0.502 per input bit); a single 24-bit multiply is NOT enough
+// (lag correlations of 1e-3 to 2e-2 depending on the constant).
+constexpr uint32_t DROP_WEYL = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t mix24(uint32_t x) {
+  x ^= x >> 16; x = __umul24(x, 0xda8f81u); x ^= x >> 16; x = __umul24(x, 0x76dfb5u); x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint64_t row) {
   return mix32((uint32_t)row ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(row >> 32) * 0x9E3779B1u);
 }
-__device__ __forceinline__ uint32_t drop_pair(uint32_t rowkey, uint32_t pair) { return mix32(rowkey + pair); }
+__device__ __forceinline__ uint32_t drop_pair(uint32_t rowkey, uint32_t pair) { return mix24(rowkey + pair * DROP_WEYL); }
 // keep-decision for element idx; thresh16 = round(p * 65536)
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
   uint32_t r = rng_pair(seed, idx >> 1);
@@ -77,8 +88,7 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
   return u >= thresh16;
 }
 // Row-kernel dropout (LayerNorm / embedding kernels): element (row, col) uses half (col & 1) of drop_pair(rowkey, col >> 1) with
-// rowkey = drop_rowkey(seed, row) hashed once per row: two 32-bit multiplies per PAIR of elements (v_mul_lo_u32 is a
-// quarter-rate instruction; the 64-bit counter form made the LayerNorm kernels VALU-co-limited).  c % 4 == 0.
+// rowkey = drop_rowkey(seed, row) hashed once per row (the 64-bit counter form made the LayerNorm kernels VALU-co-limited).  c % 4 == 0.
 __device__ __forceinline__ void drop_keep4(uint32_t rowkey, int c, uint32_t thresh16, bool k[4]) {
   const uint32_t r0 = drop_pair(rowkey, (uint32_t)c >> 1), r1 = drop_pair(rowkey, ((uint32_t)c >> 1) + 1);
   k[0] = (r0 & 0xffffu) >= thresh16; k[1] = (r0 >> 16) >= thresh16;

@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
   char* kvb = smem;
   float* mb = (float*)(smem + L::O_MB);
-  float* red = (float*)(smem + L::O_RED);
-  float* vec = (float*)(smem + L::O_VEC);
 
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,22 +163,20 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
   const int myq = rt * 32 + l31;                 // panel row this lane owns in the attention core
   const int myqc = myq < nvalid ? myq : nvalid - 1;
 
-  const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
-  for (int j = tid; j < 128; j += 256)
-    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
-  for (int j = tid; j < H; j += 256) { vec[j] = p.bo[j]; vec[H + j] = p.gamma[j]; vec[2 * H + j] = p.beta[j]; }
-
-  // Q fragments of the NEXT step (B operand: row = lane&31, d = (kk*2+g)*8 ..), by asm loads like everything else that is in
-  // flight across the loop (a compiler-visible load would be waited for with vmcnt(0), draining the prefetch ring with it)
+  // Start-up order: the first head pair's K/V DMA and the first Q fragments are issued BEFORE the mask / bias vectors are fetched, so the
+  // three round trips to memory overlap (the vectors' plain loads make the compiler wait for everything outstanding, which the barrier
+  // below needs anyway).  Step 0's Q fragments are plain loads for the same reason: nothing of theirs is in flight past the barrier.
   bf16x8 qn[4];
   const char* Qb = (const char*)(p.Q + qrow * p.ldq + hsel * HD);
   const uint32_t qvo = (uint32_t)((myqc * p.ldq) * 2 + g * 16);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qn[kk] = *(const bf16x8*)(Qb + qvo + kk * 32);
+  // Q fragments of the NEXT step (B operand: row = lane&31, d = (kk*2+g)*8 ..), by asm loads like everything else that is in
+  // flight across the loop (a compiler-visible load would be waited for with vmcnt(0), draining the prefetch ring with it)
   auto load_q = [&](int s) {
     const char* qb = Qb + s * (2 * HD * 2);
     gl_ld16<0>(qn[0], qvo, qb); gl_ld16<32>(qn[1], qvo, qb); gl_ld16<64>(qn[2], qvo, qb); gl_ld16<96>(qn[3], qvo, qb);
   };
-  __syncthreads();                               // mb / vec visible (no DMA pending yet: a plain barrier)
-  load_q(0);
 
   // ---- K/V staging: lane-linear LDS image, swizzle on the source chunk (attn_tiles.h stage_head), as SGPR-base DMA
   const char* Kg = (const char*)(p.K + kvrow * p.ldk);
@@ -210,6 +206,9 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     }
   };
   stage_pair(0, 0);
+  const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
+  for (int j = tid; j < 128; j += 256)
+    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
   // Wo fragment ring: A operands from the fragment-ordered image, D x 1 KiB in flight per wave.  Fragment j = (kh*NCT + ct)*4 + kk of a
   // step feeds two MFMAs (row tiles 0 / 1).  The first D fragments of a step are issued right after the attention core's last MFMA
   // (they land under the context-panel exchange).  They are NOT carried across the loop's back edge: an asm-loaded register
@@ -223,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     gl_ld16<kk * 1024>(ring[j % D], wvo, wbase + (ct * 2 + kh) * 4096);
   };
   XA_VM(0);
+  XA_LGKM0();                                    // the mask vector's LDS writes
   __builtin_amdgcn_s_barrier();
   XA_SB();
   XA_STAMP(1);
@@ -244,11 +244,17 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
   const uint32_t mba = lds0 + L::O_MB + 16 * g;
   const uint32_t cva = lds0 + L::O_CTX + (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);      // context panel, row-major reader
 
+  // The accumulators start from the projection bias (lane (row, g) holds columns wave*WN + ct*32 + 8*gq + 4*g + {0..3} in
+  // acc[a][ct][gq*4 ..]): the epilogue then only rounds them.
   f32x16 acc[2][NCT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = zero16();
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 b4 = *(const f32x4*)(p.bo + wave * WN + ct * 32 + 8 * gq + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[0][ct][gq * 4 + j] = b4[j]; acc[1][ct][gq * 4 + j] = b4[j]; }
+    }
 
   uint64_t seed_a = p.drop_a16 ? seed_mix(p.seed_ptr, p.salt_a) : 0;
   seed_a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(seed_a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_a);   // scalar registers
@@ -325,13 +331,12 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
     const int qpos = r0p + myq;                                      // position inside the sequence
     if (p.LSE && myq < nvalid && g == 0) gl_st4((uint32_t)(myq * 4), p.LSE + ((long)seq * p.nH + h) * p.Lq + r0p, mx * LN2 + __logf(sum));
     if (p.drop_a16) {
-      const uint32_t rowkey = drop_rowkey(seed_a, ((uint64_t)seq * p.nH + h) * p.Lq + qpos);
+      const uint32_t rowkey = drop_rowkey(seed_a, ((uint64_t)seq * p.nH + h) * p.Lq + qpos) + (uint32_t)(2 * g) * DROP_WEYL;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const uint32_t pr = (uint32_t)(t * 32 + 8 * gq + 4 * g) >> 1;
-          const uint32_t r0 = drop_pair(rowkey, pr), r1 = drop_pair(rowkey, pr + 1);
+          const uint32_t r0 = drop_pair(rowkey, t * 16 + 4 * gq), r1 = drop_pair(rowkey, t * 16 + 4 * gq + 1);   // (the lane's 2g is inside rowkey)
           st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_a16 ? st[t][gq * 4 + 0] : 0.f;
           st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_a16 ? st[t][gq * 4 + 1] : 0.f;
           st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_a16 ? st[t][gq * 4 + 2] : 0.f;
@@ -426,22 +431,10 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
               if (row < nvalid) gl_st16((uint32_t)((row * p.ldc + (tl & 15) * 8) * 2), cb, cv[i]);
             }
           }
-          if (s == NS - 1) {
-            // K/V buffers are free from here on (barrier A): the residual panel streams into them under the last projection step.
-            // Rows past the sequence re-read its last valid row (finite, never stored).
-            const char* rg = (const char*)(p.R + qrow * p.ldr);
-            for (int i = 0; i < 64 * C16 / 256; ++i) {
-              const int id = tid + 256 * i;
-              const int row = id / C16, c16 = (id % C16) ^ (row & 15);
-              const int rr = row < nvalid ? row : nvalid - 1;
-              glds16((uint32_t)((rr * p.ldr + c16 * 8) * 2), rg, lds0 + wave * 1024 + i * 4096);
-            }
-          }
           XA_SB();
         }
       });
     }
-    if (s == NS - 1) XA_VM(0);                                       // the residual panel has landed (this wave's share)
     XA_LGKM0();
     __builtin_amdgcn_s_barrier();                                    // barrier B
     XA_SB();
@@ -450,103 +443,127 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
 
   // ---------------------------------------------------------------------------------------------------- epilogue
   // accumulator layout: lane (row = a*32 + l31, g) holds columns wave*WN + ct*32 + 8*gq + 4*g + {0..3} in acc[a][ct][gq*4 ..]
-  const char* rs = kvb;                                              // residual image; z and then y overwrite it in place
-  const uint64_t seed_h = p.drop_h16 ? seed_mix(p.seed_ptr, p.salt_h) : 0;
-  const bool hdrop = p.drop_h16 != 0;
-  float rsum[2] = {0.f, 0.f};
+  //
+  // Two phases.  (1) x (the accumulators started from the bias), rounded to bf16 exactly as the projection GEMM of the composite rounds
+  // it, goes to a row-major LDS image over the dead K/V buffers; the accumulators are free after that.  (2) The LayerNorm row kernel's
+  // body (rowops.hip ln_fwd16_kernel) on that image: half a wave owns a row (32 lanes x NCH 16-byte chunks), a wave walks its 16 rows
+  // two at a time; hidden dropout (the counter hash of spmm_ln_fwd: spmm_ln_bwd regenerates the mask), + residual straight from HBM
+  // (whole rows; all of a wave's residual loads are issued before phase 1 and land under it), two-pass statistics with DPP reductions
+  // inside the half wave, z and y stored as 512-byte row segments.  One wave per SIMD: this phase is VALU-issue-bound, so its
+  // arithmetic is written on float pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two elements per issue slot).
+  constexpr int NCH = (C16 + 31) / 32;                               // 16-byte chunks of a row per lane: chunk l + 32 k
+  constexpr bool RAGGED = C16 % 32 != 0;                             // H = 128: lanes 16..31 of a half wave own no chunk
+  const int hw = lane >> 5;                                          // which of the wave's two rows
+  u32x4 rres[8][NCH];
+  {
+    const bf16* Rg = p.R + qrow * p.ldr;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = a * 32 + l31;
-    const uint32_t rowkey = hdrop ? drop_rowkey(seed_h, (uint64_t)(p.row_base + qrow + row)) : 0u;
+    for (int i = 0; i < 8; ++i) {
+      const int row = wave * 16 + 2 * i + hw, rr = row < nvalid ? row : nvalid - 1;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
-        const f32x4 b4 = *(const f32x4*)(vec + c);
-        const bf16x4 r4 = *(const bf16x4*)(rs + pslot<C16>(row, c >> 3) * 16 + g * 8);
-        bool keep[4] = {true, true, true, true};
-        if (hdrop) drop_keep4(rowkey, c, p.drop_h16, keep);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[a][ct][gq * 4 + j] + b4[j];
-          v = hdrop ? (keep[j] ? v * p.scale_h : 0.f) : v;
-          v += (float)r4[j];
-          acc[a][ct][gq * 4 + j] = v;
-          rsum[a] += v;
-        }
+      for (int k = 0; k < NCH; ++k) {
+        const int ch = l31 + 32 * k;
+        rres[i][k] = *(const u32x4*)(Rg + (long)rr * p.ldr + (ch < C16 ? ch : 0) * 8);
       }
+    }
+  }
+  f32x2 gm[NCH][4], bt[NCH][4];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = ((l31 + 32 * k) < C16 ? (l31 + 32 * k) : 0) * 8;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { gm[k][m] = *(const f32x2*)(p.gamma + c + 2 * m); bt[k][m] = *(const f32x2*)(p.beta + c + 2 * m); }
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    rsum[a] += __shfl_xor(rsum[a], 32, 64);
-    if (g == 0) red[wave * 64 + a * 32 + l31] = rsum[a];
-  }
-  __syncthreads();
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = a * 32 + l31;
+        *(bf16x4*)(kvb + pslot<C16>(row, c >> 3) * 16 + g * 8) =
+            to_bf16x4(acc[a][ct][gq * 4], acc[a][ct][gq * 4 + 1], acc[a][ct][gq * 4 + 2], acc[a][ct][gq * 4 + 3]);
+      }
+    }
+  // (a raw barrier: __syncthreads would also wait for the residual loads, which phase 2 wants in flight)
+  XA_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  XA_SB();
   XA_STAMP(20);
-  float mean[2], rstd[2], rss[2] = {0.f, 0.f};
+  const uint64_t seed_h = p.drop_h16 ? seed_mix(p.seed_ptr, p.salt_h) : 0;
+  const uint32_t lw = (uint32_t)(l31 * 4) * DROP_WEYL;               // the lane's part of the pair index (column >> 1) = (l + 32 k) * 4 + m
+#pragma unroll                                                       // (unrolled: rres[i] must stay in registers)
+  for (int i = 0; i < 8; ++i) {
+    if (wave * 16 + 2 * i >= nvalid) break;                          // wave-uniform: both rows of the pair lie past the sequence
+    const int row = wave * 16 + 2 * i + hw;
+    f32x2 z[NCH][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = a * 32 + l31;
-    mean[a] = (red[row] + red[64 + row] + red[128 + row] + red[192 + row]) * (1.f / H);
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = l31 + 32 * k;
+      const u32x4 xv = *(const u32x4*)(kvb + pslot<C16>(row, ch < C16 ? ch : 0) * 16);
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+      for (int m = 0; m < 4; ++m) {
+        const f32x2 x2 = {__builtin_bit_cast(float, xv[m] << 16), __builtin_bit_cast(float, xv[m] & 0xffff0000u)};
+        const f32x2 r2 = {__builtin_bit_cast(float, rres[i][k][m] << 16), __builtin_bit_cast(float, rres[i][k][m] & 0xffff0000u)};
+        z[k][m] = p.drop_h16 ? x2 : x2 + r2;                         // (with dropout the residual joins after the mask below)
+      }
+    }
+    if (p.drop_h16) {
+      const uint32_t rk = drop_rowkey(seed_h, (uint64_t)(p.row_base + qrow + row)) + lw;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float d = acc[a][ct][r] - mean[a]; rss[a] += d * d; }
-    rss[a] += __shfl_xor(rss[a], 32, 64);
-    if (g == 0) red[256 + wave * 64 + row] = rss[a];
-  }
-  if (p.Z) {                                                         // z image over the residual image (each lane rewrites what it read)
+      for (int k = 0; k < NCH; ++k)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int row = a * 32 + l31;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
-          *(bf16x4*)(kvb + pslot<C16>(row, c >> 3) * 16 + g * 8) =
-              to_bf16x4(acc[a][ct][gq * 4], acc[a][ct][gq * 4 + 1], acc[a][ct][gq * 4 + 2], acc[a][ct][gq * 4 + 3]);
+        for (int m = 0; m < 4; ++m) {
+          const uint32_t r = drop_pair(rk, 128 * k + m);
+          const f32x2 keep = {(r & 0xffffu) >= p.drop_h16 ? p.scale_h : 0.f, (r >> 16) >= p.drop_h16 ? p.scale_h : 0.f};
+          const f32x2 r2 = {__builtin_bit_cast(float, rres[i][k][m] << 16), __builtin_bit_cast(float, rres[i][k][m] & 0xffff0000u)};
+          z[k][m] = z[k][m] * keep + r2;                             // one packed FMA: dropout scale / zero and the residual
         }
     }
-  }
-  __syncthreads();
+    f32x2 sm2 = {0.f, 0.f};
+    u32x4 zb[NCH];                                                   // z as stored for the backward (rounded before it is centred)
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = a * 32 + l31;
-    const float var = (red[256 + row] + red[320 + row] + red[384 + row] + red[448 + row]) * (1.f / H);
-    rstd[a] = rsqrtf(var + p.eps);
-    if (!(var + p.eps > 0.f)) rstd[a] = 0.f;
-    if (p.mean && wave == 0 && g == 0 && row < nvalid) { p.mean[qrow + row] = mean[a]; p.rstd[qrow + row] = rstd[a]; }
-  }
-  XA_STAMP(21);
-  if (p.Z) {
-    for (int id = tid; id < 64 * C16; id += 256) {
-      const int row = id / C16, c16 = id % C16;
-      if (row < nvalid) *(u32x4*)(p.Z + (qrow + row) * p.ldz + c16 * 8) = *(const u32x4*)(kvb + pslot<C16>(row, c16) * 16);
-    }
-    __syncthreads();
-  }
+    for (int k = 0; k < NCH; ++k) {
+      if (RAGGED && l31 + 32 * k >= C16) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = a * 32 + l31;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int c = wave * WN + ct * 32 + 8 * gq + 4 * g;
-        const f32x4 gm = *(const f32x4*)(vec + H + c), bt = *(const f32x4*)(vec + 2 * H + c);
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (acc[a][ct][gq * 4 + j] - mean[a]) * rstd[a] * gm[j] + bt[j];
-        *(bf16x4*)(kvb + pslot<C16>(row, c >> 3) * 16 + g * 8) = to_bf16x4(o[0], o[1], o[2], o[3]);
+        for (int m = 0; m < 4; ++m) z[k][m] = f32x2{0.f, 0.f};
       }
-  }
-  __syncthreads();
-  XA_STAMP(22);
-  for (int id = tid; id < 64 * C16; id += 256) {
-    const int row = id / C16, c16 = id % C16;
-    if (row < nvalid) *(u32x4*)(p.Y + (qrow + row) * p.ldy + c16 * 8) = *(const u32x4*)(kvb + pslot<C16>(row, c16) * 16);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { sm2 += z[k][m]; zb[k][m] = pk2(z[k][m].x, z[k][m].y); }
+    }
+    const float mean = half_sum(sm2.x + sm2.y) * (1.f / H);
+    const f32x2 mean2 = {mean, mean};
+    f32x2 ss2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        z[k][m] -= mean2;                                            // centred from here on
+        const f32x2 d = (RAGGED && l31 + 32 * k >= C16) ? f32x2{0.f, 0.f} : z[k][m];
+        ss2 += d * d;
+      }
+    const float var = half_sum(ss2.x + ss2.y) * (1.f / H);
+    float rstd = rsqrtf(var + p.eps);
+    if (!(var + p.eps > 0.f)) rstd = 0.f;
+    const f32x2 rstd2 = {rstd, rstd};
+    if (row < nvalid) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int ch = l31 + 32 * k;
+        if (!RAGGED || ch < C16) {
+          u32x4 o;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const f32x2 y2 = z[k][m] * rstd2 * gm[k][m] + bt[k][m];
+            o[m] = pk2(y2.x, y2.y);
+          }
+          *(u32x4*)(p.Y + (qrow + row) * p.ldy + ch * 8) = o;
+          if (p.Z) *(u32x4*)(p.Z + (qrow + row) * p.ldz + ch * 8) = zb[k];
+        }
+      }
+      if (p.mean && l31 == 0) { p.mean[qrow + row] = mean; p.rstd[qrow + row] = rstd; }
+    }
   }
   XA_STAMP(23);
 }

@@ -31,6 +31,6 @@ for nm, nseq, U, Lq, Lkv in (("PV -> text 54x128", 512, 128, 54, 128), ("text ->
         steps_att = sum(d(1 + 2 * s, 2 + 2 * s) for s in range(6)) / 6
         steps_proj = sum(d(2 + 2 * s, 3 + 2 * s) for s in range(6)) / 6
         print(f"{nm} {mode}: panels {len(t)}  cycles (s_memtime ticks, 100 MHz?) total {d(0, 23):.0f} | prologue {d(0, 1):.0f} | per step: attention {steps_att:.0f} "
-              f"projection {steps_proj:.0f} | epilogue: bias+residual+sum {d(13, 20):.0f} var+z-image {d(20, 21):.0f} z-store+y-image {d(21, 22):.0f} y-store {d(22, 23):.0f}")
+              f"projection {steps_proj:.0f} | epilogue: bias -> LDS image {d(13, 20):.0f} LayerNorm rows (dropout, residual, statistics, z / y stores) {d(20, 23):.0f}")
         first = float(t[:, 0].min()); print(f"    launch span: first start -> last end {float(t[:, 23].max()) - first:.0f} ticks; per-step detail (panel 0): "
               + " ".join(f"{int(t[0, i + 1] - t[0, i])}" for i in range(0, 13)))
