@@ -48,3 +48,22 @@ def test_bad_shape_is_reported_without_touching_the_gpu(built):
         L.call("spmm_attn_fwd", None, 64, None, 64, None, 64, None, None, None, None, None, None, None, 64, None, 1, 1, 300, 54, 1, 0, 0.0, None, 0, 0, 0, None)
     with pytest.raises(RuntimeError, match="SPMM_models.py:279"):
         L.call("spmm_enqueue", None, 5, 64, None, 16, None, None, 64, 4, None, 1, None, None)
+
+
+def test_product_refuses_to_run_without_the_extension(tmp_path):
+    """No CPU / eager fallback: with the shared library missing the library handle and the ops that reach it raise and name the file
+    they looked for (ops that take a stream fail even earlier on a box without a GPU: torch reports the missing device)."""
+    code = (
+        "import sys, torch\n"
+        "from spmm_amd import _lib, ops\n"
+        "for what, fn in (('lib', _lib.lib), ('op', ops.adam_scalars_bytes), ('query', lambda: ops.xattn_supported(768, 12, 54, 128))):\n"
+        "    try:\n"
+        "        fn()\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'no CPU / eager fallback' in str(e) and 'missing_lib.so' in str(e), e\n"
+        "    else:\n"
+        "        sys.exit(what + ' did not raise')\n"
+        "print('refused')\n")
+    env = dict(os.environ, SPMM_HIP_LIB=str(tmp_path / "missing_lib.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stdout + r.stderr
