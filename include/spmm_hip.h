@@ -79,6 +79,14 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
 int spmm_gemm_tn_splits(int M, int N, int K, int kernel);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
                  long ldc, float* workspace, int kernel, spmm_stream_t stream);
+/* The same product with its slab reduction left PENDING: *ns_out slabs of N*K floats stay in `workspace` (0: C is complete) and the
+ * NEXT chained call on the same stream folds them into its own launch (prev_*: workspace, slab count, N, K, C, ldc of that earlier
+ * call; prev_ws null = nothing pending); spmm_gemm_tn_reduce finishes the last one.  The ~100 reduction launches of a backward pass
+ * between the weight-gradient GEMMs become one.  The caller keeps `workspace` alive until it has been folded or reduced. */
+int spmm_gemm_tn_chain(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
+                       long ldc, float* workspace, const float* prev_ws, int prev_ns, int prev_N, int prev_K, float* prev_C,
+                       long prev_ldc, int* ns_out, int kernel, spmm_stream_t stream);
+int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream);
 /* All the weight-gradient problems of a layer (up to 8) in ONE launch + one slab reduction: C_i[N_i,K_i] += alpha * A_i[M_i,N_i]^T B_i[M_i,K_i].
  * Arrays of n entries; a problem is eligible when spmm_gemm_tn_group_ok says so; workspace: spmm_gemm_tn_group_workspace(...) floats. */
 int spmm_gemm_tn_group_ok(int M, int N, int K);
