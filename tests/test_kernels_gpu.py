@@ -3,6 +3,8 @@ Inputs are asymmetric random data rounded to bf16 first, so the only differences
 bf16 rounding of outputs; tolerances are stated per test."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -660,6 +662,70 @@ def test_attention_dropout_consistency(ops):
     O2 = torch.zeros_like(O)
     ops.attn_fwd(Q, K, eye, O2, lse, **kw)
     assert ((O2.float() != 0) != (pd.permute(0, 2, 1, 3).reshape(nseq * Lq, H) != 0)).float().mean().item() > 0.05
+
+
+def _host_dropout_keep(seed, salt, rows, ncols, p):
+    """Host model of csrc/common.h's dropout counter hash: keep[row, col] for `rows` (uint64 row counters) x ncols elements.
+    seed_mix (two splitmix64 rounds over seed and salt) -> drop_rowkey (lowbias32 of the row) -> drop_pair (Weyl step + two 24-bit
+    multiply rounds) -> one 16-bit half per element against round(p * 65536).  The statistics of THIS function were checked against
+    lowbias32 when it was adopted (EXPERIMENTS.md 1.7); the test below pins the kernels to it bit for bit."""
+    M64, M32 = (1 << 64) - 1, np.uint64(0xffffffff)
+
+    def splitmix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    def mix32(x):                                   # uint64 arrays holding 32-bit values
+        x = x ^ (x >> np.uint64(16)); x = (x * np.uint64(0x21f0aaad)) & M32
+        x = x ^ (x >> np.uint64(15)); x = (x * np.uint64(0x735a2d97)) & M32
+        return x ^ (x >> np.uint64(15))
+
+    def mix24(x):
+        x = x ^ (x >> np.uint64(16)); x = ((x & np.uint64(0xffffff)) * np.uint64(0xda8f81)) & M32
+        x = x ^ (x >> np.uint64(16)); x = ((x & np.uint64(0xffffff)) * np.uint64(0x76dfb5)) & M32
+        return x ^ (x >> np.uint64(16))
+
+    s64 = splitmix64((splitmix64(seed & M64) + salt) & M64)
+    s_lo, s_hi = np.uint64(s64 & 0xffffffff), np.uint64(s64 >> 32)
+    rows = np.asarray(rows, dtype=np.uint64)
+    rowkey = mix32((rows & M32) ^ s_lo) ^ s_hi ^ (((rows >> np.uint64(32)) * np.uint64(0x9E3779B1)) & M32)
+    pair = np.arange(ncols // 2, dtype=np.uint64)
+    r = mix24((rowkey[:, None] + pair[None, :] * np.uint64(0x9E3779B1)) & M32)
+    u = np.stack([r & np.uint64(0xffff), r >> np.uint64(16)], axis=2).reshape(len(rows), ncols)
+    return u >= np.uint64(int(p * 65536 + 0.5))
+
+
+def test_dropout_masks_equal_the_host_model_of_the_hash(ops):
+    """The keep masks the kernels draw (attention probabilities: recovered with Q = 0 and V = identity; hidden dropout: recovered from the
+    pre-LayerNorm sum of a ones matrix) are bit for bit the host model's, so what was checked about that function's statistics holds for
+    the device.  1.5 M + 3.1 M decisions; the drop rate is also checked to four standard deviations."""
+    p, seed_v = 0.1, 20260931
+    seed = torch.tensor([seed_v], dtype=torch.int64, device="cuda")
+    # ---- attention: element (seq, head, q, kv) uses row counter (seq * nH + head) * Lq + q
+    nseq, nH, Lq, Lkv = 16, 12, 128, 64
+    H = nH * 64
+    Q = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")               # uniform softmax: every probability is 1 / 64 > 0
+    K = rnd(nseq * Lkv, H, seed=44)
+    eye = torch.eye(64, dtype=BF, device="cuda").repeat(nseq, nH)
+    O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+    lse = torch.zeros(nseq, nH, Lq, device="cuda")
+    ops.attn_fwd(Q, K, eye, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, dropout_p=p, seed=seed, salt=4242)
+    got = (O.float().view(nseq, Lq, nH, 64).permute(0, 2, 1, 3) != 0).cpu().numpy().reshape(nseq * nH * Lq, Lkv)
+    want = _host_dropout_keep(seed_v, 4242, np.arange(nseq * nH * Lq), Lkv, p)
+    assert np.array_equal(got, want), f"attention mask: {np.mean(got != want):.4f} of the decisions differ from the host model"
+    # ---- hidden dropout of the LayerNorm kernels: element (row, col) uses row counter row
+    rows, Hh = 4099, 768
+    x = torch.ones(rows, Hh, dtype=BF, device="cuda")
+    z, y = torch.empty_like(x), torch.empty_like(x)
+    ops.ln_fwd(x, None, torch.ones(Hh, device="cuda"), torch.zeros(Hh, device="cuda"), y, zout=z, dropout_p=p, seed=seed, salt=77)
+    got2 = (z.float() != 0).cpu().numpy()
+    want2 = _host_dropout_keep(seed_v, 77, np.arange(rows), Hh, p)
+    assert np.array_equal(got2, want2), f"hidden-dropout mask: {np.mean(got2 != want2):.4f} of the decisions differ from the host model"
+    for m in (got, got2):
+        n, pt = m.size, int(p * 65536 + 0.5) / 65536
+        assert abs((1 - m.mean()) - pt) < 4 * (pt * (1 - pt) / n) ** 0.5, (1 - m.mean(), pt)
 
 
 # ------------------------------------------------------------------------------------------- fp8 tier (BASELINE configs[4])
