@@ -190,7 +190,8 @@ def decode_bench(args):
     torch.cuda.synchronize()
     tms = sum(a.elapsed_time(b) for a, b, _ in ev)
     nbytes = sum(b for _, _, b in ev)
-    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_kernel (csrc/decode.hip): one wave per (beam row, head) over the K/V cache",
+    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_group_kernel (csrc/decode.hip): one wave per (molecule, head) over the K/V cache, a key / value row loaded once for all beams that share it "
+                                                         "(bytes counted per beam row: the sharing is the kernel's, not the algorithm's)",
                        "achieved": round(nbytes / (tms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": round(nbytes / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches": len(ev),
                        "avg_launch_us": round(tms * 1e3 / len(ev), 2), "algorithmic_bytes_per_launch": round(nbytes / len(ev)),
