@@ -95,7 +95,8 @@ int spmm_gemm_tn_group(int n, const void* const* A, const long* lda, const void*
                        const int* K, float* const* C, const long* ldc, float alpha, float* workspace, spmm_stream_t stream);
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 
-/* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 128.
+/* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 256 (one workgroup holds the K/V
+ * panel of a head in LDS; the forward runs one workgroup per 128-query chunk, the backward one launch per 128-query chunk).
  * Replaces BertSelfAttention.forward xbert.py:305-354 incl. the additive masks of :889-948 (self: 0/-10000, causal
  * for sequences >= causal_from) and invert_attention_mask :1038-1043 (cross: 0/finfo.min, is_cross=1).
  * kv_seq (optional, [nseq]): query sequence s reads the keys/values of sequence kv_seq[s] -- the passes of SPMM.forward
@@ -105,9 +106,10 @@ int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stre
  * layouts -- sequence s owns q_len[s] <= Lq rows from row q_row0[s] of Q/O/dO/dQ, source u owns kv_len[u] <= Lkv rows from
  * row kv_row0[u] of K/V (and of dK/dV unless kv_seq is given).  Rows of padding tokens whose outputs never reach a loss
  * (SPMM_models.py:139-206 read only position 0 of those passes) are then simply not computed.
- * Sequences longer than 128 run as <= 128-long query / key chunks over several launches (spmm_amd/ops.py::attn_fwd_long):
+ * Sequences longer than 256 run as <= 128-long query / key chunks over several launches (spmm_amd/ops.py::attn_fwd_long):
  * q_off / kv_off give the chunk's position for the causal mask; backward d_mode 1 writes only D[q] = sum_kv P dP of this key
- * chunk to Dbuf [nseq, nH, Lq], d_mode 2 reads the D summed over all key chunks from Dbuf (0: computed in-kernel). */
+ * chunk to Dbuf [nseq, nH, Lq], d_mode 2 reads the D summed over all key chunks from Dbuf (0: computed in-kernel; d_mode != 0
+ * takes Lq, Lkv <= 128). */
 int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const int* kmask,
                   const int* kv_seq, const int* q_row0, const int* q_len, const int* kv_row0, const int* kv_len, void* O,
                   long ldo, float* LSE, int nseq, int nH, int Lq, int Lkv, int causal_from, int is_cross, float dropout_p,

@@ -6,8 +6,9 @@
 // padding when is_decoder) and invert_attention_mask (0 / finfo.min, call site :1038-1043) folded in from the
 // raw [nseq, Lkv] 0/1 mask -- no [B,1,L,L] tensor is ever materialised.
 //
-// One workgroup per (sequence, head); head_dim is 64; Lq, Lkv <= 128, so the whole K/V panel of a head sits
-// in LDS and the score tile lives in MFMA accumulators: single pass, no online-softmax rescaling.
+// One workgroup per (sequence, head, 128-query chunk); head_dim is 64; Lkv <= 256, so the whole K/V panel of a head sits
+// in LDS (64 KiB at most) and a wave's 32 x Lkv score tile lives in MFMA accumulators (128 registers per lane at Lkv = 256):
+// single pass, no online-softmax rescaling.  (Sequences longer than 256 go through the chunked path of ops.py.)
 // Scores are computed TRANSPOSED (S^T = K Q^T via v_mfma_f32_32x32x16_bf16 with K rows as the A operand), so
 // a lane owns one query row (lane&31) and its kv entries sit in its accumulator registers: the row max / sum
 // need one cross-lane exchange (lane ^ 32) only.  The probabilities feed the second MFMA (O^T = V^T P^T)
@@ -37,6 +38,9 @@ struct AttnP {
   // kv_off are the chunk's positions inside the sequence (causal mask); d_mode 1 = only write D[q] = sum_kv P dP of this key
   // chunk to Dbuf, 2 = take D[q] (summed over all key chunks by the caller) from Dbuf instead of computing it.
   int q_off, kv_off, d_mode; float* Dbuf;
+  // backward, Lq > 128: one launch per 128-query chunk starting at row qc0 of every sequence; launches after the first ADD their
+  // dK / dV to what the earlier chunks wrote (same (sequence, head) workgroup, plain read-modify-write, launches are stream-ordered)
+  int qc0, acc_dkv;
   bf16* O; long ldo;              // fwd output (unused by backward)
   float* LSE;                     // [nseq, nH, Lq]
   const bf16* dO; long lddo;
@@ -66,11 +70,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   char* Vs = smem + NT * 32 * ROWB;
   // (the bias vector sits behind the larger of the K/V tiles and the output transposition space: 4 KiB per wave)
   const int tile_bytes = 2 * NT * 32 * ROWB > (int)blockDim.x * 64 ? 2 * NT * 32 * ROWB : (int)blockDim.x * 64;
-  float* mb = (float*)(smem + tile_bytes);            // mask value per kv (1/0), -1 = padding
-  const int h = blockIdx.x, seq = blockIdx.y;
+  float* mb = (float*)(smem + tile_bytes);            // additive bias per kv
+  const int h = blockIdx.x, seq = blockIdx.y, qc0 = blockIdx.z * 128;      // qc0: first query row of this workgroup's 128-row chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, nthreads = blockDim.x;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
   const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
+  if (qc0 >= Lq) return;                              // (packed layouts: a short sequence has no second chunk; workgroup-uniform)
   const long qrow = p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq;
   const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
   const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
@@ -82,10 +87,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   // Scores are kept in units of log2 (x log2 e): softmax = exp2(s2 - max2), one FMA per score.  (finfo.min x log2 e is clamped back to
   // finfo.min: a row with every key masked must stay finite and come out uniform, as in the reference.)
   const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
-  for (int j = tid; j < 128; j += nthreads)
+  for (int j = tid; j < NT * 32; j += nthreads)
     mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
   // Q fragments straight from HBM (B operand: row = lane&31, 8 consecutive d at (kk*2+g)*8)
-  const int q = wave * 32 + (lane & 31);
+  const int q = qc0 + wave * 32 + (lane & 31);
   const int qc = q < Lq ? q : Lq - 1;
   bf16x8 qf[4];
 #pragma unroll
@@ -93,42 +98,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __syncthreads();
 
   const bool causal = seq >= p.causal_from;
+  // Causal sequences: a key tile wholly to the right of this wave's 32 query rows contributes exp(s - 10000 - max) = 0 exactly
+  // whenever the row has one attended key -- key 0 is visible to every row, so "key 0 is not masked" (the [CLS] position of every
+  // real batch) is enough.  Those tiles are skipped (wave-uniform); if key 0 IS masked the reference's -10000 arithmetic over all
+  // keys is reproduced in full.
+  // (not in the chunked path of longer sequences -- q_off / kv_off != 0 -- where "key 0" is only the chunk's first key)
+  const bool skip_ok = causal && p.q_off == 0 && p.kv_off == 0 && __builtin_amdgcn_readfirstlane((int)(mb[0] == 0.f));
+  const int tlast = skip_ok ? (qc0 + wave * 32 + 31) >> 5 : NT - 1;
   f32x16 st[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     st[t] = zero16();
+    if (t <= tlast) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
+      for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
+    }
   }
   // registers 4*gq .. 4*gq+3 of tile t hold the 4 consecutive keys t*32 + 8*gq + 4*g + {0..3}: one 16-B read of the bias vector
   float mx = -INFINITY;
   const int qpos = q + p.q_off - p.kv_off;          // causal: key kv is visible iff kv <= qpos
 #pragma unroll
   for (int t = 0; t < NT; ++t)
+    if (t <= tlast) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int kv0 = t * 32 + 8 * gq + 4 * g;
-      f32x4 b = *(const f32x4*)(mb + kv0);
-      if (causal) {                                 // workgroup-uniform
+      for (int gq = 0; gq < 4; ++gq) {
+        const int kv0 = t * 32 + 8 * gq + 4 * g;
+        f32x4 b = *(const f32x4*)(mb + kv0);
+        if (causal) {                                 // workgroup-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], neg2) : b[j];
-      }
+          for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], neg2) : b[j];
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float sc = __builtin_fmaf(st[t][gq * 4 + j], 0.125f * LOG2E, b[j]);
-        st[t][gq * 4 + j] = sc;
-        mx = fmaxf(mx, sc);
+        for (int j = 0; j < 4; ++j) {
+          const float sc = __builtin_fmaf(st[t][gq * 4 + j], 0.125f * LOG2E, b[j]);
+          st[t][gq * 4 + j] = sc;
+          mx = fmaxf(mx, sc);
+        }
       }
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
+    if (t <= tlast) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
-      st[t][r] = e;
-      sum += e;
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
+        st[t][r] = e;
+        sum += e;
+      }
     }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
@@ -137,20 +155,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const uint32_t rk = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q) + (uint32_t)(2 * g) * DROP_WEYL;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
+      if (t <= tlast) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
-        // pair index (t*32 + 8*gq + 4*g) >> 1: the lane's part (2g) is already inside rk, the rest is a literal
-        const uint32_t r0 = drop_pair(rk, t * 16 + 4 * gq), r1 = drop_pair(rk, t * 16 + 4 * gq + 1);
-        st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] : 0.f;
-        st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] : 0.f;
-        st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] : 0.f;
-        st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] : 0.f;
+        for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
+          // pair index (t*32 + 8*gq + 4*g) >> 1: the lane's part (2g) is already inside rk, the rest is a literal
+          const uint32_t r0 = drop_pair(rk, t * 16 + 4 * gq), r1 = drop_pair(rk, t * 16 + 4 * gq + 1);
+          st[t][gq * 4 + 0] = (r0 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 0] : 0.f;
+          st[t][gq * 4 + 1] = (r0 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 1] : 0.f;
+          st[t][gq * 4 + 2] = (r1 & 0xffffu) >= p.drop_thresh16 ? st[t][gq * 4 + 2] : 0.f;
+          st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] : 0.f;
+        }
       }
   }
   // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
   f32x16 ot[2] = {zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (t > tlast) continue;
     const bf16x8 pf0 = pack8(st[t], 0), pf1 = pack8(st[t], 1);
     bf16x8 vf0[2], vf1[2];
     ld_tr2x2(Vs, t * 32, lane, vf0, vf1);
@@ -176,37 +197,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
             to_bf16x4(ot[dt][gq * 4] * osc, ot[dt][gq * 4 + 1] * osc, ot[dt][gq * 4 + 2] * osc, ot[dt][gq * 4 + 3] * osc);
     // (same wave: LDS operations execute in order, no barrier between its writes and its reads)
     const int r8 = lane >> 3, c = lane & 7;
-    bf16* Og = p.O + (qrow + wave * 32 + r8) * p.ldo + h * HD + c * 8;
+    bf16* Og = p.O + (qrow + qc0 + wave * 32 + r8) * p.ldo + h * HD + c * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32x4s v = *(const u32x4s*)(T + (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4));
-      if (wave * 32 + r8 + 8 * i < Lq) *(u32x4s*)(Og + (long)(8 * i) * p.ldo) = v;
+      if (qc0 + wave * 32 + r8 + 8 * i < Lq) *(u32x4s*)(Og + (long)(8 * i) * p.ldo) = v;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward
 // LDS: region X | Q | dO | small vectors.  X holds K and V during phase A, then the probabilities P~ (dropout applied) and
-// then dS, as [q][kv] bf16 tiles with 256-B rows: the transposed layout phase B needs is produced by ONE pass over the
-// scores (phase A) instead of recomputing S and dP per key tile.
+// then dS, as [q][kv] bf16 tiles with 256-B rows (512-B rows when Lkv > 128): the transposed layout phase B needs is produced by
+// ONE pass over the scores (phase A) instead of recomputing S and dP per key tile.
+// A launch covers one chunk of <= 128 query rows (p.qc0) against ALL keys: Lkv <= 128 keeps a wave's 32 x Lkv tiles of P, dP in ~170-244
+// registers (2-3 workgroups per CU); 128 < Lkv <= 256 takes one wave per SIMD (the whole 512-register file: the row sum D = sum P dP
+// must be complete before dS can be formed, so every score tile of the row stays in registers).
+__host__ __device__ constexpr int bwd_xrow(int nt_kv) { return nt_kv <= 4 ? 256 : 512; }
 __host__ __device__ constexpr int bwd_xbytes(int nt_kv, int nt_q) {
-  return 2 * nt_kv * 32 * 128 > nt_q * 32 * 256 ? 2 * nt_kv * 32 * 128 : nt_q * 32 * 256;
+  return 2 * nt_kv * 32 * 128 > nt_q * 32 * bwd_xrow(nt_kv) ? 2 * nt_kv * 32 * 128 : nt_q * 32 * bwd_xrow(nt_kv);
 }
-constexpr int BWD_LDS = bwd_xbytes(4, 4) + 2 * TILE + 3 * 128 * 4;
+constexpr int BWD_LDS = bwd_xbytes(8, 4) + 2 * TILE + (256 + 128) * 4;
 
-// [q][kv] bf16 tile, 256-B rows, 8-B slots (4 consecutive kv).  Slot index XOR ((q & 3) << 3 | ((q >> 2) & 3) << 1):
+// [q][kv] bf16 tile, RB-byte rows, 8-B slots (4 consecutive kv).  Slot index XOR ((q & 3) << 3 | ((q >> 2) & 3) << 1):
 //  * the 16 lanes of a write group (16 consecutive q, one slot) land on 16 distinct slots;
 //  * the 4 rows x 8 slots of a 32-lane transpose-read group land on 4 distinct 64-B spans.
-__device__ __forceinline__ int xoff(int q, int slot) { return q * 256 + ((slot ^ (((q & 3) << 3) | (((q >> 2) & 3) << 1))) << 3); }
+// (RB = 512: the XOR touches the low 5 bits of the 6-bit slot index only, and rows stay a multiple of the 256-B bank window apart.)
+template <int RB>
+__device__ __forceinline__ int xoff(int q, int slot) { return q * RB + ((slot ^ (((q & 3) << 3) | (((q >> 2) & 3) << 1))) << 3); }
 
 // B-operand fragment of the [q][kv] tile for MFMA 32x32x16: lane (kv = cb + (lane & 31), g = lane >> 5) receives
 // X[rb + 4g + {0..3, 8..11}][kv] -- the k-slot order of ld_tr2's A operands.
+template <int RB>
 __device__ __forceinline__ bf16x8 ld_xt(const char* X, int rb, int cb, int lane) {
   const int i16 = lane & 15, j = lane >> 4;
   const int row0 = rb + 4 * (j >> 1) + (i16 >> 2);
   const int slot = (cb + (j & 1) * 16 + (i16 & 3) * 4) >> 2;
-  const unsigned a0 = (unsigned)(size_t)(X + xoff(row0, slot));
-  const unsigned a1 = (unsigned)(size_t)(X + xoff(row0 + 8, slot));
+  const unsigned a0 = (unsigned)(size_t)(X + xoff<RB>(row0, slot));
+  const unsigned a1 = (unsigned)(size_t)(X + xoff<RB>(row0 + 8, slot));
   bf16x4 r0, r1;
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1) : "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -217,10 +245,18 @@ __device__ __forceinline__ float up_hi(uint32_t w) { return __builtin_bit_cast(f
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: ceil(max Lq / 32) tiles)
-  const int ntq_max = (p.Lq + 31) >> 5;
+  constexpr int RB = bwd_xrow(NT);
+  constexpr int KI = (NT + 3) / 4;                   // key tiles per wave in phase B
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
+  const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
+  const int qc0 = p.qc0, nq = Lq - qc0 < 128 ? Lq - qc0 : 128;   // this launch's query rows of the sequence: [qc0, qc0 + nq)
+  if (nq <= 0) return;                               // (a later chunk of a short packed sequence: nothing to add; workgroup-uniform)
+  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: the chunk's tiles of the longest sequence)
+  const int ntq_max = p.Lq - qc0 >= 128 ? 4 : (p.Lq - qc0 + 31) >> 5;
   const int kvb = NT * 32 * 128, qb = ntq_max * 32 * 128, xb = bwd_xbytes(NT, ntq_max);
   char* X = smem;
   char* Ks = X;
@@ -228,30 +264,26 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   char* Qs = X + xb;
   char* dOs = Qs + qb;
   float* mb = (float*)(dOs + qb);
-  float* lse = mb + 128;
-  const int h = blockIdx.x, seq = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-  const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
-  const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
-  const long qrow = p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq;
+  float* lse = mb + NT * 32;
+  const long qrow = (p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq) + qc0;
   const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
   const long dkvrow = p.kv_seq ? (long)seq * p.Lkv : kvrow;     // shared sources: dK/dV per query sequence, dense
   const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
   const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
   const bf16* dOg = p.dO + qrow * p.lddo + h * HD;
-  const int qrows = ((Lq + 31) >> 5) * 32;
+  const int qrows = ((nq + 31) >> 5) * 32;
   stage_head(Kg, p.ldk, Lkv, Ks, tid, 256, NT * 32);
   stage_head(Vg, p.ldv, Lkv, Vs, tid, 256, NT * 32);
-  stage_head(Qg, p.ldq, Lq, Qs, tid, 256, qrows);
-  stage_head(dOg, p.lddo, Lq, dOs, tid, 256, qrows);
-  if (tid < 128) {
-    const int j = tid;
+  stage_head(Qg, p.ldq, nq, Qs, tid, 256, qrows);
+  stage_head(dOg, p.lddo, nq, dOs, tid, 256, qrows);
+  {
     // additive score bias per key as in the forward: 0 (attend), mask_neg (masked), -inf (tile padding past Lkv: P = 0 exactly);
-    // query rows past Lq get lse = +inf, i.e. P = exp(s - inf) = 0, so neither needs a per-element test below
+    // query rows past the chunk get lse = +inf, i.e. P = exp(s - inf) = 0, so neither needs a per-element test below
     const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);     // (units of log2, as in the forward)
-    mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
-    lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + j] * LOG2E : INFINITY;
+    for (int j = tid; j < NT * 32; j += 256)
+      mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
+    if (tid < 128) lse[tid] = tid < nq ? p.LSE[((long)seq * p.nH + h) * p.Lq + qc0 + tid] * LOG2E : INFINITY;
   }
   __syncthreads();
 
@@ -259,23 +291,29 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   const bool drop = p.drop_thresh16 != 0;
   const uint64_t seed = drop ? seed_mix(p.seed_ptr, p.seed_salt) : 0;
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
-  const int NTq = (Lq + 31) >> 5;
+  const int NTq = (nq + 31) >> 5;
   const float dsc = drop ? p.drop_scale : 1.f, qsc = 0.125f * dsc;     // (see the dropout note in phase A)
+  // causal sequences whose key 0 is attended: (query tile, key tile) pairs wholly above the diagonal hold P = 0 exactly and are
+  // skipped, as in the forward (never in the chunked path of sequences longer than 256)
+  const bool skip_ok = causal && p.q_off == 0 && p.kv_off == 0 && p.d_mode == 0 && __builtin_amdgcn_readfirstlane((int)(mb[0] == 0.f));
+  const int qt0 = qc0 >> 5;                            // global index of the chunk's first query tile
 
   // ---- phase A: wave owns query tile `wave`: ONE pass over the scores gives D[q] = sum_kv P dP (fp32, exactly consistent with
   // ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and dS = P (dP - D).
   // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
   // ds = P (dP - D) is a small difference of large numbers that such a D would swamp.
   uint32_t ppk[NT][8], dpk[NT][8];                   // packed bf16 pairs: registers (2i, 2i+1) of tile t
-  const int q = wave * 32 + (lane & 31);
+  const int ql = wave * 32 + (lane & 31);            // row inside the chunk
+  const int q = qc0 + ql;                            // row inside the sequence
+  const int tlast = skip_ok ? qt0 + wave : NT - 1;   // last key tile this wave's rows can see
   if (wave < NTq) {
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      qf[kk] = ld_rm(Qs, q, kk * 2 + g);
-      dof[kk] = ld_rm(dOs, q, kk * 2 + g);
+      qf[kk] = ld_rm(Qs, ql, kk * 2 + g);
+      dof[kk] = ld_rm(dOs, ql, kk * 2 + g);
     }
-    const float lq = lse[q];
+    const float lq = lse[ql];
     const int qpos = q + p.q_off - p.kv_off;           // causal: key kv is visible iff kv <= qpos
     const float neg2c = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
     const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) + (uint32_t)(2 * g) * DROP_WEYL : 0u;
@@ -284,6 +322,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
     float dloc = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (t > tlast) continue;                         // (wave-uniform) nothing of this tile is visible: P = dS = 0, never stored
       f32x16 st = zero16();
       dp[t] = zero16();
 #pragma unroll
@@ -340,6 +379,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
       f32x16 dq[2] = {zero16(), zero16()};
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+        if (t > tlast) continue;
         const uint32_t kb = keepbits[t];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -364,7 +404,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
         // No LDS is free here (Q and dO are read again in phase B), so the 8-byte pieces are widened in registers instead: lanes l
         // and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands lane l the other half of the
         // EVEN chunks and lane l + 32 the other half of the ODD ones: four 16-byte stores per lane instead of eight 8-byte ones.
-        bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD + 8 * g;
+        bf16* dQg = p.dQ + (qrow + ql) * p.lddq + h * HD + 8 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -381,86 +421,113 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   }
   if (p.d_mode == 1) return;   // partial-D pass: nothing else is written
 
-  // ---- phase B: wave owns kv tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
+  // ---- phase B: wave owns kv tiles `wave`, `wave + 4`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
+  // (a (query tile, key tile) pair above the causal diagonal holds zeros -- or, for key tiles past tlast, was never written -- and is
+  // skipped: pair (qt, kt) is live iff kt <= qt0 + qt)
   __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
   if (wave < NTq) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
+      if (t <= tlast) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *(u32x2*)(X + xoff(q, t * 8 + 2 * gq + g)) = u32x2{ppk[t][2 * gq], ppk[t][2 * gq + 1]};
+        for (int gq = 0; gq < 4; ++gq) {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{ppk[t][2 * gq], ppk[t][2 * gq + 1]};
+        }
       }
   }
   __syncthreads();
-  const int kv = wave * 32 + (lane & 31);
-  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-  if (wave < NT) {
-    for (int qt = 0; qt < NTq; ++qt)
+  f32x16 dk[KI][2], dv[KI][2];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = ld_xt(X, qt * 32 + hf * 16, wave * 32, lane);
-        bf16x8 dof[2];
-        ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
-        dv[0] = MFMA32(dof[0], pf, dv[0]);
-        dv[1] = MFMA32(dof[1], pf, dv[1]);
-      }
+  for (int ki = 0; ki < KI; ++ki) {
+    dk[ki][0] = zero16(); dk[ki][1] = zero16(); dv[ki][0] = zero16(); dv[ki][1] = zero16();
+    const int kt = wave + 4 * ki;
+    if (kt < NT) {
+      for (int qt = skip_ok && kt > qt0 ? kt - qt0 : 0; qt < NTq; ++qt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const bf16x8 pf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
+          bf16x8 dof[2];
+          ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
+          dv[ki][0] = MFMA32(dof[0], pf, dv[ki][0]);
+          dv[ki][1] = MFMA32(dof[1], pf, dv[ki][1]);
+        }
+    }
   }
   __syncthreads();             // P~ consumed: region X becomes the dS tile
   if (wave < NTq) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
+      if (t <= tlast) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *(u32x2*)(X + xoff(q, t * 8 + 2 * gq + g)) = u32x2{dpk[t][2 * gq], dpk[t][2 * gq + 1]};
+        for (int gq = 0; gq < 4; ++gq) {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{dpk[t][2 * gq], dpk[t][2 * gq + 1]};
+        }
       }
   }
   __syncthreads();
-  if (wave < NT) {
-    for (int qt = 0; qt < NTq; ++qt)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 dsf = ld_xt(X, qt * 32 + hf * 16, wave * 32, lane);
-        bf16x8 qf[2];
-        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
-        dk[0] = MFMA32(qf[0], dsf, dk[0]);
-        dk[1] = MFMA32(qf[1], dsf, dk[1]);
-      }
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kt = wave + 4 * ki;
+    if (kt < NT) {
+      for (int qt = skip_ok && kt > qt0 ? kt - qt0 : 0; qt < NTq; ++qt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const bf16x8 dsf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
+          bf16x8 qf[2];
+          ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
+          dk[ki][0] = MFMA32(qf[0], dsf, dk[ki][0]);
+          dk[ki][1] = MFMA32(qf[1], dsf, dk[ki][1]);
+        }
+    }
   }
   // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
-  // once all waves are past their last read, and the kv-wave w transposes through bytes [8192 w, 8192 w + 8192) of region X
-  // (X >= 2 NT x 4 KiB).
+  // once all waves are past their last read, and wave w transposes through bytes [8192 w, 8192 w + 8192) of region X (X >= 32 KiB
+  // whenever 4 waves hold tiles).  Launches for later query chunks add to what the earlier ones stored (p.acc_dkv).
   __syncthreads();
-  if (wave < NT) {
-    char* T = X + wave * 8192;
-    const int row = lane & 31;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kt = wave + 4 * ki;
+    if (kt < NT) {
+      char* T = X + wave * 8192;
+      const int row = lane & 31;
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
-        *(bf16x4*)(T + off) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
-        *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
-      }
-    const int r8 = lane >> 3, c = lane & 7;
-    bf16* dKg = p.dK + (dkvrow + wave * 32 + r8) * p.lddk + h * HD + c * 8;
-    bf16* dVg = p.dV + (dkvrow + wave * 32 + r8) * p.lddv + h * HD + c * 8;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
-      const u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
-      if (wave * 32 + r8 + 8 * i < Lkv) {
-        *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
-        *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
+        for (int gq = 0; gq < 4; ++gq) {
+          const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
+          *(bf16x4*)(T + off) = to_bf16x4(dk[ki][dt][gq * 4] * qsc, dk[ki][dt][gq * 4 + 1] * qsc, dk[ki][dt][gq * 4 + 2] * qsc, dk[ki][dt][gq * 4 + 3] * qsc);
+          *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[ki][dt][gq * 4] * dsc, dv[ki][dt][gq * 4 + 1] * dsc, dv[ki][dt][gq * 4 + 2] * dsc, dv[ki][dt][gq * 4 + 3] * dsc);
+        }
+      const int r8 = lane >> 3, c = lane & 7;
+      bf16* dKg = p.dK + (dkvrow + kt * 32 + r8) * p.lddk + h * HD + c * 8;
+      bf16* dVg = p.dV + (dkvrow + kt * 32 + r8) * p.lddv + h * HD + c * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
+        u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
+        if (kt * 32 + r8 + 8 * i < Lkv) {
+          if (p.acc_dkv) {
+            const u32x4 ok = *(const u32x4*)(dKg + (long)(8 * i) * p.lddk), ov = *(const u32x4*)(dVg + (long)(8 * i) * p.lddv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              vk[e] = pk2(up_lo(vk[e]) + up_lo(ok[e]), up_hi(vk[e]) + up_hi(ok[e]));
+              vv[e] = pk2(up_lo(vv[e]) + up_lo(ov[e]), up_hi(vv[e]) + up_hi(ov[e]));
+            }
+          }
+          *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
+          *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
+        }
       }
     }
   }
 }
 
+constexpr int ATTN_MAXL = 256;
 int check_common(const char* name, int nseq, int nH, int Lq, int Lkv, long ldq, long ldk, long ldv) {
   SPMM_CHECK_SHAPE(nseq > 0 && nH > 0, "%s: empty problem", name);
-  SPMM_CHECK_SHAPE(Lq >= 1 && Lq <= 128 && Lkv >= 1 && Lkv <= 128, "%s: Lq=%d Lkv=%d must be in [1,128]", name, Lq, Lkv);
+  SPMM_CHECK_SHAPE(Lq >= 1 && Lq <= ATTN_MAXL && Lkv >= 1 && Lkv <= ATTN_MAXL, "%s: Lq=%d Lkv=%d must be in [1,%d]", name, Lq, Lkv, ATTN_MAXL);
   SPMM_CHECK_SHAPE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "%s: row strides must be multiples of 8", name);
   return SPMM_OK;
 }
@@ -489,15 +556,33 @@ extern "C" int spmm_attn_fwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
-  const int nt = (Lkv + 31) / 32, nw = (Lq + 31) / 32;
-  const size_t kvb = (size_t)2 * (nt > 4 ? 4 : nt) * 32 * ROWB, trb = (size_t)nw * 4096;      // K/V tiles; output transposition space
-  const size_t lds = (kvb > trb ? kvb : trb) + 128 * 4;
-  dim3 grid(nH, nseq), block(64 * nw);
+  // > 64 KiB of dynamic LDS (Lkv > 224) needs the opt-in: once per process
+  static const hipError_t attr_rc = [] {
+    const void* fns[4] = {(const void*)attn_fwd_kernel<5>, (const void*)attn_fwd_kernel<6>, (const void*)attn_fwd_kernel<7>,
+                          (const void*)attn_fwd_kernel<8>};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 32 * ROWB + 256 * 4);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }();
+  if (attr_rc != hipSuccess) {
+    spmm_set_error("spmm_attn_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(attr_rc));
+    return SPMM_ERR_LAUNCH;
+  }
+  const int nt = (Lkv + 31) / 32, nw = Lq > 128 ? 4 : (Lq + 31) / 32;                         // 128-query chunks: grid.z
+  const size_t kvb = (size_t)2 * nt * 32 * ROWB, trb = (size_t)nw * 4096;                    // K/V tiles; output transposition space
+  const size_t lds = (kvb > trb ? kvb : trb) + (size_t)nt * 32 * 4;
+  dim3 grid(nH, nseq, (Lq + 127) / 128), block(64 * nw);
   switch (nt) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, stream, p); break;
     case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, stream, p); break;
     case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, block, lds, stream, p); break;
-    default: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, stream, p); break;
+    case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, stream, p); break;
+    case 5: hipLaunchKernelGGL(attn_fwd_kernel<5>, grid, block, lds, stream, p); break;
+    case 6: hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, lds, stream, p); break;
+    case 7: hipLaunchKernelGGL(attn_fwd_kernel<7>, grid, block, lds, stream, p); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, stream, p); break;
   }
   SPMM_LAUNCH_CHECK("spmm_attn_fwd");
   return SPMM_OK;
@@ -515,12 +600,14 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   SPMM_CHECK_SHAPE((q_row0 == nullptr) == (q_len == nullptr) && (kv_row0 == nullptr) == (kv_len == nullptr),
                    "spmm_attn_bwd: row0 and len arrays come in pairs");
   SPMM_CHECK_SHAPE(d_mode == 0 || ((d_mode == 1 || d_mode == 2) && Dbuf != nullptr), "spmm_attn_bwd: d_mode=%d needs Dbuf", d_mode);
+  SPMM_CHECK_SHAPE(d_mode == 0 || (Lq <= 128 && Lkv <= 128), "spmm_attn_bwd: d_mode=%d is the chunked path of sequences longer than %d: chunks of <= 128", d_mode, ATTN_MAXL);
   // > 64 KiB dynamic LDS needs the opt-in: once per process (function-local static: initialised exactly once, thread-safe --
   // backward entries are called from autograd worker threads)
   static const hipError_t attr_rc = [] {
-    const void* fns[4] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
-                          (const void*)attn_bwd_kernel<4>};
-    for (int i = 0; i < 4; ++i) {
+    const void* fns[8] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
+                          (const void*)attn_bwd_kernel<4>, (const void*)attn_bwd_kernel<5>, (const void*)attn_bwd_kernel<6>,
+                          (const void*)attn_bwd_kernel<7>, (const void*)attn_bwd_kernel<8>};
+    for (int i = 0; i < 8; ++i) {
       hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
       if (e != hipSuccess) return e;
     }
@@ -542,13 +629,22 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f);
   p.drop_scale = 1.f / (1.f - dropout_p);
   p.seed_ptr = seed_ptr; p.seed_salt = seed_salt;
-  const int nt_b = (Lkv + 31) / 32 > 4 ? 4 : (Lkv + 31) / 32;
-  const size_t lds_b = (size_t)bwd_xbytes(nt_b, (Lq + 31) / 32) + (size_t)2 * ((Lq + 31) / 32) * 32 * 128 + 3 * 128 * 4;
-  switch ((Lkv + 31) / 32) {
-    case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-    case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-    case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-    default: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+  const int nt = (Lkv + 31) / 32;
+  // one launch per 128-query chunk, all keys each; chunks after the first add their dK / dV to the earlier ones' (stream order)
+  for (int qc0 = 0; qc0 < Lq; qc0 += 128) {
+    p.qc0 = qc0; p.acc_dkv = qc0 > 0;
+    const int ntq = Lq - qc0 >= 128 ? 4 : (Lq - qc0 + 31) / 32;
+    const size_t lds_b = (size_t)bwd_xbytes(nt, ntq) + (size_t)2 * ntq * 32 * 128 + (size_t)(nt * 32 + 128) * 4;
+    switch (nt) {
+      case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 5: hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 6: hipLaunchKernelGGL(attn_bwd_kernel<6>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 7: hipLaunchKernelGGL(attn_bwd_kernel<7>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      default: hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+    }
   }
   SPMM_LAUNCH_CHECK("spmm_attn_bwd");
   return SPMM_OK;

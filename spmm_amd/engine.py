@@ -271,20 +271,20 @@ class Engine:
     # ---------------------------------------------------------------------------------------- attention launches
     @staticmethod
     def _attn_fwd(Q, K, V, O, lse, *, Lq, Lkv, q_row0=None, q_len=None, kv_row0=None, kv_len=None, **kw):
-        """Kernels keep <= 128 rows of Q / K / V on chip; longer (dense) sequences go through the chunked path of ops.py."""
-        if Lq <= 128 and Lkv <= 128:
+        """Kernels keep <= 256 rows of K / V on chip; longer (dense) sequences go through the chunked path of ops.py."""
+        if Lq <= ops.ATTN_MAXL and Lkv <= ops.ATTN_MAXL:
             return ops.attn_fwd(Q, K, V, O, lse, Lq=Lq, Lkv=Lkv, q_row0=q_row0, q_len=q_len, kv_row0=kv_row0, kv_len=kv_len, **kw)
         if q_row0 is not None or kv_row0 is not None:
-            raise ValueError("packed layouts are limited to 128-token sequences")
+            raise ValueError("packed layouts are limited to %d-token sequences" % ops.ATTN_MAXL)
         return ops.attn_fwd_long(Q, K, V, O, lse, Lq=Lq, Lkv=Lkv, **kw)
 
     @staticmethod
     def _attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, *, Lq, Lkv, q_row0=None, q_len=None, kv_row0=None, kv_len=None, **kw):
-        if Lq <= 128 and Lkv <= 128:
+        if Lq <= ops.ATTN_MAXL and Lkv <= ops.ATTN_MAXL:
             return ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, Lq=Lq, Lkv=Lkv, q_row0=q_row0, q_len=q_len, kv_row0=kv_row0,
                                 kv_len=kv_len, **kw)
         if q_row0 is not None or kv_row0 is not None:
-            raise ValueError("packed layouts are limited to 128-token sequences")
+            raise ValueError("packed layouts are limited to %d-token sequences" % ops.ATTN_MAXL)
         return ops.attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, Lq=Lq, Lkv=Lkv, **kw)
 
     # ---------------------------------------------------------------------------------------- attention block

@@ -442,19 +442,22 @@ def segment_sum_bf16(src, start, lst, out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Sequences longer than the 128 rows the attention kernels keep on chip (up to the 512 positions of config_bert.json):
+# Sequences longer than the 256 rows the attention kernels keep on chip (up to the 512 positions of config_bert.json):
 # queries and keys are processed in <= 128-long chunks by several launches and merged here.  Forward merges the per-key-chunk
 # outputs with their log-sum-exp weights (exact, also with dropout: the mask does not depend on the normalisation); backward
 # first sums D[q] = sum_kv P dP over the key chunks (d_mode 1), then runs the gradient launches with that D (d_mode 2).
 # Dense layouts only (optionally with shared key/value sources).
 # ---------------------------------------------------------------------------------------------------------------------
+ATTN_MAXL = 256          # csrc/attention.hip: K / V panel of a head in LDS, a wave's 32 x Lkv score tile in registers
+
+
 def _chunks(L, step=128):
     return [(o, min(step, L - o)) for o in range(0, L, step)]
 
 
 def attn_fwd_long(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0, seed=None,
                   salt=0, kv_seq=None):
-    if Lq <= 128 and Lkv <= 128:
+    if Lq <= ATTN_MAXL and Lkv <= ATTN_MAXL:
         return attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=kmask, causal_from=causal_from, is_cross=is_cross,
                         dropout_p=dropout_p, seed=seed, salt=salt, kv_seq=kv_seq)
     dev, H = Q.device, nH * 64
@@ -486,7 +489,7 @@ def attn_fwd_long(Q, K, V, O, lse, *, nseq, nH, Lq, Lkv, kmask=None, causal_from
 def attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, *, nseq, nH, Lq, Lkv, kmask=None, causal_from=None, is_cross=False, dropout_p=0.0,
                   seed=None, salt=0, kv_seq=None):
     """dK / dV: [nseq*Lkv, H] views when kv_seq is given (per query sequence), else [sources*Lkv, H]."""
-    if Lq <= 128 and Lkv <= 128:
+    if Lq <= ATTN_MAXL and Lkv <= ATTN_MAXL:
         return attn_bwd(Q, K, V, O, lse, dO, dQ, dK, dV, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=kmask, causal_from=causal_from,
                         is_cross=is_cross, dropout_p=dropout_p, seed=seed, salt=salt, kv_seq=kv_seq)
     dev, H = Q.device, nH * 64

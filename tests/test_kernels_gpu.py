@@ -329,6 +329,10 @@ ATT_CASES = [  # nseq, nH, Lq, Lkv, causal_from, is_cross
     (3, 2, 54, 54, 3, False), (4, 2, 54, 54, 2, False), (2, 12, 128, 128, 1, False), (3, 2, 54, 128, 3, True),
     (3, 2, 128, 54, 3, True), (5, 2, 16, 16, 2, False), (2, 2, 24, 54, 2, True), (2, 3, 100, 77, 2, True),
     (2, 2, 33, 33, 0, False),
+    # 128 < L <= 256: the K/V panel still sits in LDS, a wave's 32 x Lkv score tile in registers; the forward runs one workgroup per
+    # 128-query chunk, the backward one launch per chunk (later chunks add to dK / dV)
+    (2, 2, 256, 256, 1, False), (3, 2, 200, 200, 1, False), (2, 3, 192, 192, 0, False), (3, 2, 54, 256, 3, True), (2, 2, 256, 54, 2, True),
+    (2, 2, 130, 54, 2, True), (2, 2, 160, 224, 2, True), (2, 12, 129, 129, 1, False),
 ]
 
 
@@ -525,11 +529,12 @@ def test_fused_cross_attention_block(ops, nH, nseq, U, Lq, Lkv, packed, drop):
         close(out["y"][int(qs[s_]):int(qs[s_]) + lq], yy, atol=6e-2, rtol=2e-2, name=f"y vs fp32 torch, sequence {s_}")
 
 
+@pytest.mark.parametrize("Lq", [100, 230])
 @pytest.mark.parametrize("is_cross,shared", [(False, False), (True, False), (True, True)])
-def test_attention_packed_variable_length_layout(ops, is_cross, shared):
+def test_attention_packed_variable_length_layout(ops, is_cross, shared, Lq):
     """Packed rows (q_row0/q_len, kv_row0/kv_len) give bit-identical O, LSE, dQ, dK, dV on the valid rows to the dense
     padded layout with a key mask: the padded positions are simply never computed."""
-    nseq, nH, Lq, Lkv = 6, 2, 100, 54 if is_cross else 100
+    nseq, nH, Lkv = 6, 2, 54 if is_cross else Lq
     H = nH * 64
     g = torch.Generator().manual_seed(77)
     qlen = torch.randint(5, Lq + 1, (nseq,), generator=g); qlen[0] = Lq
@@ -572,11 +577,11 @@ def test_attention_packed_variable_length_layout(ops, is_cross, shared):
         assert torch.equal(dKVp, dKVd[ksel])
 
 
-@pytest.mark.parametrize("nseq,nH,Lq,Lkv,causal_from,is_cross", [(3, 2, 200, 200, 1, False), (2, 2, 256, 256, 0, False), (3, 2, 54, 256, 3, True),
-                                                               (2, 2, 130, 54, 2, True)])
+@pytest.mark.parametrize("nseq,nH,Lq,Lkv,causal_from,is_cross", [(3, 2, 300, 300, 1, False), (2, 2, 512, 512, 0, False), (3, 2, 54, 400, 3, True),
+                                                               (2, 2, 300, 54, 2, True), (2, 2, 256, 256, 1, False)])
 def test_attention_long_sequences_by_chunks(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
-    """Sequences beyond the 128 rows the kernels keep on chip (up to 256 here): chunked launches merged by log-sum-exp in
-    forward, two-pass D in backward, against the fp32 reference arithmetic."""
+    """Sequences beyond the 256 rows the kernels keep on chip (up to the 512 positions of config_bert.json): chunked launches merged
+    by log-sum-exp in forward, two-pass D in backward, against the fp32 reference arithmetic (<= 256: the single-launch kernels)."""
     H = nH * 64
     qkv, kv, _ = _attn_inputs(nseq, nH, Lq, Lkv, seed=60)
     g = torch.Generator().manual_seed(61)
@@ -600,6 +605,36 @@ def test_attention_long_sequences_by_chunks(ops, nseq, nH, Lq, Lkv, causal_from,
     ops.attn_bwd_long(Q, K, V, O, lse, dO, dQ, dK, dV, **kw)
     ro.backward(dO.float().view(nseq, Lq, H))
     for got, ref, nm in ((dQ, q.grad, "dQ"), (dK, k.grad, "dK"), (dV, v.grad, "dV")):
+        ref2 = ref.reshape(got.shape)
+        close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
+
+
+@pytest.mark.parametrize("L", [96, 256])
+def test_attention_causal_rows_with_key0_masked(ops, L):
+    """Causal key tiles wholly above the diagonal are skipped only when key 0 is attended (then they hold exp(-10000 - ...) = 0
+    exactly).  With key 0 masked the reference's additive -10000 arithmetic runs over ALL keys -- a row whose visible keys are all
+    masked spreads over the future keys too -- and the kernels must reproduce that."""
+    nseq, nH = 3, 2
+    H = nH * 64
+    qkv = rnd(nseq * L, 3 * H, seed=70)
+    mask = torch.ones(nseq, L, dtype=torch.int32)
+    mask[1, 0] = 0; mask[2, :5] = 0; mask[2, L - 7:] = 0
+    mask = mask.cuda()
+    Q, K, V = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    dO = rnd(nseq * L, H, seed=71)
+    O = torch.zeros(nseq * L, H, dtype=BF, device="cuda"); lse = torch.zeros(nseq, nH, L, device="cuda")
+    kw = dict(nseq=nseq, nH=nH, Lq=L, Lkv=L, kmask=mask, causal_from=0)
+    ops.attn_fwd(Q, K, V, O, lse, **kw)
+    q = Q.float().reshape(nseq, L, H).requires_grad_(True)
+    k = K.float().reshape(nseq, L, H).requires_grad_(True)
+    v = V.float().reshape(nseq, L, H).requires_grad_(True)
+    ro, rl = ref_attention(q, k, v, mask, nH, 0, False)
+    close(lse, rl.detach(), 2e-3, 1e-4, "lse")
+    close(O.view(nseq, L, H), ro.detach(), 1.5e-2, 1e-2, "attention out")
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(Q, K, V, O, lse, dO, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], **kw)
+    ro.backward(dO.float().view(nseq, L, H))
+    for got, ref, nm in ((dqkv[:, :H], q.grad, "dQ"), (dqkv[:, H:2 * H], k.grad, "dK"), (dqkv[:, 2 * H:], v.grad, "dV")):
         ref2 = ref.reshape(got.shape)
         close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
 
@@ -630,18 +665,28 @@ def test_attention_backward_near_constant_values(ops):
         assert rel < 2e-2, (nm, rel, ref.norm().item())
 
 
-def test_attention_dropout_consistency(ops):
-    """Recover the dropout mask from a forward with V = identity, then check fwd/bwd against torch using THAT mask."""
-    nseq, nH, Lq, Lkv, p = 3, 2, 54, 64, 0.1
+@pytest.mark.parametrize("Lq,Lkv", [(54, 64), (200, 256)])
+def test_attention_dropout_consistency(ops, Lq, Lkv):
+    """Recover the dropout mask from forwards with V = a shifted identity (64 keys per pass), then check fwd/bwd against torch using
+    THAT mask."""
+    nseq, nH, p = 3, 2, 0.1
     H = nH * 64
     Q, K = rnd(nseq * Lq, H, seed=40), rnd(nseq * Lkv, H, seed=41)
-    eye = torch.eye(64, dtype=BF, device="cuda").repeat(nseq, nH)          # V[kv][d] = [kv == d] per head
     seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
     O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
     lse = torch.zeros(nseq, nH, Lq, device="cuda")
     kw = dict(nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, dropout_p=p, seed=seed, salt=99)
-    ops.attn_fwd(Q, K, eye, O, lse, **kw)
-    pd = O.float().view(nseq, Lq, nH, 64).permute(0, 2, 1, 3)              # = dropped probabilities
+
+    def dropped_probabilities():
+        parts = []
+        for off in range(0, Lkv, 64):                                      # V[kv][d] = [kv == off + d] per head
+            eye = torch.zeros(Lkv, 64, dtype=BF, device="cuda")
+            eye[off:off + 64] = torch.eye(64, dtype=BF, device="cuda")
+            ops.attn_fwd(Q, K, eye.repeat(nseq, nH), O, lse, **kw)
+            parts.append(O.float().view(nseq, Lq, nH, 64).permute(0, 2, 1, 3).clone())
+        return torch.cat(parts, dim=-1)                                    # [nseq, nH, Lq, Lkv]
+
+    pd = dropped_probabilities()
     keep = (pd != 0).float()
     rate = 1 - keep.mean().item()
     assert abs(rate - p) < 0.02, rate
@@ -659,9 +704,7 @@ def test_attention_dropout_consistency(ops):
         close(got, ref.reshape(got.shape), 4e-2, 2e-2, "dropout " + nm)
     # a different seed gives a different mask
     seed.fill_(7654321)
-    O2 = torch.zeros_like(O)
-    ops.attn_fwd(Q, K, eye, O2, lse, **kw)
-    assert ((O2.float() != 0) != (pd.permute(0, 2, 1, 3).reshape(nseq * Lq, H) != 0)).float().mean().item() > 0.05
+    assert ((dropped_probabilities() != 0) != (pd != 0)).float().mean().item() > 0.05
 
 
 def _host_dropout_keep(seed, salt, rows, ncols, p):

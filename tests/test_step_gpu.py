@@ -26,6 +26,8 @@ LOSS_ATOL = {
                                                         # 9.3e-4 / 1.13e-3 (bf16 stream, same run: 5.5e-4 / 1.0e-2 / 3.8e-3 / 1.8e-3): MLM and ITA meet north_star's 1e-3
     "edge_shapes":   [1e-3, 3e-3, 3.1e-3, 2.3e-3],      # worst over the five cases: 4.4e-4 / 1.9e-3 / 2.1e-3 / 1.5e-3
     "lt160":         [1e-3, 1.3e-3, 4.4e-3, 1e-3],      # measured 2.0e-4 / 8.6e-4 / 2.9e-3 / 1.2e-4
+    "lt300":         [1e-3, 1.3e-3, 4.4e-3, 1e-3],      # (chunked attention path, > 256 tokens)
+    "lt256_h768":    [1e-3, 1e-3, 1e-3, 1e-3],          # measured 5.2e-5 / 3.8e-4 / 6.5e-4 / 6.2e-4: BASELINE configs[4]'s sequence length at the published widths, 2+2 layers, packed rows
     "wide_golden":   [1e-3, 4.4e-3, 2e-2, 7.7e-3],      # measured 5.4e-4 / 2.9e-3 / 1.33e-2 / 5.1e-3 (closed-form weights ~0.08: sims up to 40)
     "grad_tiny":     [1e-3, 2.9e-3, 1.3e-3, 1e-3],      # measured 2.5e-4 / 1.9e-3 / 8.2e-4 / 4.0e-4
 }
@@ -995,15 +997,16 @@ def test_edge_shapes_match_oracle(env, case):
     assert_losses(got, ref, "edge_shapes", case)
 
 
-def test_long_sequences_forward_backward_match_oracle(env):
-    """Lt = 160 > 128: the dense step with chunked attention (forward merge by log-sum-exp, two-pass D in backward) vs the
-    oracle's losses, and the gradient norm vs the oracle's autograd."""
+@pytest.mark.parametrize("Lt", [160, 300])
+def test_long_sequences_forward_backward_match_oracle(env, Lt):
+    """Lt = 160: the attention kernels' 128 < L <= 256 forms (packed rows); Lt = 300 > 256: the dense step with chunked attention
+    (forward merge by log-sum-exp, two-pass D in backward) vs the oracle's losses, and the gradient norm vs the oracle's autograd."""
     O, SPMM, tiny_config, *_ = env
     ocfg, cfg = O.tiny_cfg(), tiny_config()
     for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
         c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
     sd = O.closed_form_state_dict(ocfg)
-    B, Lt = 4, 160
+    B = 4
     prop, ids, mask = O.synthetic_batch(B, Lt, seed=31)
     mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(6))
     neg = (torch.arange(B).roll(1), torch.arange(B).roll(3))
@@ -1020,9 +1023,45 @@ def test_long_sequences_forward_backward_match_oracle(env):
     ref = np.array([float(x) for x in ref_l])
     gn_ref = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
     gn = m.store.grad.double().norm().item()
-    print("Lt=160 hip", got, "oracle", ref, "grad norm", gn, gn_ref)
-    assert_losses(got, ref, "lt160")
+    print(f"Lt={Lt} hip", got, "oracle", ref, "diff", np.abs(got - ref), "grad norm", gn, gn_ref)
+    assert_losses(got, ref, f"lt{Lt}")
     assert abs(gn - gn_ref) / gn_ref < 2e-3                 # measured 4e-4
+
+
+def test_seq_len_256_step_matches_oracle_at_published_widths(env):
+    """BASELINE configs[4]'s sequence length (Lt = 256) at H = 768 / 12 heads, 2 text layers (1 fusion) + 2 PV layers, B = 8, ragged
+    lengths, packed rows (the default schedule), dropout off: four losses and the whole gradient against the fp32 oracle."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env)
+    for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.init_state_dict(ocfg, seed=4)
+    B, Lt = 8, 256
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=41)
+    assert int(mask.sum(1).max()) == Lt and int(mask.sum(1).min()) < Lt
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(8))
+    neg = (torch.arange(B).roll(3), torch.arange(B).roll(5))
+    m = _mk(SPMM, cfg, sd).train()
+    assert m.engine.pack_text
+    losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+    sum(losses).backward()
+    got = np.array([float(x) for x in losses])
+    names = O.trainable_names(ocfg)
+    for n in names:
+        sd[n].requires_grad_(True)
+    O._finish_tied(sd)
+    ref_l = O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, train=True)
+    sum(ref_l).backward()
+    ref = np.array([float(x) for x in ref_l])
+    total_r = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
+    err2 = 0.0
+    for n in names:
+        if sd[n].grad is not None:
+            err2 += (m.store.g(n).detach().cpu().reshape(sd[n].grad.shape) - sd[n].grad).norm().item() ** 2
+    glob = err2 ** 0.5 / total_r
+    print("Lt=256 H=768 hip", got, "oracle", ref, "diff", np.abs(got - ref), f"whole gradient |g|={total_r:.4f} relative L2 error {glob:.5f}")
+    assert_losses(got, ref, "lt256_h768")
+    assert glob < 1.5e-2
 
 
 def test_wide_model_matches_reference_golden(env, golden_dir):
