@@ -374,6 +374,9 @@ def main():
     spread = {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
               "p90": round(per_step[int(0.9 * (len(per_step) - 1) + 0.5)], 3), "note": "GPU-side interval between consecutive steps' last kernels (this rank)"}
     final_losses = [float(x) for x in losses.cpu()]
+    mst = torch.cuda.memory_stats(dev)
+    hbm = {"peak_allocated_gb": round(mst.get("allocated_bytes.all.peak", 0) / 2**30, 2), "peak_reserved_gb": round(mst.get("reserved_bytes.all.peak", 0) / 2**30, 2),
+           "alloc_retries": int(mst.get("num_alloc_retries", 0)), "device_mallocs": int(mst.get("segment.all.allocated", 0))}
 
     # ---- per-kernel timing with HIP events on the launch stream: same step, every GEMM / cross-attention launch bracketed.
     roof, xattn = None, None
@@ -522,14 +525,14 @@ def main():
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}", "schedule": "one hipGraph replay per step, dense text layout" if args.graph else
-                      ("eager launches on three HIP streams, packed text rows" + ("" if sync is None else
+                      (("eager launches on one HIP stream" if getattr(model.engine, "_one_stream", False) else "eager launches on three HIP streams") + ", packed text rows" + ("" if sync is None else
                        "; per-layer gradient exchange overlapped with the backward, weight gradients on the backward's stream meanwhile"))},
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
-                                         - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= 128 else 0.0)) / 1e12, 2),
+                                         - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= ops.ATTN_MAXL else 0.0)) / 1e12, 2),
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
-           "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses}
+           "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses, "hbm": hbm}
     from spmm_amd import streams
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks

@@ -87,12 +87,6 @@ int spmm_gemm_tn_chain(const void* A, long lda, const void* B, long ldb, int M, 
                        long ldc, float* workspace, const float* prev_ws, int prev_ns, int prev_N, int prev_K, float* prev_C,
                        long prev_ldc, int* ns_out, int kernel, spmm_stream_t stream);
 int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream);
-/* All the weight-gradient problems of a layer (up to 8) in ONE launch + one slab reduction: C_i[N_i,K_i] += alpha * A_i[M_i,N_i]^T B_i[M_i,K_i].
- * Arrays of n entries; a problem is eligible when spmm_gemm_tn_group_ok says so; workspace: spmm_gemm_tn_group_workspace(...) floats. */
-int spmm_gemm_tn_group_ok(int M, int N, int K);
-long spmm_gemm_tn_group_workspace(int n, const int* M, const int* N, const int* K);
-int spmm_gemm_tn_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, const int* M, const int* N,
-                       const int* K, float* const* C, const long* ldc, float alpha, float* workspace, spmm_stream_t stream);
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 256 (one workgroup holds the K/V

@@ -272,13 +272,44 @@ def _finish_aliases(sd: SD, cfg: SPMMCfg) -> None:
         sd[p + "cls.predictions.decoder.bias"] = sd[p + "cls.predictions.bias"]
 
 
+# ------------------------------------------------------------------------ bf16 storage model
+# `with bf16_storage():` makes the oracle round its tensors to bfloat16 at exactly the points where the HIP product STORES bf16
+# (spmm_amd/engine.py, default options): GEMM weights (the bf16 shadows) and every GEMM / LayerNorm / attention output written to
+# HBM, the un-normalised softmax numerators that feed the second attention MFMA.  Everything else stays as in the fp32 oracle:
+# accumulation, biases, LayerNorm statistics and affine parameters, softmax sums, the loss heads' arithmetic.  It is the yard-stick
+# that separates "deviation caused by bf16 storage" (shared by this model and the product) from "kernel error" (what is left
+# between them): tests/test_step_gpu.py::test_losses_match_the_bf16_storage_model_of_the_oracle.  Forward only, dropout off.
+_BF16_STORAGE = False
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _BF16_STORAGE
+        self._old, _BF16_STORAGE = _BF16_STORAGE, True
+
+    def __exit__(self, *exc):
+        global _BF16_STORAGE
+        _BF16_STORAGE = self._old
+
+
+def _st(x: Tensor) -> Tensor:
+    """A tensor as the product holds it in HBM."""
+    return x.to(torch.bfloat16).to(torch.float32) if _BF16_STORAGE else x
+
+
 # ------------------------------------------------------------------------ xbert.py
-def _lin(sd: SD, p: str, x: Tensor) -> Tensor:
-    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+def _lin(sd: SD, p: str, x: Tensor, act=None, f32_out: bool = False, f32_w: bool = False) -> Tensor:
+    """nn.Linear (+ fused activation).  bf16 storage model: bf16 weight shadow unless `f32_w` (the small loss heads read the fp32
+    master), fp32 accumulation + bias + activation, bf16 output unless `f32_out` (logits, feature projections, head outputs)."""
+    w = sd[p + ".weight"]
+    y = F.linear(x, w if f32_w else _st(w), sd[p + ".bias"])
+    if act is not None:
+        y = act(y)
+    return y if f32_out else _st(y)
 
 
 def _ln(sd: SD, p: str, x: Tensor, eps: float) -> Tensor:
-    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+    return _st(F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps))
 
 
 def _drop(x: Tensor, p: float, train: bool) -> Tensor:
@@ -327,8 +358,14 @@ def attention(sd: SD, p: str, c: BertCfg, hidden: Tensor, add_mask: Tensor,
     k = _lin(sd, p + ".self.key", kv_src).view(B, -1, nh, d).permute(0, 2, 1, 3)
     v = _lin(sd, p + ".self.value", kv_src).view(B, -1, nh, d).permute(0, 2, 1, 3)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + add_mask
-    pr = _drop(torch.softmax(s, dim=-1), c.attention_probs_dropout_prob, train)
-    ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
+    if _BF16_STORAGE:
+        # csrc/attention.hip: e = exp(s - max) in fp32, row sum of the UNROUNDED e, e rounded to bf16 as the MFMA operand,
+        # context = (e_bf16 . V) / sum rounded to bf16
+        e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+        ctx = _st(torch.matmul(_st(e), v) / e.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, L, H)
+    else:
+        pr = _drop(torch.softmax(s, dim=-1), c.attention_probs_dropout_prob, train)
+        ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
     out = _drop(_lin(sd, p + ".output.dense", ctx), c.hidden_dropout_prob, train)
     return _ln(sd, p + ".output.LayerNorm", out + hidden, c.layer_norm_eps)
 
@@ -341,7 +378,7 @@ def bert_layer(sd: SD, p: str, c: BertCfg, i: int, has_cross: bool, hidden, self
     if has_cross and i >= c.fusion_layer:
         assert enc is not None
         a = attention(sd, lp + "crossattention", c, a, enc_mask, enc, train)
-    h = F.gelu(_lin(sd, lp + "intermediate.dense", a))                       # :434-437 erf GELU
+    h = _lin(sd, lp + "intermediate.dense", a, act=F.gelu)                   # :434-437 erf GELU
     o = _drop(_lin(sd, lp + "output.dense", h), c.hidden_dropout_prob, train)  # :447-451
     return _ln(sd, lp + "output.LayerNorm", o + a, c.layer_norm_eps)
 
@@ -372,9 +409,9 @@ def bert_model(sd: SD, p: str, c: BertCfg, has_cross: bool, *, input_ids=None, i
 
 def mlm_head(sd: SD, p: str, c: BertCfg, x: Tensor) -> Tensor:
     """BertOnlyMLMHead xbert.py:662-706: decoder(LN(gelu(dense(x)))) + bias, decoder tied."""
-    h = F.gelu(_lin(sd, p + "cls.predictions.transform.dense", x))
+    h = _lin(sd, p + "cls.predictions.transform.dense", x, act=F.gelu)
     h = _ln(sd, p + "cls.predictions.transform.LayerNorm", h, c.layer_norm_eps)
-    return F.linear(h, sd[p + "cls.predictions.decoder.weight"], sd[p + "cls.predictions.bias"])
+    return F.linear(h, _st(sd[p + "cls.predictions.decoder.weight"]), sd[p + "cls.predictions.bias"])
 
 
 # ------------------------------------------------------------------ SPMM_models.py
@@ -444,19 +481,19 @@ def spmm_forward(sd: SD, cfg: SPMMCfg, property_original: Tensor, text_input_ids
     # ---- unimodal encoders :90-95
     prop_embeds = bert_model(sd, "property_encoder.", pc, False, inputs_embeds=properties, train=train)
     prop_atts = torch.ones(prop_embeds.shape[:2], dtype=torch.long)
-    prop_feat = F.normalize(_lin(sd, "property_proj", prop_embeds[:, 0, :]), dim=-1)
+    prop_feat = F.normalize(_lin(sd, "property_proj", prop_embeds[:, 0, :], f32_out=True), dim=-1)
     text_embeds = bert_model(sd, "text_encoder.bert.", tc, True, input_ids=text_input_ids,
                              attention_mask=text_attention_mask, mode="text", train=train)
-    text_feat = F.normalize(_lin(sd, "text_proj", text_embeds[:, 0, :]), dim=-1)
+    text_feat = F.normalize(_lin(sd, "text_proj", text_embeds[:, 0, :], f32_out=True), dim=-1)
     # ---- momentum branch :98-119
     with torch.no_grad():
         momentum_update(sd, cfg)
         prop_embeds_m = bert_model(sd, "property_encoder_m.", pc, False, inputs_embeds=properties, train=train)
-        prop_feat_m = F.normalize(_lin(sd, "property_proj_m", prop_embeds_m[:, 0, :]), dim=-1)
+        prop_feat_m = F.normalize(_lin(sd, "property_proj_m", prop_embeds_m[:, 0, :], f32_out=True), dim=-1)
         prop_feat_all = torch.cat([prop_feat_m.t(), sd["prop_queue"].clone()], dim=1)
         text_embeds_m = bert_model(sd, "text_encoder_m.bert.", tc, True, input_ids=text_input_ids,
                                    attention_mask=text_attention_mask, mode="text", train=train)
-        text_feat_m = F.normalize(_lin(sd, "text_proj_m", text_embeds_m[:, 0, :]), dim=-1)
+        text_feat_m = F.normalize(_lin(sd, "text_proj_m", text_embeds_m[:, 0, :], f32_out=True), dim=-1)
         text_feat_all = torch.cat([text_feat_m.t(), sd["text_queue"].clone()], dim=1)
         sim_i2t_m = prop_feat_m @ text_feat_all / temp
         sim_t2i_m = text_feat_m @ prop_feat_all / temp
@@ -511,7 +548,7 @@ def spmm_forward(sd: SD, cfg: SPMMCfg, property_original: Tensor, text_input_ids
                               enc=prop_embeds_all, enc_mask=prop_atts_all, **fus)[:, 0, :]
     pos_neg = torch.cat([pos_neg_prop, pos_neg_text], dim=-1)
     vl = torch.cat([pos_pos, pos_neg], dim=0)
-    vl_output = _lin(sd, "itm_head", vl)
+    vl_output = _lin(sd, "itm_head", vl, f32_out=True, f32_w=True)
     itm_labels = torch.cat([torch.ones(B, dtype=torch.long), torch.zeros(2 * B, dtype=torch.long)])
     loss_itm = F.cross_entropy(vl_output, itm_labels)
     # ---- queue :208
@@ -538,10 +575,10 @@ def spmm_forward(sd: SD, cfg: SPMMCfg, property_original: Tensor, text_input_ids
     prop_output = bert_model(sd, "text_encoder.bert.", tc, encoder_embeds=prop_embeds_causal,
                              attention_mask=prop_atts, enc=text_embeds, enc_mask=text_attention_mask,
                              is_decoder=True, **fus)[:, :-1, :]
-    h = F.gelu(_lin(sd, "property_mtr_head.0", prop_output))
-    h = F.layer_norm(h, (h.shape[-1],), sd["property_mtr_head.2.weight"], sd["property_mtr_head.2.bias"],
-                     tc.layer_norm_eps)
-    pred = _lin(sd, "property_mtr_head.3", h).squeeze(-1)
+    h = _lin(sd, "property_mtr_head.0", prop_output, act=F.gelu)
+    h = _st(F.layer_norm(h, (h.shape[-1],), sd["property_mtr_head.2.weight"], sd["property_mtr_head.2.bias"],
+                         tc.layer_norm_eps))
+    pred = _lin(sd, "property_mtr_head.3", h, f32_out=True, f32_w=True).squeeze(-1)
     keep = (1 - mpm_mask).to(torch.bool)
     loss_mpm = F.mse_loss(pred[keep], property_original[keep])
     if aux is not None:

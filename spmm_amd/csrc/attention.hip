@@ -217,7 +217,7 @@ __host__ __device__ constexpr int bwd_xrow(int nt_kv) { return nt_kv <= 4 ? 256 
 __host__ __device__ constexpr int bwd_xbytes(int nt_kv, int nt_q) {
   return 2 * nt_kv * 32 * 128 > nt_q * 32 * bwd_xrow(nt_kv) ? 2 * nt_kv * 32 * 128 : nt_q * 32 * bwd_xrow(nt_kv);
 }
-constexpr int BWD_LDS = bwd_xbytes(8, 4) + 2 * TILE + (256 + 128) * 4;
+constexpr int BWD_LDS = bwd_xbytes(8, 4) + 2 * TILE + (256 + 128 + 256) * 4 + 4 * 32 * 64 * 4;
 
 // [q][kv] bf16 tile, RB-byte rows, 8-B slots (4 consecutive kv).  Slot index XOR ((q & 3) << 3 | ((q >> 2) & 3) << 1):
 //  * the 16 lanes of a write group (16 consecutive q, one slot) land on 16 distinct slots;
@@ -245,12 +245,18 @@ __device__ __forceinline__ float up_hi(uint32_t w) { return __builtin_bit_cast(f
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // NT <= 4: four waves, wave w owns query tile w against all keys.  NT > 4 (SPLIT): eight waves, wave (qw, hv) owns query tile qw
+  // against key tiles 4 hv .. 4 hv + 3 -- the register footprint of the four-tile form, two waves per SIMD -- and the two halves of a
+  // row exchange their partial D = sum P dP and their partial dQ through LDS.
+  constexpr bool SPLIT = NT > 4;
+  constexpr int TH = SPLIT ? 512 : 256;
+  constexpr int NTL = SPLIT ? 4 : NT;                // key tiles held by one wave in phase A
   constexpr int RB = bwd_xrow(NT);
-  constexpr int KI = (NT + 3) / 4;                   // key tiles per wave in phase B
   const int h = blockIdx.x, seq = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int qw = wave & 3, hv = SPLIT ? wave >> 2 : 0;
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
   const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
   const int qc0 = p.qc0, nq = Lq - qc0 < 128 ? Lq - qc0 : 128;   // this launch's query rows of the sequence: [qc0, qc0 + nq)
@@ -265,6 +271,8 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_k
   char* dOs = Qs + qb;
   float* mb = (float*)(dOs + qb);
   float* lse = mb + NT * 32;
+  float* dpart = lse + 128;                          // SPLIT: [2][128] partial D of the two key halves
+  float* EX = dpart + 256;                           // SPLIT: [4 query tiles][32 registers][64 lanes] partial dQ of the upper key half
   const long qrow = (p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq) + qc0;
   const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
   const long dkvrow = p.kv_seq ? (long)seq * p.Lkv : kvrow;     // shared sources: dK/dV per query sequence, dense
@@ -273,15 +281,15 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_k
   const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
   const bf16* dOg = p.dO + qrow * p.lddo + h * HD;
   const int qrows = ((nq + 31) >> 5) * 32;
-  stage_head(Kg, p.ldk, Lkv, Ks, tid, 256, NT * 32);
-  stage_head(Vg, p.ldv, Lkv, Vs, tid, 256, NT * 32);
-  stage_head(Qg, p.ldq, nq, Qs, tid, 256, qrows);
-  stage_head(dOg, p.lddo, nq, dOs, tid, 256, qrows);
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, TH, NT * 32);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, TH, NT * 32);
+  stage_head(Qg, p.ldq, nq, Qs, tid, TH, qrows);
+  stage_head(dOg, p.lddo, nq, dOs, tid, TH, qrows);
   {
     // additive score bias per key as in the forward: 0 (attend), mask_neg (masked), -inf (tile padding past Lkv: P = 0 exactly);
     // query rows past the chunk get lse = +inf, i.e. P = exp(s - inf) = 0, so neither needs a per-element test below
     const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);     // (units of log2, as in the forward)
-    for (int j = tid; j < NT * 32; j += 256)
+    for (int j = tid; j < NT * 32; j += TH)
       mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
     if (tid < 128) lse[tid] = tid < nq ? p.LSE[((long)seq * p.nH + h) * p.Lq + qc0 + tid] * LOG2E : INFINITY;
   }
@@ -298,15 +306,22 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_k
   const bool skip_ok = causal && p.q_off == 0 && p.kv_off == 0 && p.d_mode == 0 && __builtin_amdgcn_readfirstlane((int)(mb[0] == 0.f));
   const int qt0 = qc0 >> 5;                            // global index of the chunk's first query tile
 
-  // ---- phase A: wave owns query tile `wave`: ONE pass over the scores gives D[q] = sum_kv P dP (fp32, exactly consistent with
-  // ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and dS = P (dP - D).
+  // ---- phase A: a wave owns query tile `qw` (and, SPLIT, one half of the keys): ONE pass over the scores gives D[q] = sum_kv P dP
+  // (fp32, exactly consistent with ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and
+  // dS = P (dP - D).
   // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
   // ds = P (dP - D) is a small difference of large numbers that such a D would swamp.
-  uint32_t ppk[NT][8], dpk[NT][8];                   // packed bf16 pairs: registers (2i, 2i+1) of tile t
-  const int ql = wave * 32 + (lane & 31);            // row inside the chunk
+  uint32_t ppk[NTL][8], dpk[NTL][8];                 // packed bf16 pairs: registers (2i, 2i+1) of local tile tl
+  f32x16 dp[NTL];
+  uint32_t keepbits[NTL];
+  const int ql = qw * 32 + (lane & 31);              // row inside the chunk
   const int q = qc0 + ql;                            // row inside the sequence
-  const int tlast = skip_ok ? qt0 + wave : NT - 1;   // last key tile this wave's rows can see
-  if (wave < NTq) {
+  const int t0 = hv * 4;                             // first key tile of this wave
+  const int tlast = skip_ok ? qt0 + qw : NT - 1;     // last key tile this wave's rows can see
+  const int ntl = NT - t0 < NTL ? NT - t0 : NTL;     // local tiles that exist
+  const bool act = qw < NTq;
+  float dloc = 0.f;
+  if (act) {
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -316,33 +331,32 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_k
     const float lq = lse[ql];
     const int qpos = q + p.q_off - p.kv_off;           // causal: key kv is visible iff kv <= qpos
     const float neg2c = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
-    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) + (uint32_t)(2 * g) * DROP_WEYL : 0u;
-    f32x16 dp[NT];
-    uint32_t keepbits[NT];
-    float dloc = 0.f;
+    // (the pair index of key tile t0 + tl is a literal plus hv * 64: the wave's part goes into the row key like the lane's 2g)
+    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + q) + (uint32_t)(2 * g + 64 * hv) * DROP_WEYL : 0u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t > tlast) continue;                         // (wave-uniform) nothing of this tile is visible: P = dS = 0, never stored
+    for (int tl = 0; tl < NTL; ++tl) {
+      const int t = t0 + tl;
+      if (tl >= ntl || t > tlast) continue;            // (wave-uniform) no such tile / nothing of it is visible: P = dS = 0, never stored
       f32x16 st = zero16();
-      dp[t] = zero16();
+      dp[tl] = zero16();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         st = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st);
-        dp[t] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[t]);
+        dp[tl] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[tl]);
       }
       uint32_t kb = 0xffffu;                           // bit r: probability (q, kv(r)) survived dropout in forward
       if (drop) {
         kb = 0;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const uint32_t r0 = drop_pair(rowkey, t * 16 + 4 * gq), r1 = drop_pair(rowkey, t * 16 + 4 * gq + 1);   // (the lane's 2g is inside rowkey)
+          const uint32_t r0 = drop_pair(rowkey, tl * 16 + 4 * gq), r1 = drop_pair(rowkey, tl * 16 + 4 * gq + 1);   // (2g and 64 hv are inside rowkey)
           kb |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
           kb |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
           kb |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);
           kb |= ((r1 >> 16) >= p.drop_thresh16 ? 8u : 0u) << (gq * 4);
         }
       }
-      keepbits[t] = kb;
+      keepbits[tl] = kb;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3: the 4 consecutive keys t*32 + 8*gq + 4*g + {0..3}
         const int kv0 = t * 32 + 8 * gq + 4 * g;
@@ -357,168 +371,183 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : NT <= 4 ? 2 : 1) void attn_bwd_k
         for (int j = 0; j < 4; ++j) {
           const int r = gq * 4 + j;
           const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], 0.125f * LOG2E, b[j]));
-          float dpr = dp[t][r];
+          float dpr = dp[tl][r];
           // dropout: dP is only MASKED here (bit r of kb, sign-extended to an all-ones word); the factor 1 / (1 - p) is linear in
           // everything downstream (D, dS, P~) and is applied once to the dQ / dK / dV accumulators at their stores
           if (drop) dpr = __builtin_bit_cast(float, __builtin_bit_cast(int, dpr) & __builtin_amdgcn_sbfe((int)kb, r, 1));
           st[r] = pr;
-          dp[t][r] = dpr;
+          dp[tl][r] = dpr;
           dloc += pr * dpr;
         }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ppk[t][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
+      for (int i = 0; i < 8; ++i) ppk[tl][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
     }
     dloc += __shfl_xor(dloc, 32, 64);
-    if (p.d_mode == 1) {
+    if (SPLIT) {
+      if (g == 0) dpart[hv * 128 + ql] = dloc;
+    } else if (p.d_mode == 1) {
       if (g == 0 && q < Lq) p.Dbuf[headbase + q] = dloc;
     } else if (p.d_mode == 2) {
       dloc = q < Lq ? p.Dbuf[headbase + q] : 0.f;
     }
-    if (p.d_mode != 1) {
-      f32x16 dq[2] = {zero16(), zero16()};
+  }
+  if (!SPLIT && p.d_mode == 1) return;   // partial-D pass: nothing else is written
+  if (SPLIT) {
+    __syncthreads();                     // both key halves of every row have left their partial D
+    if (act) dloc = dpart[ql] + dpart[128 + ql];
+  }
+  f32x16 dq[2] = {zero16(), zero16()};
+  if (act) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t > tlast) continue;
-        const uint32_t kb = keepbits[t];
+    for (int tl = 0; tl < NTL; ++tl) {
+      const int t = t0 + tl;
+      if (tl >= ntl || t > tlast) continue;
+      const uint32_t kb = keepbits[tl];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float p0 = up_lo(ppk[t][i]), p1 = up_hi(ppk[t][i]);
-          dpk[t][i] = pk2(p0 * (dp[t][2 * i] - dloc), p1 * (dp[t][2 * i + 1] - dloc));
-          if (drop)                                     // P~ = P masked (the packed bf16 pair AND a per-half all-ones / zero word)
-            ppk[t][i] &= ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i, 1) & 0xffffu) |
-                         ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i + 1, 1) & 0xffff0000u);
-        }
-        {
-          const u32x4 w0 = {dpk[t][0], dpk[t][1], dpk[t][2], dpk[t][3]}, w1 = {dpk[t][4], dpk[t][5], dpk[t][6], dpk[t][7]};
-          const bf16x8 ds0 = __builtin_bit_cast(bf16x8, w0), ds1 = __builtin_bit_cast(bf16x8, w1);
-          bf16x8 kf0[2], kf1[2];
-          ld_tr2x2(Ks, t * 32, lane, kf0, kf1);
-          dq[0] = MFMA32(kf0[0], ds0, dq[0]);
-          dq[1] = MFMA32(kf0[1], ds0, dq[1]);
-          dq[0] = MFMA32(kf1[0], ds1, dq[0]);
-          dq[1] = MFMA32(kf1[1], ds1, dq[1]);
-        }
+      for (int i = 0; i < 8; ++i) {
+        const float p0 = up_lo(ppk[tl][i]), p1 = up_hi(ppk[tl][i]);
+        dpk[tl][i] = pk2(p0 * (dp[tl][2 * i] - dloc), p1 * (dp[tl][2 * i + 1] - dloc));
+        if (drop)                                     // P~ = P masked (the packed bf16 pair AND a per-half all-ones / zero word)
+          ppk[tl][i] &= ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i, 1) & 0xffffu) |
+                        ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i + 1, 1) & 0xffff0000u);
       }
       {
-        // No LDS is free here (Q and dO are read again in phase B), so the 8-byte pieces are widened in registers instead: lanes l
-        // and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands lane l the other half of the
-        // EVEN chunks and lane l + 32 the other half of the ODD ones: four 16-byte stores per lane instead of eight 8-byte ones.
-        bf16* dQg = p.dQ + (qrow + ql) * p.lddq + h * HD + 8 * g;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int e = (2 * j) * 4, o = (2 * j + 1) * 4;
-            uint32_t e0 = pk2(dq[dt][e] * qsc, dq[dt][e + 1] * qsc), e1 = pk2(dq[dt][e + 2] * qsc, dq[dt][e + 3] * qsc);
-            uint32_t o0 = pk2(dq[dt][o] * qsc, dq[dt][o + 1] * qsc), o1 = pk2(dq[dt][o + 2] * qsc, dq[dt][o + 3] * qsc);
-            const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-            if (q < Lq) *(u32x4*)(dQg + dt * 32 + 16 * j) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-          }
+        const u32x4 w0 = {dpk[tl][0], dpk[tl][1], dpk[tl][2], dpk[tl][3]}, w1 = {dpk[tl][4], dpk[tl][5], dpk[tl][6], dpk[tl][7]};
+        const bf16x8 ds0 = __builtin_bit_cast(bf16x8, w0), ds1 = __builtin_bit_cast(bf16x8, w1);
+        bf16x8 kf0[2], kf1[2];
+        ld_tr2x2(Ks, t * 32, lane, kf0, kf1);
+        dq[0] = MFMA32(kf0[0], ds0, dq[0]);
+        dq[1] = MFMA32(kf0[1], ds0, dq[1]);
+        dq[0] = MFMA32(kf1[0], ds1, dq[0]);
+        dq[1] = MFMA32(kf1[1], ds1, dq[1]);
       }
     }
   }
-  if (p.d_mode == 1) return;   // partial-D pass: nothing else is written
+  // dQ leaves from registers.  No LDS is free at this point of the four-wave form (Q and dO are read again in phase B), so the 8-byte
+  // pieces are widened in registers: lanes l and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands
+  // lane l the other half of the EVEN chunks and lane l + 32 the other half of the ODD ones: four 16-byte stores per lane instead of
+  // eight 8-byte ones.  (SPLIT: the lower key half's wave stores, after adding the upper half's partial sums from LDS -- below.)
+  auto store_dq = [&]() {
+    bf16* dQg = p.dQ + (qrow + ql) * p.lddq + h * HD + 8 * g;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = (2 * j) * 4, o = (2 * j + 1) * 4;
+        uint32_t e0 = pk2(dq[dt][e] * qsc, dq[dt][e + 1] * qsc), e1 = pk2(dq[dt][e + 2] * qsc, dq[dt][e + 3] * qsc);
+        uint32_t o0 = pk2(dq[dt][o] * qsc, dq[dt][o + 1] * qsc), o1 = pk2(dq[dt][o + 2] * qsc, dq[dt][o + 3] * qsc);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+        if (q < Lq) *(u32x4*)(dQg + dt * 32 + 16 * j) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+  };
+  if (!SPLIT && act) store_dq();
 
-  // ---- phase B: wave owns kv tiles `wave`, `wave + 4`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
+  // ---- phase B: a wave owns key tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
   // (a (query tile, key tile) pair above the causal diagonal holds zeros -- or, for key tiles past tlast, was never written -- and is
   // skipped: pair (qt, kt) is live iff kt <= qt0 + qt)
   __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
-  if (wave < NTq) {
+  if (act) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t <= tlast) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{ppk[t][2 * gq], ppk[t][2 * gq + 1]};
-        }
-      }
-  }
-  __syncthreads();
-  f32x16 dk[KI][2], dv[KI][2];
-#pragma unroll
-  for (int ki = 0; ki < KI; ++ki) {
-    dk[ki][0] = zero16(); dk[ki][1] = zero16(); dv[ki][0] = zero16(); dv[ki][1] = zero16();
-    const int kt = wave + 4 * ki;
-    if (kt < NT) {
-      for (int qt = skip_ok && kt > qt0 ? kt - qt0 : 0; qt < NTq; ++qt)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const bf16x8 pf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
-          bf16x8 dof[2];
-          ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
-          dv[ki][0] = MFMA32(dof[0], pf, dv[ki][0]);
-          dv[ki][1] = MFMA32(dof[1], pf, dv[ki][1]);
-        }
-    }
-  }
-  __syncthreads();             // P~ consumed: region X becomes the dS tile
-  if (wave < NTq) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t <= tlast) {
+    for (int tl = 0; tl < NTL; ++tl) {
+      const int t = t0 + tl;
+      if (tl < ntl && t <= tlast) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{dpk[t][2 * gq], dpk[t][2 * gq + 1]};
+          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{ppk[tl][2 * gq], ppk[tl][2 * gq + 1]};
         }
       }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int ki = 0; ki < KI; ++ki) {
-    const int kt = wave + 4 * ki;
-    if (kt < NT) {
-      for (int qt = skip_ok && kt > qt0 ? kt - qt0 : 0; qt < NTq; ++qt)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const bf16x8 dsf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
-          bf16x8 qf[2];
-          ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
-          dk[ki][0] = MFMA32(qf[0], dsf, dk[ki][0]);
-          dk[ki][1] = MFMA32(qf[1], dsf, dk[ki][1]);
-        }
     }
-  }
-  // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
-  // once all waves are past their last read, and wave w transposes through bytes [8192 w, 8192 w + 8192) of region X (X >= 32 KiB
-  // whenever 4 waves hold tiles).  Launches for later query chunks add to what the earlier ones stored (p.acc_dkv).
-  __syncthreads();
-#pragma unroll
-  for (int ki = 0; ki < KI; ++ki) {
-    const int kt = wave + 4 * ki;
-    if (kt < NT) {
-      char* T = X + wave * 8192;
-      const int row = lane & 31;
+    if (SPLIT && hv == 1) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
+        for (int r = 0; r < 16; ++r) EX[(qw * 32 + dt * 16 + r) * 64 + lane] = dq[dt][r];
+    }
+  }
+  __syncthreads();
+  if (SPLIT && act && hv == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] += EX[(qw * 32 + dt * 16 + r) * 64 + lane];
+    store_dq();
+  }
+  const int kt = wave;
+  const int qtb = skip_ok && kt > qt0 ? kt - qt0 : 0;      // first query tile of the chunk that sees key tile kt
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  if (kt < NT) {
+    for (int qt = qtb; qt < NTq; ++qt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
+        bf16x8 dof[2];
+        ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
+        dv[0] = MFMA32(dof[0], pf, dv[0]);
+        dv[1] = MFMA32(dof[1], pf, dv[1]);
+      }
+  }
+  __syncthreads();             // P~ consumed: region X becomes the dS tile
+  if (act) {
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+      const int t = t0 + tl;
+      if (tl < ntl && t <= tlast) {
+#pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
-          *(bf16x4*)(T + off) = to_bf16x4(dk[ki][dt][gq * 4] * qsc, dk[ki][dt][gq * 4 + 1] * qsc, dk[ki][dt][gq * 4 + 2] * qsc, dk[ki][dt][gq * 4 + 3] * qsc);
-          *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[ki][dt][gq * 4] * dsc, dv[ki][dt][gq * 4 + 1] * dsc, dv[ki][dt][gq * 4 + 2] * dsc, dv[ki][dt][gq * 4 + 3] * dsc);
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          *(u32x2*)(X + xoff<RB>(ql, t * 8 + 2 * gq + g)) = u32x2{dpk[tl][2 * gq], dpk[tl][2 * gq + 1]};
         }
-      const int r8 = lane >> 3, c = lane & 7;
-      bf16* dKg = p.dK + (dkvrow + kt * 32 + r8) * p.lddk + h * HD + c * 8;
-      bf16* dVg = p.dV + (dkvrow + kt * 32 + r8) * p.lddv + h * HD + c * 8;
+      }
+    }
+  }
+  __syncthreads();
+  if (kt < NT) {
+    for (int qt = qtb; qt < NTq; ++qt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
-        u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
-        if (kt * 32 + r8 + 8 * i < Lkv) {
-          if (p.acc_dkv) {
-            const u32x4 ok = *(const u32x4*)(dKg + (long)(8 * i) * p.lddk), ov = *(const u32x4*)(dVg + (long)(8 * i) * p.lddv);
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 dsf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
+        bf16x8 qf[2];
+        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
+        dk[0] = MFMA32(qf[0], dsf, dk[0]);
+        dk[1] = MFMA32(qf[1], dsf, dk[1]);
+      }
+  }
+  // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
+  // once all waves are past their last read, and wave w transposes through bytes [8192 w, 8192 w + 8192) of region X (X >= 8 KiB per
+  // wave that holds a key tile).  Launches for later query chunks add to what the earlier ones stored (p.acc_dkv).
+  __syncthreads();
+  if (kt < NT) {
+    char* T = X + wave * 8192;
+    const int row = lane & 31;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              vk[e] = pk2(up_lo(vk[e]) + up_lo(ok[e]), up_hi(vk[e]) + up_hi(ok[e]));
-              vv[e] = pk2(up_lo(vv[e]) + up_lo(ov[e]), up_hi(vv[e]) + up_hi(ov[e]));
-            }
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
+        *(bf16x4*)(T + off) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
+        *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
+      }
+    const int r8 = lane >> 3, c = lane & 7;
+    bf16* dKg = p.dK + (dkvrow + kt * 32 + r8) * p.lddk + h * HD + c * 8;
+    bf16* dVg = p.dV + (dkvrow + kt * 32 + r8) * p.lddv + h * HD + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
+      u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
+      if (kt * 32 + r8 + 8 * i < Lkv) {
+        if (p.acc_dkv) {
+          const u32x4 ok = *(const u32x4*)(dKg + (long)(8 * i) * p.lddk), ov = *(const u32x4*)(dVg + (long)(8 * i) * p.lddv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vk[e] = pk2(up_lo(vk[e]) + up_lo(ok[e]), up_hi(vk[e]) + up_hi(ok[e]));
+            vv[e] = pk2(up_lo(vv[e]) + up_lo(ov[e]), up_hi(vv[e]) + up_hi(ov[e]));
           }
-          *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
-          *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
         }
+        *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
+        *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
       }
     }
   }
@@ -634,16 +663,17 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   for (int qc0 = 0; qc0 < Lq; qc0 += 128) {
     p.qc0 = qc0; p.acc_dkv = qc0 > 0;
     const int ntq = Lq - qc0 >= 128 ? 4 : (Lq - qc0 + 31) / 32;
-    const size_t lds_b = (size_t)bwd_xbytes(nt, ntq) + (size_t)2 * ntq * 32 * 128 + (size_t)(nt * 32 + 128) * 4;
+    const size_t lds_b = (size_t)bwd_xbytes(nt, ntq) + (size_t)2 * ntq * 32 * 128 + (size_t)(nt * 32 + 128) * 4 +
+                         (nt > 4 ? (size_t)256 * 4 + 4 * 32 * 64 * 4 : 0);      // + partial D and partial dQ of the eight-wave form
     switch (nt) {
       case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
       case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
       case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
       case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      case 5: hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      case 6: hipLaunchKernelGGL(attn_bwd_kernel<6>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      case 7: hipLaunchKernelGGL(attn_bwd_kernel<7>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      default: hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 5: hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      case 6: hipLaunchKernelGGL(attn_bwd_kernel<6>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      case 7: hipLaunchKernelGGL(attn_bwd_kernel<7>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      default: hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
     }
   }
   SPMM_LAUNCH_CHECK("spmm_attn_bwd");

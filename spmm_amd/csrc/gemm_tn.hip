@@ -232,8 +232,7 @@ __device__ __forceinline__ void tp_tr(bf16x4& d, uint32_t addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// (the body of the 8-phase kernel as a function of the problem and the workgroup's index in it: launched per problem by
-// gemm_tn_p8_kernel and for several problems at once by gemm_tn_p8_group_kernel)
+// (the body of the 8-phase kernel as a function of the problem and the workgroup's index in it)
 template <bool SLAB>
 __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const int bz) {
   extern __shared__ __attribute__((aligned(16))) char smem_tp[];
@@ -251,7 +250,7 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
   if (p.nsplit > 0) {
     const int tiles = ntn * ntk, G = tiles * p.nsplit;
     const int b = bidx, q = G >> 3, r = G & 7, xcd = b & 7, i = b >> 3;
-    if (i >= (xcd < r ? q + 1 : q)) return;            // (grouped launches pad every problem to a multiple of 8 workgroups)
+    if (i >= (xcd < r ? q + 1 : q)) return;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     zsplit = L / tiles;
     tile = L - zsplit * tiles;
@@ -529,56 +528,6 @@ __global__ __launch_bounds__(512) void gemm_tn_p8_fold_kernel(TnP p, TnFold f) {
   tn_fold(f, blockIdx.x, gridDim.x, threadIdx.x);
 }
 
-// Several weight-gradient problems of one layer in ONE launch (spmm_gemm_tn_group): workgroup b belongs to problem i with
-// start[i] <= b < start[i+1] (starts are multiples of 8, so the XCD of a workgroup is the XCD its problem's own launch would give
-// it), every problem in slab mode with its own number of row slices.
-constexpr int TN_GROUP_MAX = 8;
-struct TnGroup {
-  int n;
-  int start[TN_GROUP_MAX + 1];
-  TnP p[TN_GROUP_MAX];
-};
-__global__ __launch_bounds__(512) void gemm_tn_p8_group_kernel(TnGroup g) {
-  int i = 0;
-#pragma unroll
-  for (int j = 1; j < TN_GROUP_MAX; ++j)
-    if (j < g.n && (int)blockIdx.x >= g.start[j]) i = j;
-  tn_p8_body<true>(g.p[i], (int)blockIdx.x - g.start[i], 0);
-}
-
-struct TnReduceGroup {
-  int n;
-  int start[TN_GROUP_MAX + 1];                 // block ranges
-  const float* slab[TN_GROUP_MAX];
-  float* C[TN_GROUP_MAX];
-  long ldc[TN_GROUP_MAX];
-  int splits[TN_GROUP_MAX], N[TN_GROUP_MAX], K4[TN_GROUP_MAX];
-};
-// C_i[n*ldc + k] += sum_z slab_i[z][n][k] for every problem of a group
-__global__ __launch_bounds__(256) void slab_reduce_group_kernel(TnReduceGroup g) {
-  int i = 0;
-#pragma unroll
-  for (int j = 1; j < TN_GROUP_MAX; ++j)
-    if (j < g.n && (int)blockIdx.x >= g.start[j]) i = j;
-  const float* __restrict__ slab = g.slab[i];
-  float* __restrict__ C = g.C[i];
-  const int K4 = g.K4[i], splits = g.splits[i];
-  const long ldc = g.ldc[i], total = (long)g.N[i] * K4;
-  const long nb = g.start[i + 1] - g.start[i];
-  for (long e = ((long)blockIdx.x - g.start[i]) * 256 + threadIdx.x; e < total; e += nb * 256) {
-    const int n = (int)(e / K4), k = (int)(e - (long)n * K4) * 4;
-    f32x4 s = *(const f32x4*)(slab + e * 4);
-    for (int z = 1; z < splits; ++z) {
-      const f32x4 v = *(const f32x4*)(slab + (long)z * total * 4 + e * 4);
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-    }
-    f32x4* d = (f32x4*)(C + (long)n * ldc + k);
-    f32x4 o = *d;
-    o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
-    *d = o;
-  }
-}
-
 // C[n*ldc + k] += sum_z slab[z][n][k]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int N, int K4, float* __restrict__ C,
                                                           long ldc) {
@@ -799,82 +748,6 @@ extern "C" int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float*
                    "spmm_gemm_tn_reduce: ns=%d N=%d K=%d ldc=%ld", ns, N, K, ldc);
   tn_reduce_launch(ws, ns, N, K, C, ldc, stream);
   SPMM_LAUNCH_CHECK("spmm_gemm_tn_reduce");
-  return SPMM_OK;
-}
-
-// ---- grouped launch: all the weight-gradient problems of a layer at once -------------------------------------------------------
-// Row slices per problem: the group as a whole gets about one workgroup per CU, shared out in proportion to the problems' rows
-// (every problem at least 2 slices: the masked last slice is what handles M % 128 != 0), at least 1024 rows per slice.
-static void tn_group_slices(int n, const int* M, const int* N, const int* K, int* ns) {
-  double work = 0;
-  for (int i = 0; i < n; ++i) work += (double)M[i] * ((N[i] + 255) / 256) * ((K[i] + 255) / 256);
-  const double per_wg = work / 256.0;
-  for (int i = 0; i < n; ++i) {
-    int s = (int)((double)M[i] / per_wg + 0.5);
-    const int maxs = M[i] / 1024 > 2 ? M[i] / 1024 : 2;
-    if (s > maxs) s = maxs;
-    ns[i] = s < 2 ? 2 : s;
-  }
-}
-extern "C" int spmm_gemm_tn_group_ok(int M, int N, int K) {   // can this problem join a grouped launch?
-  return N % 8 == 0 && K % 8 == 0 && N >= 256 && K >= 256 && M >= 2048;
-}
-extern "C" long spmm_gemm_tn_group_workspace(int n, const int* M, const int* N, const int* K) {   // floats
-  if (n < 1 || n > TN_GROUP_MAX) return -1;
-  int ns[TN_GROUP_MAX];
-  tn_group_slices(n, M, N, K, ns);
-  long tot = 0;
-  for (int i = 0; i < n; ++i) tot += (long)ns[i] * N[i] * K[i];
-  return tot;
-}
-extern "C" int spmm_gemm_tn_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, const int* M,
-                                  const int* N, const int* K, float* const* C, const long* ldc, float alpha, float* workspace,
-                                  spmm_stream_t stream) {
-  SPMM_CHECK_SHAPE(n >= 1 && n <= TN_GROUP_MAX, "spmm_gemm_tn_group: %d problems (1..%d)", n, TN_GROUP_MAX);
-  SPMM_CHECK_SHAPE(workspace != nullptr, "spmm_gemm_tn_group: needs the workspace of spmm_gemm_tn_group_workspace");
-  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)gemm_tn_p8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS);
-  if (attr_rc != hipSuccess) {
-    spmm_set_error("spmm_gemm_tn_group: cannot raise dynamic LDS to %d: %s", TP_LDS, hipGetErrorString(attr_rc));
-    return SPMM_ERR_LAUNCH;
-  }
-  int ns[TN_GROUP_MAX];
-  tn_group_slices(n, M, N, K, ns);
-  TnGroup g = {};
-  TnReduceGroup r = {};
-  g.n = r.n = n;
-  long woff = 0;
-  int b0 = 0, rb0 = 0;
-  for (int i = 0; i < n; ++i) {
-    SPMM_CHECK_SHAPE(spmm_gemm_tn_group_ok(M[i], N[i], K[i]), "spmm_gemm_tn_group: problem %d (M=%d N=%d K=%d) is not eligible", i, M[i], N[i], K[i]);
-    SPMM_CHECK_SHAPE(lda[i] % 8 == 0 && ldb[i] % 8 == 0 && lda[i] >= N[i] && ldb[i] >= K[i] && ldc[i] % 4 == 0 && ((uintptr_t)A[i] % 16 == 0) &&
-                         ((uintptr_t)B[i] % 16 == 0),
-                     "spmm_gemm_tn_group: problem %d: strides / alignment", i);
-    SPMM_CHECK_SHAPE((unsigned long)M[i] * (unsigned long)lda[i] * 2ul < (1ul << 32) && (unsigned long)M[i] * (unsigned long)ldb[i] * 2ul < (1ul << 32),
-                     "spmm_gemm_tn_group: problem %d: operands beyond 4 GiB", i);
-    TnP& p = g.p[i];
-    p.A = (const bf16*)A[i]; p.lda = lda[i]; p.B = (const bf16*)B[i]; p.ldb = ldb[i]; p.M = M[i]; p.N = N[i]; p.K = K[i];
-    p.C = C[i]; p.ldc = ldc[i]; p.slab = workspace + woff; p.alpha = alpha;
-    // slices of rs rows (multiples of 128); the last one ends at row M and is masked where it overlaps the one before (as spmm_gemm_tn)
-    const int rs = ((((M[i] + 127) / 128) + ns[i] - 1) / ns[i]) * 128;
-    const int nsl = (M[i] + rs - 1) / rs;
-    SPMM_CHECK_SHAPE(nsl >= 2, "spmm_gemm_tn_group: problem %d: a single row slice (M=%d)", i, M[i]);
-    const int over = nsl * rs - M[i];
-    p.rsplit = rs; p.nsplit = nsl; p.rlast = rs - (over / 128) * 128; p.ndup = over % 128;
-    const int tiles = ((N[i] + 255) / 256) * ((K[i] + 255) / 256);
-    g.start[i] = b0;
-    b0 += (tiles * nsl + 7) / 8 * 8;
-    r.slab[i] = p.slab; r.C[i] = C[i]; r.ldc[i] = ldc[i]; r.splits[i] = nsl; r.N[i] = N[i]; r.K4[i] = K[i] / 4;
-    long blocks = ((long)N[i] * (K[i] / 4) + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    r.start[i] = rb0;
-    rb0 += (int)blocks;
-    woff += (long)nsl * N[i] * K[i];
-  }
-  g.start[n] = b0;
-  r.start[n] = rb0;
-  hipLaunchKernelGGL(gemm_tn_p8_group_kernel, dim3(b0), dim3(512), TP_LDS, stream, g);
-  hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(rb0), dim3(256), 0, stream, r);
-  SPMM_LAUNCH_CHECK("spmm_gemm_tn_group");
   return SPMM_OK;
 }
 

@@ -99,6 +99,9 @@ class Group:
         return self
 
 
+STREAM_TOKENS_MAX = 49152         # B x Lt above which the step runs on one stream (Engine._one_stream)
+
+
 class Engine:
     def __init__(self, cfg: SPMMConfig, params: ParamStore, device, options: Optional[EngineOptions] = None):
         self.cfg, self.P, self.dev = cfg, params, device
@@ -125,7 +128,11 @@ class Engine:
         # kernels of one fill the CUs the other leaves idle (S1: 13.8 k rows = 162 of 256 CUs per 256x256-tile GEMM wave)
         self.multi_stream = self.opt.multi_stream
         self.wgrad_async = self.opt.wgrad_stream and self.multi_stream
-        self._wg_stream, self._wg_pending, self._wg_keep, self._wg_group = None, False, [], []
+        # Batches whose every chain fills the chip by itself (B x Lt above STREAM_TOKENS_MAX) run on ONE stream: side streams gain
+        # nothing there (412 vs 408 ms per step at B = 512, Lt = 256) and every stream keeps its own allocator pool -- 228 GB peak /
+        # 286 GB reserved of 288 on three streams (one allocator retry = a multi-second step) against 160 / 207 GB on one.
+        self._one_stream = False
+        self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self._tn_pend = {}                                  # chained weight-gradient GEMMs: stream handle -> slab reduction still pending there
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
@@ -137,9 +144,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ helpers
     def _fork(self, which: int = 0):
         """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
-        self._wgrad_flush()                              # (collected weight gradients belong to the stream they were recorded on)
         self._tn_flush()
-        if not self.multi_stream or self.dev.type != "cuda" or ops._DRY_RUN:
+        if not self.multi_stream or self._one_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
         side = streams.get(self.dev, f"side{which}")        # process-wide: every model of a process shares the same streams
         ev = torch.cuda.Event()
@@ -150,7 +156,6 @@ class Engine:
     def _join(self, side):
         if side is not None:
             with torch.cuda.stream(side):
-                self._wgrad_flush()
                 self._tn_flush()
             ev = torch.cuda.Event()
             ev.record(side)
@@ -187,20 +192,10 @@ class Engine:
         `wgrad_join()` makes the current stream wait for it (before a layer's gradient exchange, before the optimiser)."""
         ws = None if inline else self._wgrad_side()
         C = gW.view(dY.shape[1], X.shape[1])
-        # grouped mode (EngineOptions.grouped_wgrad): the matrix product waits for the layer's other weight gradients and leaves with
-        # them in ONE launch (_wgrad_flush, at the end of the layer); the bias column sums go out at once as before
-        group = self.opt.grouped_wgrad and not inline and ops.gemm_tn_group_ok(dY.shape[0], dY.shape[1], X.shape[1])
-        if group:
-            if any(c.data_ptr() == C.data_ptr() for _, _, c in self._wg_group) or len(self._wg_group) == 8:
-                self._wgrad_flush()                      # (two problems of one launch must not accumulate into the same tensor)
-            self._wg_group.append((dY, X, C))
         if ws is None:
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            if not group:
-                self._tn(dY, X, C)
-            return
-        if group and gb is None:
+            self._tn(dY, X, C)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -208,8 +203,7 @@ class Engine:
         with torch.cuda.stream(ws):
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            if not group:
-                self._tn(dY, X, C)
+            self._tn(dY, X, C)
         # The operands must outlive the side stream's use of them.  They are simply kept referenced until the next join
         # (`record_stream` on ~100 tensors per step makes the caching allocator poll events on every allocation).
         self._wg_keep.append((dY, X))
@@ -230,33 +224,14 @@ class Engine:
         if self._tn_pend:
             ops.gemm_tn_flush(self._tn_pend.pop(torch.cuda.current_stream().cuda_stream, None))
 
-    def _wgrad_flush(self):
-        """Launch the weight-gradient products collected since the last flush as one grouped launch (on the weight-gradient stream
-        when there is one, behind an event on the current stream)."""
-        probs, self._wg_group = self._wg_group, []
-        if not probs:
-            return
-        ws = self._wgrad_side()
-        run = (lambda: ops.gemm_tn_group(probs)) if len(probs) > 1 else (lambda: ops.gemm_tn(*probs[0]))
-        if ws is None:
-            return run()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        ws.wait_event(ev)
-        with torch.cuda.stream(ws):
-            run()
-        self._wg_keep.append(probs)
-        self._wg_pending = True
-
     def _wgrad_side(self):
-        if not self.wgrad_async or self.dev.type != "cuda" or ops._DRY_RUN:
+        if not self.wgrad_async or self._one_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
         self._wg_stream = streams.get(self.dev, "wgrad")
         return self._wg_stream
 
     def wgrad_join(self, release: bool = False):
         """The current stream waits for every weight-gradient launch issued so far."""
-        self._wgrad_flush()
         self._tn_flush()
         if self._wg_stream is not None and self._wg_pending:
             with torch.cuda.stream(self._wg_stream):
@@ -455,7 +430,7 @@ class Engine:
         h = self._new(M, I)
         # backward needs only gelu'(pre-activation): the forward epilogue stores it (it shares the exponential with the erf) and the
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
-        u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN
+        u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN and H % 128 == 0 and I % 128 == 0     # (the 8-phase kernel's shapes)
         dact = (self._new(M, I, dtype=torch.uint8) if u8 else self._new(M, I)) if save else None
         x = self._new(M, H)
         if self.fp8 and H % 256 == 0 and I % 256 == 0:
@@ -513,7 +488,6 @@ class Engine:
     def stack_bwd(self, pfx, c, layers, tape, dY, groups, dkv_acc=None):
         for i, sv in zip(reversed(list(layers)), reversed(tape)):
             dY = self._layer_bwd(f"{pfx}encoder.layer.{i}.", c, sv, dY, groups, dkv_acc)
-            self._wgrad_flush()                          # (grouped mode: this layer's weight gradients, one launch)
             if self.layer_done_cb is not None:           # this layer's gradients are final: data-parallel reduce may start
                 self._layer_done(f"{pfx}encoder.layer.{i}.")
         return dY

@@ -140,34 +140,6 @@ def gemm_tn_flush(pending):
         _call("spmm_gemm_tn_reduce", _p(ws), ns, N, K, _p(C), _row_stride(C), _st())
 
 
-def gemm_tn_group_ok(M, N, K):
-    return bool(not _DRY_RUN and lib().cdll.spmm_gemm_tn_group_ok(int(M), int(N), int(K)))
-
-
-def gemm_tn_group(problems, *, alpha=1.0):
-    """C_i[N_i,K_i] (fp32) += alpha * A_i[M_i,N_i]^T @ B_i[M_i,K_i] for up to 8 problems (A_i, B_i, C_i) in ONE launch plus one slab
-    reduction -- all the weight gradients of a layer at once (csrc/gemm_tn.hip).  The C_i must be distinct tensors."""
-    n = len(problems)
-    assert 1 <= n <= 8
-    # long reductions first: workgroups are dispatched in index order, and a short problem in the middle of the grid frees its CUs early
-    # for the long ones behind it instead of filling the tail
-    problems = sorted(problems, key=lambda t: -t[0].shape[0])
-    for A, B, C in problems:
-        assert A.dtype == BF16 and B.dtype == BF16 and C.dtype == torch.float32 and B.shape[0] == A.shape[0] and tuple(C.shape) == (A.shape[1], B.shape[1])
-    vp = lambda xs: ctypes.cast((ctypes.c_void_p * n)(*xs), ctypes.c_void_p)
-    lp = lambda xs: ctypes.cast((ctypes.c_long * n)(*xs), ctypes.c_void_p)
-    ip = lambda xs: ctypes.cast((ctypes.c_int * n)(*xs), ctypes.c_void_p)
-    Ms, Ns, Ks = [a.shape[0] for a, _, _ in problems], [a.shape[1] for a, _, _ in problems], [b.shape[1] for _, b, _ in problems]
-    M_, N_, K_ = ip(Ms), ip(Ns), ip(Ks)
-    nws = lib().cdll.spmm_gemm_tn_group_workspace(n, M_, N_, K_)
-    if nws <= 0:
-        raise RuntimeError("spmm_gemm_tn_group_workspace failed")
-    ws = torch.empty(nws, dtype=torch.float32, device=problems[0][2].device)
-    _call("spmm_gemm_tn_group", n, vp([a.data_ptr() for a, _, _ in problems]), lp([_row_stride(a) for a, _, _ in problems]),
-          vp([b.data_ptr() for _, b, _ in problems]), lp([_row_stride(b) for _, b, _ in problems]), M_, N_, K_,
-          vp([c.data_ptr() for _, _, c in problems]), lp([_row_stride(c) for _, _, c in problems]), float(alpha), _p(ws), _st())
-
-
 def colsum_bf16(x, out):
     R, C = x.shape
     _call("spmm_colsum_bf16", _p(x), _row_stride(x), R, C, _p(out), _st())

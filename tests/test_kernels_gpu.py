@@ -35,26 +35,6 @@ def close(got, ref, atol, rtol, name=""):
                           f"(ref max {ref.abs().max().item():.4g}) first bad idx {bad.nonzero()[0].tolist()}"
 
 
-def test_grouped_weight_gradient_launch(ops):
-    """spmm_gemm_tn_group: the weight-gradient products of a layer in one launch + one slab reduction, against fp32 torch and
-    against the per-problem launches (same tiles; the row slicing differs, so fp32 sums agree to rounding, not bit for bit).
-    Ragged M (not a multiple of 128), different M per problem, accumulation into non-zero C."""
-    shapes = [(13824, 2304, 768), (13824, 768, 768), (13824, 3072, 768), (13824, 768, 3072), (6913, 1536, 768), (20001, 768, 768)]
-    probs, refs, singles = [], [], []
-    for i, (M, N, K) in enumerate(shapes):
-        assert ops.gemm_tn_group_ok(M, N, K)
-        A, B = rnd(M, N, seed=100 + i, scale=0.5), rnd(M, K, seed=200 + i, scale=0.5)
-        C0 = torch.randn(N, K, device="cuda")
-        probs.append((A, B, C0.clone()))
-        refs.append(C0 + A.float().t() @ B.float())
-        singles.append(ops.gemm_tn(A, B, C0.clone()))
-    ops.gemm_tn_group(probs)
-    torch.cuda.synchronize()
-    for (M, N, K), (_, _, C), ref, one in zip(shapes, probs, refs, singles):
-        close(C, ref, atol=2e-2 * (M / 13824) ** 0.5, rtol=2e-3, name=f"grouped {M}x{N}x{K} vs fp32 torch")
-        close(C, one, atol=2e-3 * (M / 13824) ** 0.5, rtol=1e-4, name=f"grouped {M}x{N}x{K} vs the single launch")
-
-
 def test_chained_weight_gradient_reductions(ops):
     """spmm_gemm_tn_chain / spmm_gemm_tn_reduce: every product's slab reduction rides inside the NEXT product's launch, the last one is
     flushed.  Bit-identical to the plain launches (same slabs, same summation order), incl. two products accumulating into the SAME

@@ -16,7 +16,7 @@ FAMILIES = {
     "attention backward": "spmm_attn_bwd",
     "LayerNorm forward": "spmm_ln_fwd",
     "LayerNorm backward": "spmm_ln_bwd",
-    "weight gradients (TN GEMM)": "spmm_gemm_tn,spmm_gemm_tn_group",
+    "weight gradients (TN GEMM)": "spmm_gemm_tn",
     "column sums": "spmm_colsum_bf16",
     "AdamW + clip + EMA": "spmm_adamw_step,spmm_ema_update,spmm_grad_sqnorm",
     "FFN GEMMs' second output / factor (plain epilogues instead)": "EPI_PLAIN",
