@@ -23,7 +23,17 @@ if os.environ.get("SPMM_DIST_BACKEND") != "gloo":
 # Watchdog: a run still going after this many seconds dumps every thread's Python stack and EXITS NON-ZERO (never a re-exec, never a
 # silent hang of the driver's scaling run).  Default for N>1: 600 s -- 60 default steps take ~4 s, the rest is start-up (the first
 # `import torch` of eight processes on a fresh box alone can take two minutes).
-_wd = os.environ.get("SPMM_BENCH_WATCHDOG") or ("600" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
+# (long runs get more: 2 s per step asked for beyond the default 50; SPMM_BENCH_WATCHDOG=0 turns it off)
+def _asked_steps():
+    for i, a in enumerate(sys.argv):
+        if a == "--steps" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            return int(sys.argv[i + 1])
+        if a.startswith("--steps=") and a[8:].isdigit():
+            return int(a[8:])
+    return 50
+
+
+_wd = os.environ.get("SPMM_BENCH_WATCHDOG") or (str(600 + 2 * max(0, _asked_steps() - 50)) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
 if _wd and float(_wd) > 0:
     import faulthandler
     faulthandler.dump_traceback_later(float(_wd), exit=True)
@@ -148,18 +158,22 @@ def decode_bench(args):
     cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross_attention=True),
                      prop=BertConfig(num_hidden_layers=6, fusion_layer=6, vocab_size=1), embed_dim=256, queue_size=36864)
     m = SPMM(spmm_config=cfg, no_train=True).eval()
+    if args.sep_bias:
+        # random-init weights never rank [SEP] among the k best successors, so every molecule runs all positions (the worst case, and the
+        # default here).  A bias on the [SEP] logit gives the searches a spread of lengths and exercises the early exit.
+        m.store.w("text_encoder.cls.predictions.bias")[3] += float(args.sep_bias)
     m.store.refresh_shadows()
     N, chunk, k, T = args.molecules, args.chunk, args.beams, args.decode_steps
     props = torch.randn(N, 53, generator=torch.Generator().manual_seed(42))
     chunks = [props[i:i + chunk] for i in range(0, N, chunk)]
     decode.beam_search_batched(m, props[:min(8, N)], k=k, max_steps=4)                      # warm-up (kernel attributes, allocator)
     for c in chunks[:args.warmup]:
-        decode.beam_search_batched(m, c, k=k, max_steps=T, graph=args.decode_graph)
+        decode.beam_search_batched(m, c, k=k, max_steps=T, graph={'auto': None, 'on': True, 'off': False}[args.decode_graph])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nfin = 0
     for c in chunks:
-        nfin += sum(len(r) for r in decode.beam_search_batched(m, c, k=k, max_steps=T, graph=args.decode_graph))
+        nfin += sum(len(r) for r in decode.beam_search_batched(m, c, k=k, max_steps=T, graph={'auto': None, 'on': True, 'off': False}[args.decode_graph]))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"metric": "PV->SMILES k-beam decode molecules/sec", "value": round(N / dt, 2), "unit": "molecules/s", "n_gpus": 1, "steps": len(chunks),
@@ -167,35 +181,66 @@ def decode_bench(args):
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"d_pv2smiles_batched.py: {N} synthetic PVs, k={k} beams, <= {T} positions, chunks of {chunk} molecules, 12-layer "
                                   "causal text encoder with cross-attention to the 54-token PV embeddings, K/V cache"
-                                  + (", one hipGraph replay per position" if args.decode_graph else ""), "global_batch": chunk, "seq_len": T},
-           "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin}
-    # ---- instrumented chunk: HIP events around every decode_attn launch (eager, single stream)
-    ev, orig = [], ops.decode_attn
+                                  + (", one hipGraph replay per position" if (args.decode_graph == "on" or (args.decode_graph == "auto" and chunk * k < decode.GRAPH_BELOW_ROWS)) else ""), "global_batch": chunk, "seq_len": T},
+           "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin, "sep_logit_bias": args.sep_bias}
+    # ---- instrumented chunk (eager, single stream): HIP events around every decode_attn / GEMM / LayerNorm launch
+    ev, other = [], {"gemm": [], "layernorm": []}
+    orig, orig_gemm, orig_ln = ops.decode_attn, ops.gemm_nt, ops.ln_fwd
     stream = torch.cuda.current_stream()
 
     def timed(q, K, V, o, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_div=1, group=1, **kw):
+        R, H = q.shape[0], nH * 64
+        if anc is not None:
+            # self-attention: the DISTINCT cache rows the beams of a molecule reference at each position (a row shared by several
+            # beams is loaded once by the molecule's wave) -- counted from the ancestry table, outside the timed interval
+            a = anc.view(R // group, group, -1)[:, :, :Lkv].sort(dim=1).values
+            kv_rows = int((a[:, 1:] != a[:, :-1]).sum()) + (R // group) * Lkv
+        else:
+            kv_rows = (R // kv_div) * Lkv                                   # cross-attention: one source per molecule
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         r = orig(q, K, V, o, nH=nH, Lkv=Lkv, seq_stride=seq_stride, tok_stride=tok_stride, anc=anc, kv_div=kv_div, group=group, **kw)
         e1.record(stream)
-        R, H = q.shape[0], nH * 64
-        kv_rows = R * Lkv if anc is not None else (R // kv_div) * Lkv      # self: every beam's own prefix; cross: one source per molecule
-        ev.append((e0, e1, 2.0 * (2 * kv_rows * H + 2 * R * H)))
+        ev.append((e0, e1, 2.0 * (2 * kv_rows * H + 2 * R * H), 2.0 * (2 * (R * Lkv if anc is not None else kv_rows) * H + 2 * R * H)))
         return r
-    ops.decode_attn = timed
+
+    def timed_other(kind, fn):
+        def w(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            r = fn(*a, **k)
+            e1.record(stream)
+            other[kind].append((e0, e1))
+            return r
+        return w
+    ops.decode_attn, ops.gemm_nt, ops.ln_fwd = timed, timed_other("gemm", orig_gemm), timed_other("layernorm", orig_ln)
+    tot0, tot1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
+        tot0.record(stream)
         decode.beam_search_batched(m, chunks[0], k=k, max_steps=T, graph=False)
+        tot1.record(stream)
     finally:
-        ops.decode_attn = orig
+        ops.decode_attn, ops.gemm_nt, ops.ln_fwd = orig, orig_gemm, orig_ln
     torch.cuda.synchronize()
-    tms = sum(a.elapsed_time(b) for a, b, _ in ev)
-    nbytes = sum(b for _, _, b in ev)
-    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_group_kernel (csrc/decode.hip): one wave per (molecule, head) over the K/V cache, a key / value row loaded once for all beams that share it "
-                                                         "(bytes counted per beam row: the sharing is the kernel's, not the algorithm's)",
+    tms = sum(a.elapsed_time(b) for a, b, *_ in ev)
+    nbytes = sum(b for _, _, b, _ in ev)
+    nbytes_rows = sum(b for *_, b in ev)
+    tot_ms = tot0.elapsed_time(tot1)
+    gms, lms = (sum(a.elapsed_time(b) for a, b in other[kk]) for kk in ("gemm", "layernorm"))
+    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_group_kernel (csrc/decode.hip): one wave per (molecule, head) over the K/V cache; a key / value row is loaded once "
+                                                         "for all beams of the molecule that share it, and the bytes are counted the same way: DISTINCT cache rows per molecule and "
+                                                         "position (from the ancestry table) + q + out",
                        "achieved": round(nbytes / (tms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": round(nbytes / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches": len(ev),
                        "avg_launch_us": round(tms * 1e3 / len(ev), 2), "algorithmic_bytes_per_launch": round(nbytes / len(ev)),
+                       "bytes_per_launch_if_every_beam_row_read_its_own_prefix": round(nbytes_rows / len(ev)),
                        "measured": "HIP events around every decode_attn launch of one eager chunk (event-pair overhead ~2 us included)"}
+    npos = T + 1
+    out["position_breakdown_ms"] = {"note": "one eager single-stream chunk, HIP events around every launch of the three kernel families (event-pair overhead included); "
+                                            "rest = beam bookkeeping (torch top-k / gather / scatter), cache writes, embedding, launch gaps",
+                                    "total": round(tot_ms / npos, 3), "gemm": round(gms / npos, 3), "gemm_launches": len(other["gemm"]) // npos,
+                                    "decode_attn": round(tms / npos, 3), "layernorm": round(lms / npos, 3),
+                                    "rest": round((tot_ms - gms - tms - lms) / npos, 3)}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import spmm_oracle as O
@@ -238,8 +283,10 @@ def main():
                     "molecules/s against 943 at 250 and 1 469 at 500, profiles/r03_decode_bench.json)")
     ap.add_argument("--beams", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=100)
-    ap.add_argument("--decode-graph", action="store_true", help="--decode: one hipGraph replay per position instead of eager launches (pays below "
-                    "~500 molecules per chunk, where a position is launch-bound)")
+    ap.add_argument("--sep-bias", type=float, default=0.0, help="--decode: added to the [SEP] logit of the random-init LM head (0 = [SEP] never wins: every "
+                    "molecule decodes all positions)")
+    ap.add_argument("--decode-graph", choices=["auto", "on", "off"], default="auto", help="--decode: one hipGraph replay per position instead of eager launches; auto = "
+                    "below decode.GRAPH_BELOW_ROWS beam rows per chunk, where a position is launch-bound")
     args = ap.parse_args()
     if args.decode:
         if args.warmup == 10:

@@ -63,6 +63,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define XA_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define XA_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// The wait that makes an asynchronously loaded register valid takes that register as a read-write operand: every use of the loaded value
+// is then a use of THIS statement's output, so no compiler-inserted copy, spill or re-ordered use of the register can sit ahead of the wait
+// (the register's only other appearance is as the output of the load statement itself).
+#define XA_VM_TIE(N, R) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R) : "n"(N) : "memory")
+#define XA_LGKM0_TIE(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R)::"memory")
 #define XA_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int N, typename F>
@@ -396,7 +401,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
           ds_rd<0>(cf[0][kk], a0);
           ds_rd<8192>(cf[1][kk], a0);
         }
-        XA_LGKM0();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { XA_LGKM0_TIE(cf[0][kk]); XA_LGKM0_TIE(cf[1][kk]); }
         XA_SB();
       };
       load_cf(0);
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
         // j == 0: everything older has to be in anyway -- the next pair's K/V (issued a whole attention core ago), the next Q
         // fragments, this step's first D ring fragments; later waits count the ring fragments issued after the one needed
         // (the context stores / the residual DMA below are younger too: they only make some waits stricter)
-        if constexpr (j == 0) XA_VM(0); else XA_VM(younger);
+        if constexpr (j == 0) XA_VM_TIE(0, ring[j % D]); else XA_VM_TIE(younger, ring[j % D]);
         XA_SB();
         acc[0][ct] = MFMA32(ring[j % D], cf[0][kk], acc[0][ct]);
         acc[1][ct] = MFMA32(ring[j % D], cf[1][kk], acc[1][ct]);
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(XattnP p) {
             // loads -- with the reads ahead of the fragment ring the first of the four came out clobbered)
             u32x4 cv[4];
             ds_rd<0>(cv[0], cva); ds_rd<4096>(cv[1], cva); ds_rd<8192>(cv[2], cva); ds_rd<12288>(cv[3], cva);
-            XA_LGKM0();
+            XA_LGKM0_TIE(cv[0]); XA_LGKM0_TIE(cv[1]); XA_LGKM0_TIE(cv[2]); XA_LGKM0_TIE(cv[3]);
             XA_SB();
             const char* cb = (const char*)(p.CTX + qrow * p.ldc + s * 128);
             int tl = tid;

@@ -9,6 +9,7 @@ from typing import List, Tuple
 import torch
 
 CLS_ID, SEP_ID = 2, 3           # vocab_bpe_300.txt:3-4
+GRAPH_BELOW_ROWS = 2500         # beam rows below which a decode position is bound by its ~230 launches (bench.py --decode --chunk 250 / 500)
 
 
 def _pick(p: torch.Tensor, k: int, stochastic: bool, generator=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -259,7 +260,7 @@ class CachedDecoder:
 @torch.no_grad()
 def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
                         sync_every: int = 4, prop_mask: torch.Tensor | None = None, stochastic: bool = False,
-                        generator=None, graph: bool = False) -> List[List[Tuple[float, List[int]]]]:
+                        generator=None, graph: bool | None = None) -> List[List[Tuple[float, List[int]]]]:
     """The reference's beam search for N molecules at once (props [N,53]); result[n] is what the one-molecule search
     (oracle/decode_oracle.py::beam_search) returns for props[n].
     cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
@@ -267,9 +268,12 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     (encode_properties).  stochastic=True draws the k candidates of every beam from the next-token distribution instead of
     taking the k most probable (d_pv2smiles_single.py:37-40); `generator` seeds those draws.  graph=True (cached, deterministic)
     captures one decode position -- ~230 launches -- as a hipGraph and replays it: the per-position host cost drops from ~2.3 ms
-    of launch overhead to one graph launch, which is what small batches are bound by."""
+    of launch overhead to one graph launch, which is what small batches are bound by.  graph=None (default): replay when the batch
+    is launch-bound -- fewer than GRAPH_BELOW_ROWS beam rows -- and the search is deterministic."""
     if cached is None:
         cached = hasattr(model, "engine")
+    if graph is None:
+        graph = bool(cached and not stochastic and props.shape[0] * k < GRAPH_BELOW_ROWS)
     prop_embeds = encode_properties(model, props, prop_mask)
     N, dev = prop_embeds.shape[0], prop_embeds.device
     if cached:

@@ -335,6 +335,22 @@ class Engine:
                                   Z=None if z is None else z[r], mean=None if mean is None else mean[r.start:r.stop],
                                   rstd=None if rstd is None else rstd[r.start:r.stop], CTX=None if ctx is None else ctx[r], lse=lse,
                                   attn_dropout_p=pa, salt_a=salt, hidden_dropout_p=ph, salt_h=salt_h, seed=self.seed, row_base=r.start, **lay)
+                    if r.start == 0 and not getattr(self, "_xattn_checked", False) and not ops._DRY_RUN:
+                        # one-time self-check of the fused kernel against the composite launches on the first block it serves (same
+                        # dropout masks: same seed, salts and row counter).  The kernel keeps asynchronously loaded registers in
+                        # flight behind hand-counted waits: a compiler change that broke that would corrupt y silently.
+                        self._xattn_checked = True
+                        n = r.stop
+                        c2, x2, y2 = self._new(n, H), self._new(n, H), self._new(n, H)
+                        self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], c2, None, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, is_cross=True,
+                                       dropout_p=pa, seed=self.seed, salt=salt, **lay)
+                        ops.gemm_nt(c2, P.wb(pfx + ".output.dense.weight"), x2, bias=P.w(pfx + ".output.dense.bias"))
+                        ops.ln_fwd(x2, X[r], P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y2,
+                                   eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt_h)
+                        d = (y[r].float() - y2.float()).abs()
+                        if not (float(d.max()) < 0.25 and float(d.mean()) < 5e-3):      # (bf16 roundings of x differ: ~1e-3 on average)
+                            raise RuntimeError(f"fused cross-attention kernel disagrees with the composite launches: max |dy| {float(d.max()):.3g}, "
+                                               f"mean {float(d.mean()):.3g} -- set SPMM_FUSED_XATTN=0")
                 else:
                     salt = self._next_salt()
                     self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, is_cross=True,

@@ -66,6 +66,10 @@ def serialised(busy: torch.cuda.Stream, issue, sleep_ms: float = 8.0) -> Optiona
         end.record()
     w = issue()
     done = (lambda: w.is_completed()) if hasattr(w, "is_completed") else (lambda: w.query())
+    if end.query():                                  # the sleep was over before the first look at the work: nothing can be told
+        end.synchronize()
+        _spin_until(done, 5.0)
+        return None
     finished_first = _spin_until(lambda: done() or end.query(), 5.0) and done() and not end.query()
     end.synchronize()
     _spin_until(done, 5.0)
@@ -85,7 +89,11 @@ def probe_pair(a: torch.cuda.Stream, b: torch.cuda.Stream) -> bool:
             x.add_(1.0)
             ev.record()
         return ev
-    return bool(serialised(a, issue))
+    for sleep_ms in (8.0, 32.0, 128.0):              # (None = the host was slower than the sleep: look again with a longer one)
+        r = serialised(a, issue, sleep_ms)
+        if r is not None:
+            return r
+    return False
 
 
 def place_beside_collectives(device, names=("side0", "side1", "wgrad"), max_redraws: int = 6) -> Dict[str, str]:
