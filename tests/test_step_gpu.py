@@ -214,6 +214,38 @@ def test_fp8_ffn_forward_tracks_the_bf16_pipeline(env):
     assert last < first
 
 
+def test_fp8_tier_at_seq_len_256_against_the_oracle(env):
+    """BASELINE configs[4]'s sequence length with the fp8 option on: H = 768, 2+2 layers, B = 8, Lt = 256, ragged lengths, packed rows,
+    dropout off -- the four losses of the E4M3 FFN forward against the fp32 oracle and against the bf16 pipeline, and the whole gradient
+    (the backward runs in bf16 on the saved activations: a straight-through estimate of the quantised forward).  Stated tolerances:
+    1.5 x the measured deviations; the property-regression loss (an MSE x 5 on O(1) predictions) is what 3 mantissa bits cost most."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env)
+    for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.init_state_dict(ocfg, seed=4)
+    B, Lt = 8, 256
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=41)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(8))
+    neg = (torch.arange(B).roll(3), torch.arange(B).roll(5))
+    out, grads = {}, {}
+    for mode in ("bf16", "fp8"):
+        m = _mk(SPMM, cfg, sd).train()
+        m.engine.fp8 = mode == "fp8"
+        losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+        sum(losses).backward()
+        out[mode] = np.array([float(x) for x in losses])
+        grads[mode] = m.store.grad.detach().clone()
+    with torch.no_grad():
+        ref = np.array([float(x) for x in O.spmm_forward({k: v.clone() for k, v in sd.items()}, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)])
+    d16, dref = np.abs(out["fp8"] - out["bf16"]), np.abs(out["fp8"] - ref)
+    grel = ((grads["fp8"] - grads["bf16"]).norm() / grads["bf16"].norm()).item()
+    print("Lt=256 fp8", out["fp8"], "bf16", out["bf16"], "oracle", ref, "|fp8 - bf16|", d16, "|fp8 - oracle|", dref, "gradient vs bf16 rel L2", grel)
+    assert np.all(np.isfinite(out["fp8"])) and d16.max() > 0
+    assert np.all(dref < np.array([2.5e-3, 1e-2, 2.4e-2, 3.5e-3])), dref      # measured 1.6e-3 / 6.1e-3 / 1.55e-2 / 2.3e-3
+    assert grel < 0.06                                                           # measured 0.040
+
+
 def test_fused_cross_attention_inside_the_step(env):
     """EngineOptions.fused_xattn: the cross-attention blocks of every fusion layer as ONE launch each (csrc/xattn.hip) inside the real
     step -- H=768, 2+2 layers, packed text rows, shared K/V sources, train mode with dropout.  Both forms draw the same dropout
