@@ -166,6 +166,24 @@ def grad_sync_fn(store=None, options: Optional[EngineOptions] = None):
     live = dist.is_available() and dist.is_initialized()
     if not live or (world() == 1 and not opt.force_dist):
         return None
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        # Stream order is part of the schedule (EXPERIMENTS.md 1.4): RCCL's internal stream first, the compute side streams after it
+        # is the order that measures 60-61 ms per step with a one-rank group; side streams first-touched before RCCL's ran at 80 ms.
+        # An asynchronous collective here creates the communicator's stream before spmm_amd/streams.py hands out the first side
+        # stream (they are created lazily, at the first forward); a process that already holds side streams is told so.
+        from . import streams
+        dev = torch.cuda.current_device()
+        if ("order", dev) not in _placed:
+            _placed.add(("order", dev))
+            late = bool(streams.handles(dev))
+            t = torch.zeros(1, device=f"cuda:{dev}")
+            dist.all_reduce(t, async_op=True).wait()
+            streams.note(f"cuda:{dev}: first collective issued " + ("AFTER the compute side streams existed (the slow order of EXPERIMENTS.md 1.4)"
+                                                                     if late else "before any compute side stream was created"))
+            if late:
+                import warnings
+                warnings.warn("spmm_amd: HIP side streams were created before the first RCCL collective; create the process group and "
+                              "call grad_sync_fn() before the first forward")
     if opt.probe_streams and dist.get_backend() == "nccl" and torch.cuda.is_available():
         dev = torch.cuda.current_device()
         if dev not in _placed:

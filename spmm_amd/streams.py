@@ -47,6 +47,11 @@ def log() -> List[str]:
     return list(_log)
 
 
+def note(line: str) -> None:
+    """Start-up facts about stream placement that bench.py / pretrain.py report (`stream_placement`)."""
+    _log.append(line)
+
+
 def _spin_until(pred, seconds):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
