@@ -144,6 +144,22 @@ def cpu_baseline(B, Lt, seconds_budget=45.0):
             "sample": f"oracle/spmm_oracle.py OracleTrainer, full 12+6-layer H=768 model fp32, B={B}, Lt={Lt}, {n} timed step(s) after 1 warm-up"}
 
 
+def child_bench(flags, keep, timeout=420):
+    """One more measurement of this file in a child process (never an exec from a process that has touched the GPU); -> the named keys
+    of its JSON line, or {"error": ...}."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + flags, capture_output=True, text=True, timeout=timeout,
+                           env={k: v for k, v in os.environ.items() if not k.startswith("SPMM_")})
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"rc={r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+        d = json.loads(line[-1])
+        return {k: d[k] for k in keep if k in d}
+    except Exception as e:            # noqa: BLE001  (a report, not a failure of the headline measurement)
+        return {"error": repr(e)[:300]}
+
+
 def decode_bench(args):
     """BASELINE.json configs[3]: PV -> SMILES k-beam decode (d_pv2smiles_batched.py:18-59) on synthetic PVs with the batched
     K/V-cache decoder (spmm_amd/decode.py), full-size random-init model.  A "step" is one chunk of molecules decoded to
@@ -283,11 +299,16 @@ def main():
                     "molecules/s against 943 at 250 and 1 469 at 500, profiles/r03_decode_bench.json)")
     ap.add_argument("--beams", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=100)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[3] (decode) and configs[4]-shape (B=512, Lt=256) "
+                    "measurements the default one-GPU run appends to its JSON line (each in a child process, after the timed region)")
     ap.add_argument("--sep-bias", type=float, default=0.0, help="--decode: added to the [SEP] logit of the random-init LM head (0 = [SEP] never wins: every "
                     "molecule decodes all positions)")
     ap.add_argument("--decode-graph", choices=["auto", "on", "off"], default="auto", help="--decode: one hipGraph replay per position instead of eager launches; auto = "
                     "below decode.GRAPH_BELOW_ROWS beam rows per chunk, where a position is launch-bound")
     args = ap.parse_args()
+    # the other configs ride only on the default workload of one GPU (what the driver runs), not on every experiment
+    default_run = (args.batch == 128 and args.seq_len == 128 and args.layers == "12,6,6" and args.queue == 36864 and not args.eval_mode and not args.graph
+                   and not args.fp8 and args.gpus == 1 and not args.no_kernel_timing)
     if args.decode:
         if args.warmup == 10:
             args.warmup = 1
@@ -593,6 +614,23 @@ def main():
             out["cross_attention"] = xattn
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(16, Lt)
+        if world == 1 and default_run and not args.no_other_configs:
+            # BASELINE configs[3] and configs[4]'s per-GPU shape, driver-visible: short runs of this same file in child processes
+            # (this process's model and cached blocks are released first; a child that fails is reported, never fatal)
+            model.engine.tape = None
+            del model, one_step
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = {
+                "configs[3] PV->SMILES k-beam decode (1000 PVs, k=5, 100 positions)": child_bench(["--decode", "--no-cpu-baseline"],
+                    ("metric", "value", "unit", "ms_per_position", "finished_hypotheses", "roofline", "position_breakdown_ms")),
+                "configs[4] per-GPU shape in bf16 (B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5", "--warmup", "4",
+                    "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs"],
+                    ("metric", "value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "mfma_frac_of_peak_step", "hbm", "config")),
+                "configs[4] per-GPU shape with the fp8 option (E4M3 FFN forward; B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5",
+                    "--warmup", "4", "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs", "--fp8"],
+                    ("value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "dtype"))}
         print(json.dumps(out), flush=True)
     if args.check_replicas and world > 1:
         check_replicas(args.warmup + args.steps, fatal=True)

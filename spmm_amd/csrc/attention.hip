@@ -61,8 +61,14 @@ constexpr int FWD_LDS = 2 * TILE + 128 * 4;
 
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 
+// From five key tiles on the per-tile loops below are fenced (TILEWISE): left alone the compiler interleaves the tiles' arithmetic and needs
+// 207-256 registers (spilling at NT = 8); tile by tile it needs 126-174.
+// (The fence is a wave-uniform branch the compiler cannot fold -- `t <= tlast` with tlast = NT - 1 read from a scalar register: a
+// scheduling barrier alone does not stop the IR-level code motion that causes the interleaving.)
+#define ATT_TILE_ON(t) (!TILEWISE || (t) <= tlast)
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+  constexpr bool TILEWISE = NT > 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // only the NT 32-row tiles in use are allocated (a 54-key head holds 16 KiB + the mask vector, not 33 KiB: the two-wave
   // workgroups of the PV-query calls were held to 4 per CU by LDS alone)
@@ -98,18 +104,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __syncthreads();
 
   const bool causal = seq >= p.causal_from;
-  // Causal sequences: a key tile wholly to the right of this wave's 32 query rows contributes exp(s - 10000 - max) = 0 exactly
-  // whenever the row has one attended key -- key 0 is visible to every row, so "key 0 is not masked" (the [CLS] position of every
-  // real batch) is enough.  Those tiles are skipped (wave-uniform); if key 0 IS masked the reference's -10000 arithmetic over all
-  // keys is reproduced in full.
-  // (not in the chunked path of longer sequences -- q_off / kv_off != 0 -- where "key 0" is only the chunk's first key)
-  const bool skip_ok = causal && p.q_off == 0 && p.kv_off == 0 && __builtin_amdgcn_readfirstlane((int)(mb[0] == 0.f));
-  const int tlast = skip_ok ? (qc0 + wave * 32 + 31) >> 5 : NT - 1;
+  // (Key tiles wholly above the causal diagonal are NOT skipped: the reference's mask is additive -10000, not -inf, and with large
+  // scores -- the closed-form-weight goldens reach 1e4 -- a future key keeps a non-zero weight that the parity tests see.)
+  const int tlast = __builtin_amdgcn_readfirstlane(NT - 1 - (p.nseq < 0 ? NT : 0));     // = NT - 1, opaque to the compiler (ATT_TILE_ON)
   f32x16 st[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     st[t] = zero16();
-    if (t <= tlast) {
+    if (ATT_TILE_ON(t)) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) st[t] = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st[t]);
     }
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   float mx = -INFINITY;
   const int qpos = q + p.q_off - p.kv_off;          // causal: key kv is visible iff kv <= qpos
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (t <= tlast) {
+  for (int t = 0; t < NT; ++t) {
+    if (ATT_TILE_ON(t)) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int kv0 = t * 32 + 8 * gq + 4 * g;
@@ -136,11 +138,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         }
       }
     }
+  }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (t <= tlast) {
+  for (int t = 0; t < NT; ++t) {
+    if (ATT_TILE_ON(t)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
@@ -148,14 +151,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         sum += e;
       }
     }
+  }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
   if (p.LSE && q < Lq && g == 0) p.LSE[((long)seq * p.nH + h) * p.Lq + q] = mx * LN2 + __logf(sum);
   if (p.drop_thresh16) {
     const uint32_t rk = drop_rowkey(seed_mix(p.seed_ptr, p.seed_salt), ((uint64_t)seq * p.nH + h) * p.Lq + q) + (uint32_t)(2 * g) * DROP_WEYL;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t <= tlast) {
+    for (int t = 0; t < NT; ++t) {
+      if (ATT_TILE_ON(t)) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3 hold 4 consecutive keys
           // pair index (t*32 + 8*gq + 4*g) >> 1: the lane's part (2g) is already inside rk, the rest is a literal
@@ -166,12 +170,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           st[t][gq * 4 + 3] = (r1 >> 16) >= p.drop_thresh16 ? st[t][gq * 4 + 3] : 0.f;
         }
       }
+      }
   }
   // O^T[d][q] = sum_kv V^T[d][kv] P^T[kv][q]
   f32x16 ot[2] = {zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (t > tlast) continue;
+    if (!ATT_TILE_ON(t)) continue;
     const bf16x8 pf0 = pack8(st[t], 0), pf1 = pack8(st[t], 1);
     bf16x8 vf0[2], vf1[2];
     ld_tr2x2(Vs, t * 32, lane, vf0, vf1);
@@ -244,8 +249,267 @@ __device__ __forceinline__ float up_lo(uint32_t w) { return __builtin_bit_cast(f
 __device__ __forceinline__ float up_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Four-wave form for Lkv <= 128 (NT = 1, 2, 4): wave w owns query tile w of the launch's chunk against all keys, then key tile w.  Kept as
+// its own body: the shared body below (needed for the key-split form) costs these shapes 3-12 % (the compiler schedules its two-block
+// phase A less tightly; same-box A/B with tools/bench_attn.py).
 template <int NT>   // NT = ceil(Lkv / 32)
-__global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: ceil(max Lq / 32) tiles)
+  const int ntq_max = p.Lq - p.qc0 >= 128 ? 4 : (p.Lq - p.qc0 + 31) >> 5;
+  const int kvb = NT * 32 * 128, qb = ntq_max * 32 * 128, xb = bwd_xbytes(NT, ntq_max);
+  char* X = smem;
+  char* Ks = X;
+  char* Vs = X + kvb;
+  char* Qs = X + xb;
+  char* dOs = Qs + qb;
+  float* mb = (float*)(dOs + qb);
+  float* lse = mb + NT * 32;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
+  const int Lq0 = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
+  const int qc0 = p.qc0, Lq = Lq0 - qc0 < 128 ? Lq0 - qc0 : 128;
+  if (Lq <= 0) return;
+  const long qrow = (p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq) + qc0;
+  const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
+  const long dkvrow = p.kv_seq ? (long)seq * p.Lkv : kvrow;     // shared sources: dK/dV per query sequence, dense
+  const bf16* Qg = p.Q + qrow * p.ldq + h * HD;
+  const bf16* Kg = p.K + kvrow * p.ldk + h * HD;
+  const bf16* Vg = p.V + kvrow * p.ldv + h * HD;
+  const bf16* dOg = p.dO + qrow * p.lddo + h * HD;
+  const int qrows = ((Lq + 31) >> 5) * 32;
+  stage_head(Kg, p.ldk, Lkv, Ks, tid, 256, NT * 32);
+  stage_head(Vg, p.ldv, Lkv, Vs, tid, 256, NT * 32);
+  stage_head(Qg, p.ldq, Lq, Qs, tid, 256, qrows);
+  stage_head(dOg, p.lddo, Lq, dOs, tid, 256, qrows);
+  if (tid < 128) {
+    const int j = tid;
+    // (mb holds NT * 32 entries; lse 128)
+    // additive score bias per key as in the forward: 0 (attend), mask_neg (masked), -inf (tile padding past Lkv: P = 0 exactly);
+    // query rows past Lq get lse = +inf, i.e. P = exp(s - inf) = 0, so neither needs a per-element test below
+    const float neg2 = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);     // (units of log2, as in the forward)
+    if (j < NT * 32) mb[j] = j < Lkv ? ((p.kmask == nullptr || p.kmask[(long)seq * p.Lkv + j]) ? 0.f : neg2) : -INFINITY;
+    lse[j] = j < Lq ? p.LSE[((long)seq * p.nH + h) * p.Lq + qc0 + j] * LOG2E : INFINITY;
+  }
+  __syncthreads();
+
+  const bool causal = seq >= p.causal_from;
+  const bool drop = p.drop_thresh16 != 0;
+  const uint64_t seed = drop ? seed_mix(p.seed_ptr, p.seed_salt) : 0;
+  const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
+  const int NTq = (Lq + 31) >> 5;
+  const float dsc = drop ? p.drop_scale : 1.f, qsc = 0.125f * dsc;     // (see the dropout note in phase A)
+
+  // ---- phase A: wave owns query tile `wave`: ONE pass over the scores gives D[q] = sum_kv P dP (fp32, exactly consistent with
+  // ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and dS = P (dP - D).
+  // D is NOT taken from rowsum(dO * O): O is bf16-rounded, and when dP is nearly constant over kv (real models)
+  // ds = P (dP - D) is a small difference of large numbers that such a D would swamp.
+  uint32_t ppk[NT][8], dpk[NT][8];                   // packed bf16 pairs: registers (2i, 2i+1) of tile t
+  const int q = wave * 32 + (lane & 31);
+  if (wave < NTq) {
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = ld_rm(Qs, q, kk * 2 + g);
+      dof[kk] = ld_rm(dOs, q, kk * 2 + g);
+    }
+    const float lq = lse[q];
+    const int qpos = q + qc0 + p.q_off - p.kv_off;
+    const float neg2c = fmaxf(p.mask_neg * LOG2E, -3.4028234e38f);
+    const uint32_t rowkey = drop ? drop_rowkey(seed, headbase + qc0 + q) + (uint32_t)(2 * g) * DROP_WEYL : 0u;
+    f32x16 dp[NT];
+    uint32_t keepbits[NT];
+    float dloc = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 st = zero16();
+      dp[t] = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        st = MFMA32(ld_rm(Ks, t * 32 + (lane & 31), kk * 2 + g), qf[kk], st);
+        dp[t] = MFMA32(ld_rm(Vs, t * 32 + (lane & 31), kk * 2 + g), dof[kk], dp[t]);
+      }
+      uint32_t kb = 0xffffu;                           // bit r: probability (q, kv(r)) survived dropout in forward
+      if (drop) {
+        kb = 0;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const uint32_t r0 = drop_pair(rowkey, t * 16 + 4 * gq), r1 = drop_pair(rowkey, t * 16 + 4 * gq + 1);   // (the lane's 2g is inside rowkey)
+          kb |= ((r0 & 0xffffu) >= p.drop_thresh16 ? 1u : 0u) << (gq * 4);
+          kb |= ((r0 >> 16) >= p.drop_thresh16 ? 2u : 0u) << (gq * 4);
+          kb |= ((r1 & 0xffffu) >= p.drop_thresh16 ? 4u : 0u) << (gq * 4);
+          kb |= ((r1 >> 16) >= p.drop_thresh16 ? 8u : 0u) << (gq * 4);
+        }
+      }
+      keepbits[t] = kb;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {                 // registers 4*gq .. 4*gq+3: the 4 consecutive keys t*32 + 8*gq + 4*g + {0..3}
+        const int kv0 = t * 32 + 8 * gq + 4 * g;
+        f32x4 b = *(const f32x4*)(mb + kv0);
+        if (causal) {                                  // workgroup-uniform
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = kv0 + j > qpos ? fminf(b[j], neg2c) : b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] -= lq;          // (lq already in units of log2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = gq * 4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], 0.125f * LOG2E, b[j]));
+          float dpr = dp[t][r];
+          // dropout: dP is only MASKED here (bit r of kb, sign-extended to an all-ones word); the factor 1 / (1 - p) is linear in
+          // everything downstream (D, dS, P~) and is applied once to the dQ / dK / dV accumulators at their stores
+          if (drop) dpr = __builtin_bit_cast(float, __builtin_bit_cast(int, dpr) & __builtin_amdgcn_sbfe((int)kb, r, 1));
+          st[r] = pr;
+          dp[t][r] = dpr;
+          dloc += pr * dpr;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ppk[t][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
+    }
+    dloc += __shfl_xor(dloc, 32, 64);
+    if (p.d_mode == 1) {
+      if (g == 0 && q < Lq) p.Dbuf[headbase + qc0 + q] = dloc;
+    } else if (p.d_mode == 2) {
+      dloc = q < Lq ? p.Dbuf[headbase + qc0 + q] : 0.f;
+    }
+    if (p.d_mode != 1) {
+      f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t kb = keepbits[t];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = up_lo(ppk[t][i]), p1 = up_hi(ppk[t][i]);
+          dpk[t][i] = pk2(p0 * (dp[t][2 * i] - dloc), p1 * (dp[t][2 * i + 1] - dloc));
+          if (drop)                                     // P~ = P masked (the packed bf16 pair AND a per-half all-ones / zero word)
+            ppk[t][i] &= ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i, 1) & 0xffffu) |
+                         ((uint32_t)__builtin_amdgcn_sbfe((int)kb, 2 * i + 1, 1) & 0xffff0000u);
+        }
+        {
+          const u32x4 w0 = {dpk[t][0], dpk[t][1], dpk[t][2], dpk[t][3]}, w1 = {dpk[t][4], dpk[t][5], dpk[t][6], dpk[t][7]};
+          const bf16x8 ds0 = __builtin_bit_cast(bf16x8, w0), ds1 = __builtin_bit_cast(bf16x8, w1);
+          bf16x8 kf0[2], kf1[2];
+          ld_tr2x2(Ks, t * 32, lane, kf0, kf1);
+          dq[0] = MFMA32(kf0[0], ds0, dq[0]);
+          dq[1] = MFMA32(kf0[1], ds0, dq[1]);
+          dq[0] = MFMA32(kf1[0], ds1, dq[0]);
+          dq[1] = MFMA32(kf1[1], ds1, dq[1]);
+        }
+      }
+      {
+        // No LDS is free here (Q and dO are read again in phase B), so the 8-byte pieces are widened in registers instead: lanes l
+        // and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands lane l the other half of the
+        // EVEN chunks and lane l + 32 the other half of the ODD ones: four 16-byte stores per lane instead of eight 8-byte ones.
+        bf16* dQg = p.dQ + (qrow + q) * p.lddq + h * HD + 8 * g;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int e = (2 * j) * 4, o = (2 * j + 1) * 4;
+            uint32_t e0 = pk2(dq[dt][e] * qsc, dq[dt][e + 1] * qsc), e1 = pk2(dq[dt][e + 2] * qsc, dq[dt][e + 3] * qsc);
+            uint32_t o0 = pk2(dq[dt][o] * qsc, dq[dt][o + 1] * qsc), o1 = pk2(dq[dt][o + 2] * qsc, dq[dt][o + 3] * qsc);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+            if (q < Lq) *(u32x4*)(dQg + dt * 32 + 16 * j) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
+      }
+    }
+  }
+  if (p.d_mode == 1) return;   // partial-D pass: nothing else is written
+
+  // ---- phase B: wave owns kv tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
+  __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
+  if (wave < NTq) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)(X + xoff<256>(q, t * 8 + 2 * gq + g)) = u32x2{ppk[t][2 * gq], ppk[t][2 * gq + 1]};
+      }
+  }
+  __syncthreads();
+  const int kv = wave * 32 + (lane & 31);
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  if (wave < NT) {
+    for (int qt = 0; qt < NTq; ++qt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = ld_xt<256>(X, qt * 32 + hf * 16, wave * 32, lane);
+        bf16x8 dof[2];
+        ld_tr2(dOs, qt * 32 + hf * 16, lane, dof);
+        dv[0] = MFMA32(dof[0], pf, dv[0]);
+        dv[1] = MFMA32(dof[1], pf, dv[1]);
+      }
+  }
+  __syncthreads();             // P~ consumed: region X becomes the dS tile
+  if (wave < NTq) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)(X + xoff<256>(q, t * 8 + 2 * gq + g)) = u32x2{dpk[t][2 * gq], dpk[t][2 * gq + 1]};
+      }
+  }
+  __syncthreads();
+  if (wave < NT) {
+    for (int qt = 0; qt < NTq; ++qt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 dsf = ld_xt<256>(X, qt * 32 + hf * 16, wave * 32, lane);
+        bf16x8 qf[2];
+        ld_tr2(Qs, qt * 32 + hf * 16, lane, qf);
+        dk[0] = MFMA32(qf[0], dsf, dk[0]);
+        dk[1] = MFMA32(qf[1], dsf, dk[1]);
+      }
+  }
+  // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
+  // once all waves are past their last read, and the kv-wave w transposes through bytes [8192 w, 8192 w + 8192) of region X
+  // (X >= 2 NT x 4 KiB).
+  __syncthreads();
+  if (wave < NT) {
+    char* T = X + wave * 8192;
+    const int row = lane & 31;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int off = row * 128 + ((((dt * 4 + gq) ^ (row & 7)) << 4) | (g << 3));
+        *(bf16x4*)(T + off) = to_bf16x4(dk[dt][gq * 4] * qsc, dk[dt][gq * 4 + 1] * qsc, dk[dt][gq * 4 + 2] * qsc, dk[dt][gq * 4 + 3] * qsc);
+        *(bf16x4*)(T + 4096 + off) = to_bf16x4(dv[dt][gq * 4] * dsc, dv[dt][gq * 4 + 1] * dsc, dv[dt][gq * 4 + 2] * dsc, dv[dt][gq * 4 + 3] * dsc);
+      }
+    const int r8 = lane >> 3, c = lane & 7;
+    bf16* dKg = p.dK + (dkvrow + wave * 32 + r8) * p.lddk + h * HD + c * 8;
+    bf16* dVg = p.dV + (dkvrow + wave * 32 + r8) * p.lddv + h * HD + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = (r8 + 8 * i) * 128 + ((c ^ (r8 & 7)) << 4);
+      u32x4 vk = *(const u32x4*)(T + o), vv = *(const u32x4*)(T + 4096 + o);
+      if (wave * 32 + r8 + 8 * i < Lkv) {
+        if (p.acc_dkv) {
+          const u32x4 ok = *(const u32x4*)(dKg + (long)(8 * i) * p.lddk), ov = *(const u32x4*)(dVg + (long)(8 * i) * p.lddv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vk[e] = pk2(up_lo(vk[e]) + up_lo(ok[e]), up_hi(vk[e]) + up_hi(ok[e]));
+            vv[e] = pk2(up_lo(vv[e]) + up_lo(ov[e]), up_hi(vv[e]) + up_hi(ov[e]));
+          }
+        }
+        *(u32x4*)(dKg + (long)(8 * i) * p.lddk) = vk;
+        *(u32x4*)(dVg + (long)(8 * i) * p.lddv) = vv;
+      }
+    }
+  }
+}
+
+// The general body: NT = 3 (four waves; its tile-by-tile schedule fits the 168-register bound of three workgroups per CU, which the body
+// above overflows by 68 spilled registers: 96 x 96 runs 131 us here against 215 there) and NT = 5..8 (eight waves, keys split in halves).
+template <int NT>   // NT = ceil(Lkv / 32)
+__global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_wide_kernel(AttnP p) {
+  constexpr bool TILEWISE = true;                    // (fenced tile loops: what keeps NT = 3 inside its register bound)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // NT <= 4: four waves, wave w owns query tile w against all keys.  NT > 4 (SPLIT): eight waves, wave (qw, hv) owns query tile qw
   // against key tiles 4 hv .. 4 hv + 3 -- the register footprint of the four-tile form, two waves per SIMD -- and the two halves of a
@@ -301,10 +565,6 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
   const uint64_t headbase = ((uint64_t)seq * p.nH + h) * (uint64_t)p.Lq;
   const int NTq = (nq + 31) >> 5;
   const float dsc = drop ? p.drop_scale : 1.f, qsc = 0.125f * dsc;     // (see the dropout note in phase A)
-  // causal sequences whose key 0 is attended: (query tile, key tile) pairs wholly above the diagonal hold P = 0 exactly and are
-  // skipped, as in the forward (never in the chunked path of sequences longer than 256)
-  const bool skip_ok = causal && p.q_off == 0 && p.kv_off == 0 && p.d_mode == 0 && __builtin_amdgcn_readfirstlane((int)(mb[0] == 0.f));
-  const int qt0 = qc0 >> 5;                            // global index of the chunk's first query tile
 
   // ---- phase A: a wave owns query tile `qw` (and, SPLIT, one half of the keys): ONE pass over the scores gives D[q] = sum_kv P dP
   // (fp32, exactly consistent with ds), dQ, and the two [q][kv] tiles phase B contracts over q: P~ (dropout applied) and
@@ -317,8 +577,8 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
   const int ql = qw * 32 + (lane & 31);              // row inside the chunk
   const int q = qc0 + ql;                            // row inside the sequence
   const int t0 = hv * 4;                             // first key tile of this wave
-  const int tlast = skip_ok ? qt0 + qw : NT - 1;     // last key tile this wave's rows can see
   const int ntl = NT - t0 < NTL ? NT - t0 : NTL;     // local tiles that exist
+  const int tlast = __builtin_amdgcn_readfirstlane(NT - 1 - (p.nseq < 0 ? NT : 0));     // = NT - 1, opaque to the compiler (ATT_TILE_ON)
   const bool act = qw < NTq;
   float dloc = 0.f;
   if (act) {
@@ -336,7 +596,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
       const int t = t0 + tl;
-      if (tl >= ntl || t > tlast) continue;            // (wave-uniform) no such tile / nothing of it is visible: P = dS = 0, never stored
+      if (tl >= ntl || !ATT_TILE_ON(t)) continue;      // (wave-uniform; SPLIT with NT < 8) no such tile
       f32x16 st = zero16();
       dp[tl] = zero16();
 #pragma unroll
@@ -382,7 +642,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) ppk[tl][i] = pk2(st[2 * i], st[2 * i + 1]);     // P (before dropout), bf16: input of dS and P~
-    }
+      }
     dloc += __shfl_xor(dloc, 32, 64);
     if (SPLIT) {
       if (g == 0) dpart[hv * 128 + ql] = dloc;
@@ -402,7 +662,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
       const int t = t0 + tl;
-      if (tl >= ntl || t > tlast) continue;
+      if (tl >= ntl || !ATT_TILE_ON(t)) continue;
       const uint32_t kb = keepbits[tl];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -422,7 +682,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
         dq[0] = MFMA32(kf1[0], ds1, dq[0]);
         dq[1] = MFMA32(kf1[1], ds1, dq[1]);
       }
-    }
+      }
   }
   // dQ leaves from registers.  No LDS is free at this point of the four-wave form (Q and dO are read again in phase B), so the 8-byte
   // pieces are widened in registers: lanes l and l + 32 hold the two halves of every 16-byte chunk of a row -- v_permlane32_swap hands
@@ -445,14 +705,12 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
   if (!SPLIT && act) store_dq();
 
   // ---- phase B: a wave owns key tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
-  // (a (query tile, key tile) pair above the causal diagonal holds zeros -- or, for key tiles past tlast, was never written -- and is
-  // skipped: pair (qt, kt) is live iff kt <= qt0 + qt)
   __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
   if (act) {
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
       const int t = t0 + tl;
-      if (tl < ntl && t <= tlast) {
+      if (tl < ntl) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -476,10 +734,9 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
     store_dq();
   }
   const int kt = wave;
-  const int qtb = skip_ok && kt > qt0 ? kt - qt0 : 0;      // first query tile of the chunk that sees key tile kt
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   if (kt < NT) {
-    for (int qt = qtb; qt < NTq; ++qt)
+    for (int qt = 0; qt < NTq; ++qt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 pf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
@@ -494,7 +751,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
       const int t = t0 + tl;
-      if (tl < ntl && t <= tlast) {
+      if (tl < ntl) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -505,7 +762,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
   }
   __syncthreads();
   if (kt < NT) {
-    for (int qt = qtb; qt < NTq; ++qt)
+    for (int qt = 0; qt < NTq; ++qt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 dsf = ld_xt<RB>(X, qt * 32 + hf * 16, kt * 32, lane);
@@ -633,9 +890,9 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
   // > 64 KiB dynamic LDS needs the opt-in: once per process (function-local static: initialised exactly once, thread-safe --
   // backward entries are called from autograd worker threads)
   static const hipError_t attr_rc = [] {
-    const void* fns[8] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<3>,
-                          (const void*)attn_bwd_kernel<4>, (const void*)attn_bwd_kernel<5>, (const void*)attn_bwd_kernel<6>,
-                          (const void*)attn_bwd_kernel<7>, (const void*)attn_bwd_kernel<8>};
+    const void* fns[8] = {(const void*)attn_bwd_kernel<1>, (const void*)attn_bwd_kernel<2>, (const void*)attn_bwd_kernel<4>,
+                          (const void*)attn_bwd_wide_kernel<3>, (const void*)attn_bwd_wide_kernel<5>, (const void*)attn_bwd_wide_kernel<6>,
+                          (const void*)attn_bwd_wide_kernel<7>, (const void*)attn_bwd_wide_kernel<8>};
     for (int i = 0; i < 8; ++i) {
       hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
       if (e != hipSuccess) return e;
@@ -668,12 +925,12 @@ extern "C" int spmm_attn_bwd(const void* Q, long ldq, const void* K, long ldk, c
     switch (nt) {
       case 1: hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
       case 2: hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      case 3: hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
+      case 3: hipLaunchKernelGGL(attn_bwd_wide_kernel<3>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
       case 4: hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(nH, nseq), dim3(256), lds_b, stream, p); break;
-      case 5: hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
-      case 6: hipLaunchKernelGGL(attn_bwd_kernel<6>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
-      case 7: hipLaunchKernelGGL(attn_bwd_kernel<7>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
-      default: hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      case 5: hipLaunchKernelGGL(attn_bwd_wide_kernel<5>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      case 6: hipLaunchKernelGGL(attn_bwd_wide_kernel<6>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      case 7: hipLaunchKernelGGL(attn_bwd_wide_kernel<7>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
+      default: hipLaunchKernelGGL(attn_bwd_wide_kernel<8>, dim3(nH, nseq), dim3(512), lds_b, stream, p); break;
     }
   }
   SPMM_LAUNCH_CHECK("spmm_attn_bwd");

@@ -34,6 +34,8 @@ for nm, nseq, Lq, Lkv, cross in (("self PV 54x54", 512, 54, 54, False), ("self t
     O = torch.empty(nseq * Lq, H, device=dev, dtype=BF); lse = torch.empty(nseq, nH, Lq, device=dev)
     dO = torch.randn(nseq * Lq, H, device=dev).to(BF); dQ = torch.empty_like(O); dKV = torch.empty(nseq * Lkv, 2 * H, device=dev, dtype=BF)
     out = []
+    if max(Lq, Lkv) > 128 and os.environ.get("SPMM_HIP_LIB", "").endswith("oldattn.so"):
+        continue
     for p in (0.0, 0.1):
         kw = dict(nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, is_cross=cross, dropout_p=p, seed=seed, salt=3, causal_from=0 if causal else None)
         out.append(timeit(lambda: ops.attn_fwd(Q, K, V, O, lse, **kw)))
