@@ -46,7 +46,9 @@ add("ln_fwd (dropout+residual+LN)", f"{M}x{H}", lambda: ops.ln_fwd(x, r, g, b, y
 add("ln_bwd (+dropout, dgamma, dbias)", f"{M}x{H}", lambda: ops.ln_bwd(x, z, mean, rstd, g, dz, dx=dx, dgamma=dg, dbeta=db, dropout_p=0.1, seed=seed, salt=7, dxsum=dxs), 4 * row)
 
 # attention at the S6 shapes: 512 sequences, 12 heads
-for nm, nseq, Lq, Lkv, cross in (("self PV", 512, 54, 54, False), ("self text", 512, 128, 128, False), ("cross PV->text", 512, 54, 128, True), ("cross text->PV", 512, 128, 54, True)):
+for nm, nseq, Lq, Lkv, cross in (("self PV", 512, 54, 54, False), ("self text", 512, 128, 128, False), ("cross PV->text", 512, 54, 128, True), ("cross text->PV", 512, 128, 54, True),
+                                 ("self text, Lt = 256 (configs[4])", 512, 256, 256, False), ("cross PV->text, Lt = 256", 512, 54, 256, True),
+                                 ("cross text->PV, Lt = 256", 512, 256, 54, True)):
     nH = 12
     q = torch.randn(nseq * Lq, 3 * H, device=dev).to(BF); kv = torch.randn(nseq * Lkv, 2 * H, device=dev).to(BF)
     Q, K, V = (q[:, :H], kv[:, :H], kv[:, H:]) if cross else (q[:, :H], q[:, H:2 * H], q[:, 2 * H:])
