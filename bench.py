@@ -414,6 +414,13 @@ def main():
         allseen = torch.empty(world, dtype=torch.int32, device=dev)
         torch.distributed.all_gather_into_tensor(allseen, seen)
         rccl_ranks = {"backend": torch.distributed.get_backend(), "world_size_seen_by_rank": allseen.cpu().tolist()}
+    n_check = 0
+    if sync is not None and opts.schedule_check and opts.multi_stream:
+        # the model's own schedule check (spmm_amd/model.py: both stream schedules tried over its first 12 steps) runs BEFORE the warm-up:
+        # extra untimed steps, reported as `schedule_check_steps`
+        n_check = model.SCHEDULE_CHECK_STEPS
+        for i in range(n_check):
+            one_step(i)
     for i in range(args.warmup):
         losses = one_step(i)
         if world > 1 and i == 1:         # replicas must agree from the start (no per-step buffer broadcast): checked after 2 steps, untimed
@@ -601,6 +608,8 @@ def main():
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses, "hbm": hbm}
+    if n_check:
+        out["schedule_check_steps"] = n_check
     from spmm_amd import streams
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks

@@ -132,6 +132,7 @@ class Engine:
         # nothing there (412 vs 408 ms per step at B = 512, Lt = 256) and every stream keeps its own allocator pool -- 228 GB peak /
         # 286 GB reserved of 288 on three streams (one allocator retry = a multi-second step) against 160 / 207 GB on one.
         self._one_stream = False
+        self.force_one_stream = False     # set by the data-parallel schedule check (model.py::_schedule_check)
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self._tn_pend = {}                                  # chained weight-gradient GEMMs: stream handle -> slab reduction still pending there
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration

@@ -330,6 +330,7 @@ class SPMM(_Base):
         packed GEMMs without the one blocking device read the step otherwise needs.  Returns the device tensor of the four losses."""
         eng, opt = self.engine, self.optimizers()
         eng.train_mode = self.training
+        check = self._schedule_check_begin(grad_sync)
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
         self.store.grad.zero_()
@@ -359,7 +360,48 @@ class SPMM(_Base):
             if grad_sync is not None:
                 grad_sync(self.store.grad)
         opt.step()
+        if check is not None:
+            check.record(torch.cuda.current_stream())
         return losses
+
+    # Data-parallel runs only (EngineOptions.schedule_check): the first SCHEDULE_CHECK_STEPS steps try both schedules -- steps 0-3 on the
+    # side streams to warm up (allocator pools grow while batches of new packed sizes arrive), 4-6 timed, 7-8 on one stream to warm its
+    # pool, 9-11 timed -- and the faster one runs from step 12 on, the single stream only if its median wins by 13 % or more.  On every node
+    # measured so far the three-stream schedule is 5-9 % faster; with some orders of stream creation next to RCCL's stream it runs at 80 ms
+    # instead of 60 (EXPERIMENTS.md 1.4), and this package has never run next to a multi-rank communicator.  Both schedules give the same
+    # results bit for bit; the events are read once, at the decision.
+    SCHEDULE_CHECK_STEPS = 12
+
+    def _schedule_check_begin(self, grad_sync):
+        eng = self.engine
+        st = getattr(self, "_sched", None)
+        if st is None:
+            on = (grad_sync is not None and eng.opt.schedule_check and eng.multi_stream and self.device_.type == "cuda"
+                  and not getattr(ops, "_DRY_RUN", False))
+            st = self._sched = {"n": 0, "on": on, "ev": []}
+        if not st["on"]:
+            return None
+        n = st["n"]
+        if n >= self.SCHEDULE_CHECK_STEPS:
+            ms = {"three streams": [], "one stream": []}
+            for e0, e1, which in st["ev"]:
+                e1.synchronize()
+                ms[which].append(e0.elapsed_time(e1))
+            multi, single = (sorted(v)[len(v) // 2] for v in (ms["three streams"], ms["one stream"]))
+            keep_single = single <= 0.87 * multi
+            eng.force_one_stream = keep_single
+            st["on"], st["ev"] = False, []
+            from . import streams
+            streams.note(f"schedule check: median {multi:.1f} ms on three streams, {single:.1f} ms on one -> " + ("ONE stream kept" if keep_single else "three streams kept"))
+            return None
+        eng.force_one_stream = n >= 7
+        st["n"] = n + 1
+        if n in (4, 5, 6, 9, 10, 11):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            st["ev"].append((e0, e1, "three streams" if n < 7 else "one stream"))
+            return e1
+        return None
 
     def fused_step_graphed(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None):
         """The same step as ONE hipGraph launch (single rank; SPMM_models.py:348-380 has no counterpart -- this removes the ~26 ms

@@ -75,7 +75,7 @@ class PretrainStep(Engine):
         # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
         # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
         self.hint_bad.zero_()
-        self._one_stream = B * Lt > STREAM_TOKENS_MAX
+        self._one_stream = self.force_one_stream or B * Lt > STREAM_TOKENS_MAX
         pk = self._pack_plan(mask32, B, Lt, n_tokens) if (self.pack_text and aux is None and Lt <= ops.ATTN_MAXL) else None   # packed layouts: what the attention kernels hold on chip
         if n_tokens is not None:
             self.nan_flag.bitwise_or_(self.hint_bad)

@@ -1047,7 +1047,7 @@ def test_rccl_code_path_single_rank(env):
     outs = []
     for force, wire in (("1", "fp32"), ("0", "fp32"), ("1", "bf16")):
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-        envv = dict(os.environ, SPMM_FORCE_DIST=force, SPMM_GRAD_WIRE=wire, MASTER_PORT=str(port))
+        envv = dict(os.environ, SPMM_FORCE_DIST=force, SPMM_GRAD_WIRE=wire, MASTER_PORT=str(port), SPMM_SCHEDULE_CHECK="0")   # (same step count in all three)
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=envv, cwd=root)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["losses"])
@@ -1056,6 +1056,29 @@ def test_rccl_code_path_single_rank(env):
     np.testing.assert_allclose(outs[0], outs[1], rtol=3e-3, atol=0)
     # bf16 reduce-scatter + all-gather of the gradients (RCCL, one rank): gradients rounded to bf16 before AdamW
     np.testing.assert_allclose(outs[2], outs[1], rtol=2e-2, atol=0)
+
+
+def test_data_parallel_schedule_check_times_both_schedules_and_decides(env):
+    """EngineOptions.schedule_check (data-parallel runs): the first 12 steps try the three-stream and the one-stream schedule (bench.py runs
+    them before its warm-up), the decision is reported in `stream_placement`; the losses of the run equal those of a run without the check at
+    the same step count (both schedules give the same results).  One-rank RCCL group."""
+    import subprocess, sys, json, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--batch", "8", "--seq-len", "32", "--layers", "2,1,1",
+            "--queue", "64", "--no-cpu-baseline", "--no-kernel-timing", "--eval-mode"]
+    res = {}
+    for chk in ("1", "0"):
+        cmd = base + ["--warmup", "2" if chk == "1" else "14"]          # 12 check steps + 2 = 14 untimed steps either way
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root,
+                             env=dict(os.environ, SPMM_FORCE_DIST="1", SPMM_SCHEDULE_CHECK=chk, MASTER_PORT=str(port)))
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        res[chk] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    notes = " | ".join(res["1"].get("stream_placement", []))
+    print(notes)
+    assert "schedule check:" in notes and ("three streams kept" in notes or "ONE stream kept" in notes) and res["1"]["schedule_check_steps"] == 12
+    assert "schedule check:" not in " | ".join(res["0"].get("stream_placement", []))
+    np.testing.assert_allclose(res["1"]["losses"], res["0"]["losses"], rtol=3e-3, atol=0)
 
 
 @pytest.mark.parametrize("case", ["min_len", "full_len_128", "odd_33", "mask_holes", "one_long_rest_short"])
