@@ -39,6 +39,19 @@ def get(device, name: str) -> torch.cuda.Stream:
     return _pool[(idx, name)]
 
 
+def bind_in_order(device, names) -> None:
+    """First use of the named pool streams, in this order (one trivial kernel each): a stream gets its hardware queue at its first
+    use, and hardware queues are dealt round-robin over the four pipes of the compute micro-engine -- streams whose queue indices are
+    congruent mod 4 share a pipe, which serves one queue at a time (EXPERIMENTS.md 2.7b)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = torch.zeros(8, device=f"cuda:{idx}")
+    for n in names:
+        with torch.cuda.stream(get(idx, n)):
+            t.add_(1.0)
+    torch.cuda.synchronize(idx)
+
+
 def handles(device=None) -> Dict[str, int]:
     return {n: s.cuda_stream for (i, n), s in _pool.items() if device is None or i == torch.device(device).index}
 
