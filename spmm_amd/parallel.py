@@ -180,10 +180,10 @@ def grad_sync_fn(store=None, options: Optional[EngineOptions] = None):
             dist.all_reduce(t, async_op=True).wait()
             torch.cuda.synchronize(dev)
             if not late:
-                # ... and the streams of a data-parallel step take their hardware queues NOW, in the order measured fast: queue 0 the
-                # caller's stream, 1 RCCL's, 2 / 3 the side streams, 4 the observer -- five busy streams on the four pipes of the
-                # compute micro-engine, the observer (it only waits for collectives) sharing the caller's.  The orders that put the
-                # observer or a side stream on RCCL's pipe run the step at 79-87 ms instead of 60.5 (EXPERIMENTS.md 2.7b).
+                # ... and the streams of a data-parallel step take their hardware queues NOW, in the order measured fast (RCCL's stream,
+                # side0, side1, observer).  A stream gets its queue at its first use and there are only a handful: orders that make
+                # RCCL's stream share one with a stream it exchanges dependencies with run the step at 79-87 ms instead of 60.5
+                # (EXPERIMENTS.md 2.7b, profiles/r04_stream_order.txt).
                 streams.bind_in_order(dev, ("side0", "side1", "observer"))
             streams.note(f"cuda:{dev}: first collective issued " + ("AFTER the compute side streams existed (an order EXPERIMENTS.md 2.7b measured slow is possible)"
                                                                      if late else "first, then side0, side1, observer bound to hardware queues in that order"))
