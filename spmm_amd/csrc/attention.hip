@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
   const int Lq0 = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
   const int qc0 = p.qc0, Lq = Lq0 - qc0 < 128 ? Lq0 - qc0 : 128;
-  if (Lq <= 0) return;
+  if (Lq <= 0 && qc0 > 0) return;              // (a later chunk of a short packed sequence: nothing to add; workgroup-uniform)
   const long qrow = (p.q_row0 ? (long)p.q_row0[seq] : (long)seq * p.Lq) + qc0;
   const long kvrow = p.kv_row0 ? (long)p.kv_row0[kvs] : kvs * p.Lkv;
   const long dkvrow = p.kv_seq ? (long)seq * p.Lkv : kvrow;     // shared sources: dK/dV per query sequence, dense
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
   const long kvs = p.kv_seq ? (long)p.kv_seq[seq] : (long)seq;
   const int Lq = p.q_len ? p.q_len[seq] : p.Lq, Lkv = p.kv_len ? p.kv_len[kvs] : p.Lkv;
   const int qc0 = p.qc0, nq = Lq - qc0 < 128 ? Lq - qc0 : 128;   // this launch's query rows of the sequence: [qc0, qc0 + nq)
-  if (nq <= 0) return;                               // (a later chunk of a short packed sequence: nothing to add; workgroup-uniform)
+  if (nq <= 0 && qc0 > 0) return;                    // (a later chunk of a short packed sequence: nothing to add; workgroup-uniform)
   // LDS holds only the 32-row tiles in use (K, V: NT tiles; Q, dO: the chunk's tiles of the longest sequence)
   const int ntq_max = p.Lq - qc0 >= 128 ? 4 : (p.Lq - qc0 + 31) >> 5;
   const int kvb = NT * 32 * 128, qb = ntq_max * 32 * 128, xb = bwd_xbytes(NT, ntq_max);

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--every", type=int, default=25)
 ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--seq-len", type=int, default=128, help="256: BASELINE configs[4]'s sequence length (the attention kernels' long-key forms)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross_attention=True),
@@ -21,7 +22,7 @@ tc = {'embed_dim': 256, 'temp': 0.07, 'mlm_probability': 0.15, 'queue_size': 368
 torch.manual_seed(42)
 model = SPMM(config=tc, spmm_config=cfg, loader_len=1000).train()
 model.store.refresh_shadows()
-batches = [bench.synthetic_batch(a.batch, 128, 42 + i, dev) for i in range(4)]
+batches = [bench.synthetic_batch(a.batch, a.seq_len, 42 + i, dev) for i in range(4)]
 opt = model.optimizers()
 t0 = time.time()
 print(f"{'step':>5s} {'mlm':>9s} {'5*mpm':>9s} {'ita':>9s} {'itm':>9s} {'|g|':>10s} {'temp':>7s}")
