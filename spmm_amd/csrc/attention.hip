@@ -507,10 +507,18 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void attn_bwd_kernel(AttnP p)
 
 // The general body: NT = 3 (four waves; its tile-by-tile schedule fits the 168-register bound of three workgroups per CU, which the body
 // above overflows by 68 spilled registers: 96 x 96 runs 131 us here against 215 there) and NT = 5..8 (eight waves, keys split in halves).
+// tools/ only (make -C tools ../build/libspmm_hip_attprof.so, tools/prof_attn.py): s_memtime stamps of every wave at the phase boundaries go to
+// Dbuf (unused when d_mode = 0)
+#ifdef ATT_PROFILE
+#define ATT_STAMP(K) do { if (p.Dbuf && (threadIdx.x & 63) == 0) ((unsigned long long*)p.Dbuf)[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_STAMP(K) do { } while (0)
+#endif
 template <int NT>   // NT = ceil(Lkv / 32)
 __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_wide_kernel(AttnP p) {
   constexpr bool TILEWISE = true;                    // (fenced tile loops: what keeps NT = 3 inside its register bound)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATT_STAMP(0);
   // NT <= 4: four waves, wave w owns query tile w against all keys.  NT > 4 (SPLIT): eight waves, wave (qw, hv) owns query tile qw
   // against key tiles 4 hv .. 4 hv + 3 -- the register footprint of the four-tile form, two waves per SIMD -- and the two halves of a
   // row exchange their partial D = sum P dP and their partial dQ through LDS.
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
     if (tid < 128) lse[tid] = tid < nq ? p.LSE[((long)seq * p.nH + h) * p.Lq + qc0 + tid] * LOG2E : INFINITY;
   }
   __syncthreads();
+  ATT_STAMP(1);
 
   const bool causal = seq >= p.causal_from;
   const bool drop = p.drop_thresh16 != 0;
@@ -653,10 +662,12 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
     }
   }
   if (!SPLIT && p.d_mode == 1) return;   // partial-D pass: nothing else is written
+  ATT_STAMP(2);
   if (SPLIT) {
     __syncthreads();                     // both key halves of every row have left their partial D
     if (act) dloc = dpart[ql] + dpart[128 + ql];
   }
+  ATT_STAMP(3);
   f32x16 dq[2] = {zero16(), zero16()};
   if (act) {
 #pragma unroll
@@ -703,9 +714,11 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
       }
   };
   if (!SPLIT && act) store_dq();
+  ATT_STAMP(4);
 
   // ---- phase B: a wave owns key tile `wave`; dV^T = dO^T P~ and dK^T = Q^T dS contract over q with the tiles phase A left.
   __syncthreads();             // every wave is done reading K and V: region X becomes the P~ tile
+  ATT_STAMP(5);
   if (act) {
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
@@ -733,6 +746,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
       for (int r = 0; r < 16; ++r) dq[dt][r] += EX[(qw * 32 + dt * 16 + r) * 64 + lane];
     store_dq();
   }
+  ATT_STAMP(6);
   const int kt = wave;
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   if (kt < NT) {
@@ -746,7 +760,9 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
         dv[1] = MFMA32(dof[1], pf, dv[1]);
       }
   }
+  ATT_STAMP(7);
   __syncthreads();             // P~ consumed: region X becomes the dS tile
+  ATT_STAMP(8);
   if (act) {
 #pragma unroll
     for (int tl = 0; tl < NTL; ++tl) {
@@ -761,6 +777,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
     }
   }
   __syncthreads();
+  ATT_STAMP(9);
   if (kt < NT) {
     for (int qt = 0; qt < NTq; ++qt)
 #pragma unroll
@@ -772,10 +789,12 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
         dk[1] = MFMA32(qf[1], dsf, dk[1]);
       }
   }
+  ATT_STAMP(10);
   // dK and dV leave through LDS as whole 128-byte rows, 8 rows per store instruction (see the forward): every region of LDS is dead
   // once all waves are past their last read, and wave w transposes through bytes [8192 w, 8192 w + 8192) of region X (X >= 8 KiB per
   // wave that holds a key tile).  Launches for later query chunks add to what the earlier ones stored (p.acc_dkv).
   __syncthreads();
+  ATT_STAMP(11);
   if (kt < NT) {
     char* T = X + wave * 8192;
     const int row = lane & 31;
@@ -808,6 +827,7 @@ __global__ __launch_bounds__(NT > 4 ? 512 : 256, NT <= 3 ? 3 : 2) void attn_bwd_
       }
     }
   }
+  ATT_STAMP(12);
 }
 
 constexpr int ATTN_MAXL = 256;
