@@ -16,6 +16,12 @@ inputs / recorded random draws / outputs under ``tests/golden/``;
 ``tests/test_oracle_golden.py`` checks this file against those vectors (<=1e-5).
 The reference itself ships no tests or golden vectors.
 
+Besides the fp32 restatement there is a bf16 STORAGE MODEL (``with bf16_storage():``,
+below): the same functions with their tensors rounded to bfloat16 where the HIP product
+stores bfloat16.  It is a second yard-stick for tests -- it separates deviations that
+any bf16-storing implementation shares from kernel error -- not a second oracle: the
+golden vectors pin the fp32 path only.
+
 Every function cites the reference file:line it restates (paths relative to
 /root/reference).
 """
