@@ -132,6 +132,12 @@ class Engine:
         # nothing there (412 vs 408 ms per step at B = 512, Lt = 256) and every stream keeps its own allocator pool -- 228 GB peak /
         # 286 GB reserved of 288 on three streams (one allocator retry = a multi-second step) against 160 / 207 GB on one.
         self._one_stream = False
+        # A stream takes its hardware queue at its FIRST USE and there are only a handful of queues: a foreign stream first used between
+        # side0 and side1 ran the plain step at 71.6 ms instead of 59.4 (tools/first_steps.py, EXPERIMENTS.md 2.7b).  So the step's
+        # streams take their queues here, in one go.  (Data-parallel processes do it in parallel.grad_sync_fn, RCCL's stream first.)
+        if (self.multi_stream and torch.device(device).type == "cuda" and not ops._DRY_RUN
+                and not (torch.distributed.is_available() and torch.distributed.is_initialized())):
+            streams.bind_in_order(device, ("side0", "side1", "wgrad"))
         self.force_one_stream = False     # set by the data-parallel schedule check (model.py::_schedule_check)
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self._tn_pend = {}                                  # chained weight-gradient GEMMs: stream handle -> slab reduction still pending there

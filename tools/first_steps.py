@@ -6,6 +6,15 @@ from spmm_amd.config import BertConfig, SPMMConfig
 from spmm_amd.model import SPMM
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import spmm_oracle as O
+# SPMM_TOUCH_ORDER="wgrad,side0,x": first use of the pool streams (x = an unrelated stream) in this order before the model exists
+from spmm_amd import streams as _streams
+_extra = []
+for name in [t for t in os.environ.get("SPMM_TOUCH_ORDER", "").split(",") if t]:
+    st = torch.cuda.Stream() if name == "x" else _streams.get("cuda:0", name)
+    _extra.append(st)
+    with torch.cuda.stream(st):
+        torch.zeros(8, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
 torch.manual_seed(0)
 cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross_attention=True), prop=BertConfig(num_hidden_layers=6, fusion_layer=6, vocab_size=1),
                  embed_dim=256, queue_size=36864)
@@ -26,8 +35,8 @@ nt = int(mask.sum())
 for phase, one in (("three streams", False), ("one stream (streams)", True), ("three streams again", False)):
     m.engine.force_one_stream = one
     ts = []
-    for i in range(5):
+    for i in range(int(os.environ.get("FIRST_STEPS_N", "5"))):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.fused_step(prop, ids, mask, 0.4, n_tokens=nt, grad_sync=sync)
         torch.cuda.synchronize(); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
-    print(phase, ts, flush=True)
+    print(f"touch=[{os.environ.get('SPMM_TOUCH_ORDER', '')}]", phase, ts if len(ts) <= 6 else f"median of {len(ts)}: {sorted(ts)[len(ts) // 2]}", flush=True)
