@@ -234,3 +234,5 @@ if __name__ == "__main__":
     fixture_train("train_tiny_b4_l16", cfg, B=4, Lt=16, steps=5, seed=21)
     fixture_lr()
     fixture_wide("fwd_wide768_b4_l16", wide_cfg(), B=4, Lt=16, alpha=0.3, seed=33)
+    # BASELINE configs[4]'s sequence length on the REAL reference (toy widths, ragged lengths 128..256): pins the 256-long attention path
+    fixture_wide("fwd_tiny_b4_l256", cfg, B=4, Lt=256, alpha=0.3, seed=35)

@@ -147,6 +147,35 @@ def _wide_cfg():
     return cfg
 
 
+def test_seq_len_256_matches_reference(golden_dir):
+    """BASELINE configs[4]'s sequence length on the REAL reference (fixture fwd_tiny_b4_l256: toy widths, ragged lengths 128..256, train mode,
+    dropout 0): the oracle's losses, whole-gradient norm, per-tensor gradient checksums and queue head."""
+    g = _load(golden_dir, "fwd_tiny_b4_l256.npz")
+    cfg = O.tiny_cfg()
+    for c in (cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.closed_form_state_dict(cfg)
+    names = O.trainable_names(cfg)
+    for n in names:
+        sd[n].requires_grad_(True)
+    O._finish_tied(sd)
+    B, Lt = int(g["B"]), int(g["Lt"])
+    assert Lt == 256
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=int(g["seed"]))
+    neg = (torch.from_numpy(g["prop_neg_idx"]), torch.from_numpy(g["text_neg_idx"]))
+    losses = O.spmm_forward(sd, cfg, prop, ids, mask, float(g["alpha"]), mpm_mask=torch.from_numpy(g["mpm_mask"]), neg_idx=neg, train=True)
+    sum(losses).backward()
+    np.testing.assert_allclose([float(x) for x in losses], g["losses"], rtol=2e-5, atol=2e-5)
+    gn = torch.sqrt(sum((sd[n].grad.double() ** 2).sum() for n in names if sd[n].grad is not None)).item()
+    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=1e-4)
+    for k in g.files:
+        if k.startswith("gradsum::"):
+            gr = sd[k[9:]].grad.double()
+            np.testing.assert_allclose([gr.sum().item(), gr.abs().sum().item(), gr.norm().item()], g[k], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(sd["prop_queue"][:, :B].detach().numpy(), g["prop_queue_head"], atol=1e-5)
+    np.testing.assert_allclose(sd["text_queue"][:, :B].detach().numpy(), g["text_queue_head"], atol=1e-5)
+
+
 def test_wide_model_matches_reference(golden_dir):
     """The oracle at the REAL widths against the real reference (losses, whole-gradient norm, per-tensor gradient
     checksums, queue head): the toy-width fixtures alone would not exercise 12 heads of 64 or the 3072-wide FFN."""

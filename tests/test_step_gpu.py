@@ -27,6 +27,7 @@ LOSS_ATOL = {
     "edge_shapes":   [1e-3, 3e-3, 3.1e-3, 2.3e-3],      # worst over the five cases: 4.4e-4 / 1.9e-3 / 2.1e-3 / 1.5e-3
     "lt160":         [1e-3, 1.3e-3, 4.4e-3, 1e-3],      # measured 2.0e-4 / 8.6e-4 / 2.9e-3 / 1.2e-4
     "lt300":         [1e-3, 1.3e-3, 4.4e-3, 1e-3],      # (chunked attention path, > 256 tokens)
+    "lt256_golden":  [1e-3, 2.8e-3, 2.9e-3, 1e-3],      # vs the REAL reference at Lt = 256, toy widths, closed-form weights: measured 1.9e-6 / 1.83e-3 / 1.91e-3 / 4.6e-4
     "lt256_h768":    [1e-3, 1e-3, 1e-3, 1e-3],          # measured 5.2e-5 / 3.8e-4 / 6.5e-4 / 6.2e-4: BASELINE configs[4]'s sequence length at the published widths, 2+2 layers, packed rows
     "wide_golden":   [1e-3, 4.4e-3, 2e-2, 7.7e-3],      # measured 5.4e-4 / 2.9e-3 / 1.33e-2 / 5.1e-3 (closed-form weights ~0.08: sims up to 40)
     "grad_tiny":     [1e-3, 2.9e-3, 1.3e-3, 1e-3],      # measured 2.5e-4 / 1.9e-3 / 8.2e-4 / 4.0e-4
@@ -1216,6 +1217,33 @@ def test_seq_len_256_step_matches_oracle_at_published_widths(env):
     print("Lt=256 H=768 hip", got, "oracle", ref, "diff", np.abs(got - ref), f"whole gradient |g|={total_r:.4f} relative L2 error {glob:.5f}")
     assert_losses(got, ref, "lt256_h768")
     assert glob < 1.5e-2
+
+
+def test_seq_len_256_matches_reference_golden(env, golden_dir):
+    """HIP path vs the REAL reference at BASELINE configs[4]'s sequence length (fixture tests/golden/fwd_tiny_b4_l256.npz: toy widths, ragged
+    lengths 128..256, packed rows, the 256-key attention kernels forward and backward): losses, whole-gradient norm and the gradient norms of
+    four named tensors."""
+    O, SPMM, tiny_config, *_ = env
+    g = np.load(os.path.join(golden_dir, "fwd_tiny_b4_l256.npz"))
+    cfg = tiny_config()
+    for c in (cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    sd = O.closed_form_state_dict(O.tiny_cfg())
+    m = _mk(SPMM, cfg, sd).train()
+    B, Lt = int(g["B"]), int(g["Lt"])
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=int(g["seed"]))
+    losses = m(prop, ids, mask, alpha=float(g["alpha"]), mpm_mask=torch.from_numpy(g["mpm_mask"]).cuda(),
+               neg_idx=tuple(_cuda(torch.from_numpy(g["prop_neg_idx"]), torch.from_numpy(g["text_neg_idx"]))))
+    sum(losses).backward()
+    got = np.array([float(x) for x in losses])
+    gn = m.store.grad.double().norm().item()
+    print("Lt=256 golden: hip", got, "reference", g["losses"], "diff", np.abs(got - g["losses"]), "grad norm", gn, float(g["grad_norm"]))
+    assert_losses(got, g["losses"], "lt256_golden")
+    np.testing.assert_allclose(gn, float(g["grad_norm"]), rtol=5e-3)
+    for k in g.files:
+        if k.startswith("gradsum::"):
+            hn = m.store.g(k[9:]).double().norm().item()
+            assert abs(hn - g[k][2]) <= max(6e-2 * g[k][2], 5e-4 * float(g["grad_norm"])), (k, hn, g[k][2])
 
 
 def test_wide_model_matches_reference_golden(env, golden_dir):
