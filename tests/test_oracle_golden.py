@@ -137,6 +137,36 @@ def test_oracle_module_api_runs_beam_decode():
     assert [p for p, _ in hyps] == sorted([p for p, _ in hyps], reverse=True)
 
 
+def _decode_bias(seed, gap, vocab=300):
+    """oracle/make_golden_decode.py::peaky_bias."""
+    b = torch.randn(vocab, generator=torch.Generator().manual_seed(int(seed))) * 1.5
+    b[3] = b.max() - float(gap)
+    return b
+
+
+def test_beam_search_matches_the_reference_search(golden_dir):
+    """oracle/decode_oracle.py against the REAL reference's PV -> SMILES search (d_pv2smiles_batched.py:18-59 driving
+    d_pv2smiles_single.py:26-44; fixture by oracle/make_golden_decode.py): 18 molecules, k = 5, 100 steps, every molecule with its own
+    LM-head bias.  The best hypothesis is the reference's, token for token (1 to 32 tokens); where the reference finishes nothing within
+    its 100 steps (it raises on the empty list) the restatement returns no hypothesis."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = _load(golden_dir, "decode_tiny_k5.npz")
+    props, k = torch.from_numpy(g["props"]), int(g["k"])
+    assert sorted(set(g["best_len"].tolist())) == [0, 2, 3, 4, 23, 32]
+    for n in range(props.shape[0]):
+        sd = O.closed_form_state_dict(O.tiny_cfg())
+        b = _decode_bias(g["bias_seed"][n], g["sep_gap"][n])
+        sd["text_encoder.cls.predictions.bias"] = b
+        sd["text_encoder.cls.predictions.decoder.bias"] = b
+        hyps = decode_oracle.beam_search(O.OracleModule(sd, O.tiny_cfg()), props[n], k=k, max_steps=100)
+        want = g["best_ids"][n, :int(g["best_len"][n])].tolist()
+        if not want:
+            assert hyps == [], n
+        else:
+            assert hyps[0][1][:-1] == want and hyps[0][1][-1] == 3, (n, hyps[0][1], want)
+
+
 def _wide_cfg():
     """oracle/make_golden.py::wide_cfg: the published widths (H=768, 12 heads, I=3072, E=256), 2 text layers (1 fusion) + 1 PV."""
     t = O.BertCfg(num_hidden_layers=2, fusion_layer=1)

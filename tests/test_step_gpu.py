@@ -848,6 +848,30 @@ def test_batched_decode_of_many_molecules_against_the_oracle_search(env):
     assert same >= 0.9 * N
 
 
+def test_batched_decode_against_the_reference_search(env, golden_dir):
+    """The HIP decoder (K/V cache, batched) against the REAL reference's search (tests/golden/decode_tiny_k5.npz by
+    oracle/make_golden_decode.py: d_pv2smiles_batched.py:18-59 run in the dev container): 18 molecules with their own LM-head bias, k = 5, the
+    reference's 100 steps.  The best hypothesis must be the reference's token for token -- including the 23-token one -- and the three
+    molecules for which the reference finishes nothing must finish nothing here.  bf16 activations may flip a near-tie: at most 2 of the 18
+    may differ (measured: 1 -- the 32-token hypothesis, a cycle of three tokens whose [SEP] runner-up wins at position 19 in bf16)."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd import decode
+    g = np.load(os.path.join(golden_dir, "decode_tiny_k5.npz"), allow_pickle=False)
+    props, k = torch.from_numpy(g["props"]), int(g["k"])
+    same, diff = 0, []
+    for n in range(props.shape[0]):
+        sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), seed=int(g["bias_seed"][n]), sep_gap=float(g["sep_gap"][n]))
+        m = _mk(SPMM, tiny_config(), sd).eval()
+        got = decode.beam_search_batched(m, props[n:n + 1], k=k, max_steps=100)[0]
+        want = g["best_ids"][n, :int(g["best_len"][n])].tolist()
+        ok = (got == []) if not want else (bool(got) and got[0][1][:-1] == want and got[0][1][-1] == decode.SEP_ID)
+        same += int(ok)
+        if not ok:
+            diff.append((n, want, got[0][1] if got else None))
+    print(f"batched HIP decode vs the reference's search: {same} / {props.shape[0]} best hypotheses identical; differing: {diff}")
+    assert same >= props.shape[0] - 2, diff
+
+
 def _check_cached_beam_search(O, SPMM, tiny_config, decode, sep_gap):
     sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), sep_gap=sep_gap)
     m = _mk(SPMM, tiny_config(), sd).eval()
