@@ -20,6 +20,8 @@ struct DecAttnP {
   bf16* out; long ldo;
   int R, nH, Lkv; float scale;
   const int* t_ptr;             // optional device step index: the cache holds positions 0..*t_ptr, i.e. Lkv = *t_ptr + 1 (graph replay)
+  const bf16* knew; const bf16* vnew; long ldn;   // optional: key / value of the NEWEST position (Lkv - 1) of every row, not yet in the cache: read from
+  //                                                 here (row stride ldn) and written to the cache row by the wave that owns the (row, head)
 };
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
@@ -213,6 +215,20 @@ __global__ __launch_bounds__(256) void decode_attn_group_kernel(DecAttnP p) {
   }
 }
 
+// the newest position's key / value rows into the cache, in front of the attention launch (one launch for both; folding it into the
+// attention kernel itself -- the rows read from the projection output, written by the wave that owns the (row, head) -- was built and
+// measured: 40 more live registers or an exposed load between the two passes, 1.61 -> 1.78-1.92 ms of decode_attn per position)
+__global__ __launch_bounds__(256) void cache_write_kernel(DecAttnP p, int jn) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // 16-byte chunk of a row
+  const int per_row = p.nH * 8;
+  if (i >= (long)p.R * per_row) return;
+  const long r = i / per_row, c = (i - r * per_row) * 8;
+  const int j = p.t_ptr ? min(*p.t_ptr, p.Lkv - 1) : jn;
+  const long dst = r * p.seq_stride + (long)j * p.tok_stride + c;
+  *(bf16x8*)((bf16*)p.K + dst) = *(const bf16x8*)(p.knew + r * p.ldn + c);
+  *(bf16x8*)((bf16*)p.V + dst) = *(const bf16x8*)(p.vnew + r * p.ldn + c);
+}
+
 template <int G>
 void launch_group(DecAttnP p, hipStream_t stream) {
   const long waves = (long)(p.R / G) * p.nH;
@@ -225,7 +241,9 @@ void launch_group(DecAttnP p, hipStream_t stream) {
 
 extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride,
                                 const int* anc, int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv,
-                                float scale, const int* t_ptr, hipStream_t stream) {
+                                float scale, const int* t_ptr, const void* knew, const void* vnew, long ldn, hipStream_t stream) {
+  SPMM_CHECK_SHAPE((knew == nullptr) == (vnew == nullptr) && (knew == nullptr || (anc != nullptr && ldn >= (long)nH * 64 && ldn % 8 == 0)),
+                   "spmm_decode_attn: knew / vnew come together, with an ancestry table, ldn=%ld a multiple of 8 >= nH*64", ldn);
   SPMM_CHECK_SHAPE(R > 0 && nH > 0 && Lkv > 0 && Lkv <= 256, "spmm_decode_attn: R=%d nH=%d Lkv=%d (Lkv <= 256)", R, nH, Lkv);
   SPMM_CHECK_SHAPE((anc != nullptr && anc_ld >= Lkv) || (anc == nullptr && kv_div > 0), "spmm_decode_attn: anc_ld=%d kv_div=%d", anc_ld, kv_div);
   SPMM_CHECK_SHAPE(seq_stride % 8 == 0 && tok_stride % 8 == 0 && ldq >= (long)nH * 64 && ldo >= (long)nH * 64 && ldq % 8 == 0 && ldo % 8 == 0,
@@ -234,9 +252,10 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
   const long waves = (long)R * nH;
   const int nblocks = (int)((waves + 3) / 4);
   DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, anc, anc_ld, kv_div, group, nblocks,
-                (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr};
+                (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr, (const bf16*)knew, (const bf16*)vnew, ldn};
   // beams of a molecule on one wave whenever the K/V rows of a group are (mostly) shared: cross-attention (kv_div == group) and
   // self-attention through an ancestry table
+  if (knew) hipLaunchKernelGGL(cache_write_kernel, dim3((unsigned)(((long)R * nH * 8 + 255) / 256)), dim3(256), 0, stream, p, Lkv - 1);
   static const bool per_beam = getenv("SPMM_DECODE_PER_BEAM") != nullptr;       // (debugging aid: the one-wave-per-row kernel)
   const bool grouped = !per_beam && group >= 2 && group <= 6 && (anc != nullptr || kv_div == group);
   if (grouped) {
@@ -251,5 +270,162 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
     hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
   }
   SPMM_LAUNCH_CHECK("spmm_decode_attn");
+  return SPMM_OK;
+}
+
+// ---- one position of the k-beam search for N molecules at once (d_pv2smiles_batched.py:36-50 + the top-k branch of
+// `generate`, d_pv2smiles_single.py:41-44), as ONE launch instead of ~95 tensor-library launches: next-token softmax and the k
+// best successors of every beam, the k*k candidates, candidates ending in [SEP] moved to the molecule's finals in row-major order
+// and struck out with -1e5, stop once a molecule holds >= k finals, the k best survivors, their token histories and the K/V
+// ancestry table.  One wave per molecule; lane c (< k*k) owns candidate c; everything wave-uniform is made so by butterfly
+// reductions (every lane ends with the result), so no LDS and no barrier.
+namespace {
+
+struct BeamP {
+  const float* logits; long ldl; int N, k, V, Lmax, F;
+  int t; const int* t_ptr; int t_off;          // tokens held by every live beam: *t_ptr + t_off when t_ptr is given (graph replay), else t
+  int* tokens; float* cur_p; float* fin_p; int* fin_len; int* fin_tok; int* fin_n; unsigned char* done;
+  int* anc; int anc_ld; int* ids_out; int* parent_out; int* n_done;
+};
+constexpr int BEAM_KMAX = 8, BEAM_SEP = 3;
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {        // ties -> the lower index; result in every lane
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int VJ>
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.N) return;                                                 // wave-uniform
+  const int k = p.k, kk2 = k * k, L = p.Lmax, F1 = p.F + 1;
+  const int t = p.t_ptr ? *p.t_ptr + p.t_off : p.t;
+  const bool was_done = p.done[n] != 0;
+  const float NEG = -__builtin_inff();
+  // ---- candidates: log softmax of the k most probable next tokens of every beam, on top of the beam's score
+  float my_lp = NEG;
+  int my_tok = 0;
+  for (int b = 0; b < k; ++b) {
+    const float* row = p.logits + (long)(n * k + b) * p.ldl;
+    float v[VJ];
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) v[j] = lane + 64 * j < p.V ? row[lane + 64 * j] : NEG;
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < VJ; ++j) m = fmaxf(m, v[j]);
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) s += lane + 64 * j < p.V ? expf(v[j] - m) : 0.f;
+    s = wave_sum(s);
+    const float cp = p.cur_p[n * k + b];
+    for (int r = 0; r < k; ++r) {
+      float bv = NEG;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < VJ; ++j)
+        if (v[j] > bv) { bv = v[j]; bi = lane + 64 * j; }
+      wave_argmax(bv, bi);
+#pragma unroll
+      for (int j = 0; j < VJ; ++j)
+        if (lane + 64 * j == bi) v[j] = NEG;
+      if (lane == b * k + r) { my_lp = cp + logf(expf(bv - m) / s); my_tok = bi; }      // log(softmax(x)[i]) as the reference forms it
+    }
+  }
+  // ---- finals, in row-major candidate order
+  int fin_n = p.fin_n[n];
+  if (!was_done) {
+    for (int c = 0; c < kk2; ++c) {
+      if (__shfl(my_tok, c, 64) != BEAM_SEP) continue;                  // wave-uniform
+      const float lp = __shfl(my_lp, c, 64);
+      const int slot = fin_n < p.F ? fin_n : p.F;                       // slot F: write-only dump (never reached with F = 2k)
+      const int* src = p.tokens + ((long)n * k + c / k) * L;
+      int* dst = p.fin_tok + ((long)n * F1 + slot) * L;
+      for (int pos = lane; pos < L; pos += 64) dst[pos] = pos == t ? BEAM_SEP : src[pos];
+      if (lane == 0) { p.fin_p[(long)n * F1 + slot] = lp; p.fin_len[(long)n * F1 + slot] = t + 1; }
+      ++fin_n;
+      if (lane == c) my_lp = -1e5f;
+    }
+  }
+  // ---- the k best of the k*k candidates
+  float cv = lane < kk2 ? my_lp : NEG;
+  float new_p[BEAM_KMAX];
+  int flat[BEAM_KMAX];
+#pragma unroll
+  for (int r = 0; r < BEAM_KMAX; ++r) {
+    new_p[r] = 0.f; flat[r] = 0;
+    if (r < k) {
+      float bv = cv;
+      int bi = lane;
+      wave_argmax(bv, bi);
+      new_p[r] = bv; flat[r] = bi;
+      if (lane == bi) cv = NEG;
+    }
+  }
+  const bool now_done = was_done || fin_n >= k;                         // a molecule that just reached k finals breaks before this update
+  if (!now_done) {
+    int tk[BEAM_KMAX][4], an[BEAM_KMAX][4];
+#pragma unroll
+    for (int r = 0; r < BEAM_KMAX; ++r)
+      if (r < k) {
+        const long prow = (long)n * k + flat[r] / k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pos = lane + 64 * q;
+          tk[r][q] = pos < L ? p.tokens[prow * L + pos] : 0;
+          an[r][q] = (p.anc && pos < L) ? p.anc[prow * p.anc_ld + pos] : 0;
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < BEAM_KMAX; ++r)
+      if (r < k) {
+        const long row = (long)n * k + r;
+        const int tokv = __shfl(my_tok, flat[r], 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pos = lane + 64 * q;
+          if (pos < L) {
+            p.tokens[row * L + pos] = pos == t ? tokv : tk[r][q];
+            if (p.anc) p.anc[row * p.anc_ld + pos] = pos < t ? an[r][q] : (int)row;     // positions < t inherited, the rest the row's own
+          }
+        }
+        if (lane == 0) {
+          p.cur_p[row] = new_p[r];
+          p.ids_out[row] = tokv;
+          if (p.parent_out) p.parent_out[row] = flat[r] / k;
+        }
+      }
+  } else if (lane < k) {
+    p.ids_out[(long)n * k + lane] = 0;                                  // a finished molecule keeps decoding [PAD]s nobody reads
+    if (p.parent_out) p.parent_out[(long)n * k + lane] = lane;
+  }
+  if (lane == 0) {
+    p.fin_n[n] = fin_n;
+    if (now_done && !was_done) {
+      p.done[n] = 1;
+      if (p.n_done) atomicAdd(p.n_done, 1);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int spmm_beam_step(const float* logits, long ldl, int N, int k, int V, int Lmax, int F, int t, const int* t_ptr, int t_off,
+                              int* tokens, float* cur_p, float* fin_p, int* fin_len, int* fin_tok, int* fin_n, unsigned char* done,
+                              int* anc, int anc_ld, int* ids_out, int* parent_out, int* n_done, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(N > 0 && k >= 1 && k <= BEAM_KMAX && V >= k && V <= 512 && Lmax >= 3 && Lmax <= 256 && F >= k && ldl >= V,
+                   "spmm_beam_step: N=%d k=%d V=%d Lmax=%d F=%d (k <= 8, k <= V <= 512, Lmax <= 256, F >= k)", N, k, V, Lmax, F);
+  SPMM_CHECK_SHAPE(anc == nullptr || anc_ld >= Lmax, "spmm_beam_step: anc_ld=%d < Lmax=%d", anc_ld, Lmax);
+  SPMM_CHECK_SHAPE(t_ptr != nullptr || (t >= 1 && t < Lmax), "spmm_beam_step: t=%d outside [1, Lmax)", t);
+  BeamP p = {logits, ldl, N, k, V, Lmax, F, t, t_ptr, t_off, tokens, cur_p, fin_p, fin_len, fin_tok, fin_n, done, anc, anc_ld, ids_out, parent_out, n_done};
+  const dim3 grid((unsigned)((N + 3) / 4));
+  if (V <= 320) hipLaunchKernelGGL(beam_step_kernel<5>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(beam_step_kernel<8>, grid, dim3(256), 0, stream, p);
+  SPMM_LAUNCH_CHECK("spmm_beam_step");
   return SPMM_OK;
 }

@@ -9,7 +9,8 @@ from typing import List, Tuple
 import torch
 
 CLS_ID, SEP_ID = 2, 3           # vocab_bpe_300.txt:3-4
-GRAPH_BELOW_ROWS = 2500         # beam rows below which a decode position is bound by its ~230 launches (bench.py --decode --chunk 250 / 500)
+GRAPH_BELOW_ROWS = 2500         # beam rows below which a decode position is bound by its launches (bench.py --decode --chunk 250 / 500)
+FUSED_BEAM_STEP = True          # beam bookkeeping of a position as one HIP launch (spmm_beam_step); False: the tensor-op form (BeamBook.update)
 
 
 def _pick(p: torch.Tensor, k: int, stochastic: bool, generator=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -47,18 +48,21 @@ class BeamBook:
     `final` in row-major order and struck out with -1e5, the molecule stops once it holds >= k finals, the k best of the
     k*k candidates survive."""
 
-    def __init__(self, N: int, k: int, max_steps: int, device):
+    def __init__(self, N: int, k: int, max_steps: int, device, fused: bool = False):
         self.N, self.k, self.Lmax = N, k, max_steps + 3
-        self.F = 2 * k                                    # < k finals before the last appending step, <= k appended by it
-        self.tokens = torch.zeros(N, k, self.Lmax, dtype=torch.long, device=device)
+        self.F = 2 * k                                    # < k finals before the last appending step, <= k appended by it (one [SEP] per beam)
+        it = torch.int32 if fused else torch.long         # fused: the state csrc/decode.hip::beam_step_kernel updates in place
+        self.fused = fused
+        self.tokens = torch.zeros(N, k, self.Lmax, dtype=it, device=device)
         self.tokens[:, :, 0] = CLS_ID
         self.t = 1                                        # tokens held by every live beam
         self.cur_p = torch.zeros(N, k, device=device)
         self.fin_p = torch.full((N, self.F + 1), -float("inf"), device=device)           # slot F is a write-only dump
-        self.fin_len = torch.zeros(N, self.F + 1, dtype=torch.long, device=device)
-        self.fin_tok = torch.zeros(N, self.F + 1, self.Lmax, dtype=torch.long, device=device)
-        self.fin_n = torch.zeros(N, dtype=torch.long, device=device)
+        self.fin_len = torch.zeros(N, self.F + 1, dtype=it, device=device)
+        self.fin_tok = torch.zeros(N, self.F + 1, self.Lmax, dtype=it, device=device)
+        self.fin_n = torch.zeros(N, dtype=it, device=device)
         self.done = torch.zeros(N, dtype=torch.bool, device=device)
+        self.n_done = torch.zeros(1, dtype=torch.int32, device=device) if fused else None
 
     def first(self, values: torch.Tensor, indices: torch.Tensor):
         """values/indices [N,k]: log-probs and ids of the k best successors of [CLS]."""
@@ -119,6 +123,21 @@ class BeamBook:
         self.cur_p.copy_(torch.where(live[:, None], new_p, self.cur_p))
         self.done.logical_or_(self.fin_n >= k)
         return parent, tok
+
+    def step_fused(self, logits: torch.Tensor, anc: torch.Tensor | None = None, t_ptr: torch.Tensor | None = None, t_off: int = 0,
+                   ids_out: torch.Tensor | None = None) -> torch.Tensor:
+        """`update` (and the decoder's ancestry reorder) as one HIP launch on the next-token logits [N*k, V]: softmax, the k best successors
+        per beam, finals, survivors, token histories, `anc` -- all in place.  Returns the tokens to feed next (int32 [N*k]).  With t_ptr
+        (device int32 [1]) the number of tokens held comes from device memory (*t_ptr + t_off) and self.t is left to the caller."""
+        from . import ops
+        ids = ops.beam_step(logits, self, t=self.t, t_ptr=t_ptr, t_off=t_off, anc=anc, ids_out=ids_out)
+        if t_ptr is None:
+            self.t += 1
+        return ids
+
+    def all_done(self) -> bool:
+        """Host check (one small device read): every molecule holds its k finals."""
+        return int(self.n_done.item()) == self.N if self.fused else bool(self.done.all())
 
     def results(self) -> List[List[Tuple[float, List[int]]]]:
         k, F = self.k, self.F
@@ -206,7 +225,6 @@ class CachedDecoder:
         ops, P, c, R, H, nH = self.ops, self.P, self.c, self.R, self.H, self.c.num_attention_heads
         bp = self.pfx + "bert."
         x = self._new(R, H)
-        t64 = None if t_dev is None else t_dev.to(torch.int64)
         ops.embed_step_ln_fwd(ids.to(torch.int32).contiguous(), t, x, pos_ptr=t_dev, word=P.w(bp + "embeddings.word_embeddings.weight"),
                               pos=P.w(bp + "embeddings.position_embeddings.weight"), type0=P.w(bp + "embeddings.token_type_embeddings.weight"),
                               gamma=P.w(bp + "embeddings.LayerNorm.weight"), beta=P.w(bp + "embeddings.LayerNorm.bias"), eps=c.layer_norm_eps)
@@ -216,15 +234,9 @@ class CachedDecoder:
             QKV = self._new(R, 3 * H)
             ops.gemm_nt(x, P.fused(pf + "self.", ("query", "key", "value"), "weight"), QKV,
                         bias=P.fused(pf + "self.", ("query", "key", "value"), "bias", what="w"))
-            if t64 is None:
-                self.kc[l][:, t].copy_(QKV[:, H:2 * H])
-                self.vc[l][:, t].copy_(QKV[:, 2 * H:])
-            else:
-                self.kc[l].index_copy_(1, t64, QKV[:, None, H:2 * H])
-                self.vc[l].index_copy_(1, t64, QKV[:, None, 2 * H:])
-            ctx = self._new(R, H)
-            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=self.Lmax if t64 is not None else t + 1,
-                            seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k, t_ptr=t_dev)
+            ctx = self._new(R, H)                       # (the launch also moves the new key / value rows into the cache)
+            ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=self.Lmax if t_dev is not None else t + 1,
+                            seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k, t_ptr=t_dev, knew=QKV[:, H:2 * H], vnew=QKV[:, 2 * H:])
             a = self._attn_out(pf, ctx, x)
             if l >= c.fusion_layer:
                 pf = lp + "crossattention."
@@ -279,7 +291,8 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     if cached:
         model.engine.train_mode = False
     dec = (CachedDecoder if cached else RecomputeDecoder)(model, prop_embeds, k, max_steps + 3)
-    book = BeamBook(N, k, max_steps, dev)
+    fused = bool(cached and not stochastic and k <= 8 and FUSED_BEAM_STEP)      # one launch per position for the beam bookkeeping (csrc/decode.hip)
+    book = BeamBook(N, k, max_steps, dev, fused=fused)
     ids = torch.full((N * k,), CLS_ID, dtype=torch.long, device=dev)
     logits = dec.step(ids, 0).view(N, k, -1)[:, 0]                       # all k rows hold the same [CLS] prefix
     values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
@@ -288,12 +301,15 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     if graph and cached and not stochastic:
         return _decode_graphed(dec, book, ids, N, k, max_steps, sync_every)
     for s in range(max_steps):
-        logits = dec.step(ids, s + 1).view(N, k, -1)
-        values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, stochastic, generator)
-        parent, tok = book.update(values, indices)
-        dec.reorder(parent, s + 2)
-        ids = tok.reshape(N * k)
-        if s % sync_every == sync_every - 1 and bool(book.done.all()):
+        logits = dec.step(ids, s + 1)
+        if fused:
+            ids = book.step_fused(logits, dec.anc)
+        else:
+            values, indices = _pick(torch.softmax(logits.view(N, k, -1).float(), dim=-1), k, stochastic, generator)
+            parent, tok = book.update(values, indices)
+            dec.reorder(parent, s + 2)
+            ids = tok.reshape(N * k)
+        if s % sync_every == sync_every - 1 and book.all_done():
             break
     return book.results()
 
@@ -331,30 +347,33 @@ def _decode_graphed(dec: "CachedDecoder", book: BeamBook, ids: torch.Tensor, N: 
     """The loop of beam_search_batched with every step-dependent scalar in device memory: two eager positions (they also set the
     kernels' one-time attributes), then one captured position replayed for the rest."""
     dev = ids.device
-    ids_s = ids.clone()                                          # static input of the graph
+    ids_s = ids.to(torch.int32).clone() if book.fused else ids.clone()      # static input of the graph
     t_dev = torch.ones(1, dtype=torch.int32, device=dev)         # position of the token in ids_s
 
     def one_position():
-        t64 = t_dev.to(torch.int64)
-        logits = dec.step(ids_s, 0, t_dev=t_dev).view(N, k, -1)
-        values, indices = _pick(torch.softmax(logits.float(), dim=-1), k, False)
-        parent, tok = book.update_dev(values, indices, t64 + 1)
-        dec.reorder_dev(parent, t64 + 1)
-        ids_s.copy_(tok.reshape(N * k))
+        logits = dec.step(ids_s, 0, t_dev=t_dev)
+        if book.fused:
+            book.step_fused(logits, dec.anc, t_ptr=t_dev, t_off=1, ids_out=ids_s)      # ids_s: the kernel's output and the next position's input
+        else:
+            t64 = t_dev.to(torch.int64)
+            values, indices = _pick(torch.softmax(logits.view(N, k, -1).float(), dim=-1), k, False)
+            parent, tok = book.update_dev(values, indices, t64 + 1)
+            dec.reorder_dev(parent, t64 + 1)
+            ids_s.copy_(tok.reshape(N * k))
         t_dev.add_(1)
 
     eager = min(2, max_steps)
     for _ in range(eager):
         one_position()
     steps_left = max_steps - eager
-    if steps_left > 0 and not bool(book.done.all()):
+    if steps_left > 0 and not book.all_done():
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
             one_position()
         g.replay()                                               # capture records, it does not execute: this is position `eager`
         for s in range(1, steps_left):
-            if s % sync_every == 0 and bool(book.done.all()):
+            if s % sync_every == 0 and book.all_done():
                 break
             g.replay()
     book.t = int(t_dev.item()) + 1

@@ -1248,6 +1248,37 @@ def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group, co
     close(out.float(), ref, 2e-2, 2e-2, "decode_attn")
 
 
+@pytest.mark.parametrize("R,nH,Lkv,Lmax,group", [(15, 12, 37, 64, 5), (10, 2, 1, 16, 1), (35, 4, 9, 16, 7), (500, 12, 100, 103, 5), (12, 2, 54, 64, 6)])
+def test_decode_attention_writes_the_newest_position_into_the_cache(ops, R, nH, Lkv, Lmax, group):
+    """With knew / vnew the launch reads the newest position's key / value from the projection output (a strided view of QKV) and writes
+    them into the cache itself (one copy launch in front of the attention kernel): the output equals the copy-then-attend sequence, the
+    cache afterwards holds the new rows at position Lkv - 1 and nothing else changed."""
+    H = nH * 64
+    g = torch.Generator().manual_seed(R * 7 + Lkv)
+    qkv = torch.randn(R, 3 * H, generator=g).to(BF).cuda()
+    Kc, Vc = torch.randn(R, Lmax, H, generator=g).to(BF).cuda(), torch.randn(R, Lmax, H, generator=g).to(BF).cuda()
+    anc = torch.randint(0, R, (R, Lmax), generator=g).to(torch.int32).cuda()
+    anc[:, Lkv - 1:] = torch.arange(R, dtype=torch.int32, device="cuda")[:, None]           # the newest position is the row's own
+    K2, V2 = Kc.clone(), Vc.clone()
+    K2[:, Lkv - 1] = qkv[:, H:2 * H]
+    V2[:, Lkv - 1] = qkv[:, 2 * H:]
+    want = torch.zeros(R, H, dtype=BF, device="cuda")
+    ops.decode_attn(qkv[:, :H], K2, V2, want, nH=nH, Lkv=Lkv, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group)
+    got = torch.zeros(R, H, dtype=BF, device="cuda")
+    ops.decode_attn(qkv[:, :H], Kc, Vc, got, nH=nH, Lkv=Lkv, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group, knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:])
+    close(got.float(), want.float(), 8e-3, 8e-3, "decode_attn + cache write")
+    assert torch.equal(Kc, K2) and torch.equal(Vc, V2)
+    # the same through a device-resident position (graph replay)
+    Kc3, Vc3 = K2.clone(), V2.clone()
+    Kc3[:, Lkv - 1] = 0
+    t_dev = torch.tensor([Lkv - 1], dtype=torch.int32, device="cuda")
+    got3 = torch.zeros(R, H, dtype=BF, device="cuda")
+    ops.decode_attn(qkv[:, :H], Kc3, Vc3, got3, nH=nH, Lkv=Lmax, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group, t_ptr=t_dev,
+                    knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:])
+    close(got3.float(), want.float(), 8e-3, 8e-3, "decode_attn + cache write, device position")
+    assert torch.equal(Kc3, K2)
+
+
 def test_decode_attention_rejects_bad_arguments(ops):
     q = torch.zeros(4, 128, dtype=BF, device="cuda")
     kv = torch.zeros(4, 300, 128, dtype=BF, device="cuda")
@@ -1270,3 +1301,55 @@ def test_embed_step_matches_full_embedding(ops):
         y = torch.empty(n, H, dtype=BF, device="cuda")
         ops.embed_step_ln_fwd(ids[:, t].contiguous(), t, y, word=word, pos=pos, type0=typ, gamma=gamma, beta=beta)
         assert torch.equal(y, full.view(n, L, H)[:, t])
+
+
+def test_beam_step_kernel_matches_tensor_bookkeeping():
+    """csrc/decode.hip::beam_step_kernel (one launch per decode position) against decode.BeamBook.update + CachedDecoder.reorder (the
+    tensor-op form of d_pv2smiles_batched.py:36-50) on random logits in which [SEP] is a frequent top-k member: same finals in the same
+    slots, same survivors, token histories, scores, ancestry table and tokens to feed, position by position until every molecule is done."""
+    from spmm_amd import decode
+    N, k, V, T = 37, 5, 300, 16
+    L, R = T + 3, N * k
+    g = torch.Generator().manual_seed(3)
+    ref, fus = decode.BeamBook(N, k, T, "cuda"), decode.BeamBook(N, k, T, "cuda", fused=True)
+    v0, i0 = torch.randn(N, k, generator=g).cuda(), torch.randint(4, V, (N, k), generator=g).cuda()
+    ref.first(v0, i0)
+    fus.first(v0, i0)
+    rows = torch.arange(R, dtype=torch.int32, device="cuda")
+    anc_ref = rows[:, None].repeat(1, L).contiguous()
+    anc_fus = anc_ref.clone()
+    n_fin = 0
+    for s in range(T):
+        logits = torch.randn(R, V, generator=g) * 2.0
+        boost = torch.rand(R, generator=g) < 0.12
+        logits[:, decode.SEP_ID] += torch.where(boost, torch.full((R,), 6.0), torch.full((R,), -2.0))
+        logits = logits.cuda()
+        was_done = ref.done.clone()
+        values, indices = decode._pick(torch.softmax(logits.view(N, k, -1), dim=-1), k, False)
+        parent, tok = ref.update(values, indices)
+        anc_ref = anc_ref.view(N, k, L).gather(1, parent[:, :, None].expand(N, k, L).long()).reshape(R, L).contiguous()
+        anc_ref[:, s + 2:] = rows[:, None]
+        ids = fus.step_fused(logits, anc_fus)
+        live = ~ref.done
+        assert torch.equal(fus.done, ref.done) and int(fus.n_done) == int(ref.done.sum()), s
+        assert torch.equal(fus.fin_n.long(), ref.fin_n), s
+        assert torch.equal(fus.tokens.long(), ref.tokens), s
+        torch.testing.assert_close(fus.cur_p, ref.cur_p, rtol=0, atol=2e-5)
+        F = ref.F
+        fp_f, fp_r = fus.fin_p[:, :F], ref.fin_p[:, :F]
+        assert torch.equal(torch.isinf(fp_f), torch.isinf(fp_r)), s
+        torch.testing.assert_close(torch.where(torch.isinf(fp_f), torch.zeros_like(fp_f), fp_f), torch.where(torch.isinf(fp_r), torch.zeros_like(fp_r), fp_r),
+                                   rtol=0, atol=2e-5)
+        used = torch.arange(F, device="cuda")[None, :] < ref.fin_n[:, None]
+        assert torch.equal(fus.fin_len[:, :F].long()[used], ref.fin_len[:, :F][used]), s
+        assert torch.equal(fus.fin_tok[:, :F].long()[used], ref.fin_tok[:, :F][used]), s
+        lr = live[:, None].expand(N, k).reshape(R)
+        assert torch.equal(ids.long()[lr], tok.reshape(R)[lr]), s
+        assert torch.equal(anc_fus[lr], anc_ref[lr]), s
+        anc_ref = torch.where(lr[:, None], anc_ref, anc_fus)         # finished molecules: the tensor form permutes rows nobody reads
+        n_fin = int(ref.fin_n.sum())
+        if bool(ref.done.all()):
+            break
+    assert n_fin > 2 * N and bool(ref.done.any())
+    got, want = fus.results(), ref.results()
+    assert [[h[1] for h in m] for m in got] == [[h[1] for h in m] for m in want]
