@@ -388,6 +388,12 @@ class SPMM(_Base):
                 e1.synchronize()
                 ms[which].append(e0.elapsed_time(e1))
             multi, single = (sorted(v)[len(v) // 2] for v in (ms["three streams"], ms["one stream"]))
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # the step ends when the slowest rank does: every rank decides on the slowest rank's medians (and so decides the same)
+                both = torch.tensor([multi, single], dtype=torch.float32, device=self.device_)
+                dist.all_reduce(both, op=dist.ReduceOp.MAX)
+                multi, single = float(both[0]), float(both[1])
             keep_single = single <= 0.87 * multi
             eng.force_one_stream = keep_single
             st["on"], st["ev"] = False, []
