@@ -163,7 +163,8 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, co
 
 /* Single-query attention over a key/value cache (xbert.py:305-354 for the newest position only; the cache slots the
  * reference sketches at xbert.py:291-295,480,1344-1348).  Row r, head h: softmax_j(q_r,h . K[s(r,j), j, h] * scale) V[...],
- * j < Lkv <= 256, head_dim 64.  Key/value (s, j) lives at element offset s*seq_stride + j*tok_stride (+ h*64) from K / V.
+ * j < Lkv <= 256, head_dim 64.  Key/value (s, j) of head h lives at element offset s*seq_stride + j*tok_stride + h*head_stride from K / V (token-major rows:
+ * tok_stride = row width, head_stride = 64; head-major caches [S, nH, L, 64]: tok_stride = 64, head_stride = L*64).
  * s(r,j) = anc[r*anc_ld + j] (self-attention: beam ancestry table, cache rows are never moved) or r / kv_div when anc is
  * null (cross-attention: the k beams of a molecule share its PV keys/values).  `group` (R % group == 0) only steers
  * placement: rows n*group .. n*group+group-1 are scheduled next to each other because they read mostly the same lines.
@@ -171,7 +172,7 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, co
  * Lkv -- the step counter of a replayed hipGraph.  knew / vnew (optional, with anc; row stride ldn): key and value of the newest
  * position (the last valid one) of every row, straight from the projection output: copied into the cache row (s = r) by a
  * small launch in front of the attention kernel, so the caller needs no cache-update copies of its own. */
-int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, const int* anc,
+int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, long head_stride, const int* anc,
                      int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv, float scale,
                      const int* t_ptr, const void* knew, const void* vnew, long ldn, spmm_stream_t stream);
 

@@ -15,7 +15,7 @@ namespace {
 
 struct DecAttnP {
   const bf16* q; long ldq;
-  const bf16* K; const bf16* V; long seq_stride, tok_stride;
+  const bf16* K; const bf16* V; long seq_stride, tok_stride, head_stride;   // element (s, j, h, d) at s*seq_stride + j*tok_stride + h*head_stride + d
   const int* anc; int anc_ld; int kv_div; int group; int nblocks;
   bf16* out; long ldo;
   int R, nH, Lkv; float scale;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
     for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * p.scale;
   }
   const int* anc_row = p.anc ? p.anc + (long)r * p.anc_ld : nullptr;
-  const long own = (long)(r / max(p.kv_div, 1)) * p.seq_stride + h * 64 + c * 8;
+  const long own = (long)(r / max(p.kv_div, 1)) * p.seq_stride + h * p.head_stride + c * 8;
   const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
   const int niter = (Lkv + 7) >> 3;
   float mx = -INFINITY;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
     const int j = i * 8 + g;
     float part = 0.f;
     if (j < Lkv) {
-      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * 64 + c * 8 : own) + (long)j * p.tok_stride;
+      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * p.head_stride + c * 8 : own) + (long)j * p.tok_stride;
       const bf16x8 kv = *(const bf16x8*)(p.K + off);
 #pragma unroll
       for (int e = 0; e < 8; ++e) part += (float)kv[e] * qf[e];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
       const float e = __expf(ssc[wave][j] - mx);
       sum += e;
       const float pe = (float)(bf16)e;               // the tiled training kernel feeds bf16 probabilities to the PV MFMA
-      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * 64 + c * 8 : own) + (long)j * p.tok_stride;
+      const long off = (anc_row ? (long)anc_row[j] * p.seq_stride + h * p.head_stride + c * 8 : own) + (long)j * p.tok_stride;
       const bf16x8 vv = *(const bf16x8*)(p.V + off);
 #pragma unroll
       for (int d = 0; d < 8; ++d) acc[d] += pe * (float)vv[d];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void decode_attn_group_kernel(DecAttnP p) {
         sanc[wave][b][j] = p.anc ? (j < Lkv ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
   }
   __builtin_amdgcn_wave_barrier();
-  const long hoff = h * 64 + c * 8;
+  const long hoff = h * p.head_stride + c * 8;
   float mx[G];
 #pragma unroll
   for (int b = 0; b < G; ++b) mx[b] = -INFINITY;
@@ -222,11 +222,12 @@ __global__ __launch_bounds__(256) void cache_write_kernel(DecAttnP p, int jn) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // 16-byte chunk of a row
   const int per_row = p.nH * 8;
   if (i >= (long)p.R * per_row) return;
-  const long r = i / per_row, c = (i - r * per_row) * 8;
+  const long r = i / per_row;
+  const int ch = (int)(i - r * per_row), h = ch >> 3, c = (ch & 7) * 8;
   const int j = p.t_ptr ? min(*p.t_ptr, p.Lkv - 1) : jn;
-  const long dst = r * p.seq_stride + (long)j * p.tok_stride + c;
-  *(bf16x8*)((bf16*)p.K + dst) = *(const bf16x8*)(p.knew + r * p.ldn + c);
-  *(bf16x8*)((bf16*)p.V + dst) = *(const bf16x8*)(p.vnew + r * p.ldn + c);
+  const long dst = r * p.seq_stride + (long)j * p.tok_stride + h * p.head_stride + c;
+  *(bf16x8*)((bf16*)p.K + dst) = *(const bf16x8*)(p.knew + r * p.ldn + h * 64 + c);
+  *(bf16x8*)((bf16*)p.V + dst) = *(const bf16x8*)(p.vnew + r * p.ldn + h * 64 + c);
 }
 
 template <int G>
@@ -239,19 +240,20 @@ void launch_group(DecAttnP p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride,
+extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, long head_stride,
                                 const int* anc, int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv,
                                 float scale, const int* t_ptr, const void* knew, const void* vnew, long ldn, hipStream_t stream) {
   SPMM_CHECK_SHAPE((knew == nullptr) == (vnew == nullptr) && (knew == nullptr || (anc != nullptr && ldn >= (long)nH * 64 && ldn % 8 == 0)),
                    "spmm_decode_attn: knew / vnew come together, with an ancestry table, ldn=%ld a multiple of 8 >= nH*64", ldn);
   SPMM_CHECK_SHAPE(R > 0 && nH > 0 && Lkv > 0 && Lkv <= 256, "spmm_decode_attn: R=%d nH=%d Lkv=%d (Lkv <= 256)", R, nH, Lkv);
   SPMM_CHECK_SHAPE((anc != nullptr && anc_ld >= Lkv) || (anc == nullptr && kv_div > 0), "spmm_decode_attn: anc_ld=%d kv_div=%d", anc_ld, kv_div);
+  SPMM_CHECK_SHAPE(head_stride >= 64 && head_stride % 8 == 0, "spmm_decode_attn: head_stride=%ld (a multiple of 8, >= 64)", head_stride);
   SPMM_CHECK_SHAPE(seq_stride % 8 == 0 && tok_stride % 8 == 0 && ldq >= (long)nH * 64 && ldo >= (long)nH * 64 && ldq % 8 == 0 && ldo % 8 == 0,
                    "spmm_decode_attn: strides must keep 16-B alignment (seq %ld tok %ld)", seq_stride, tok_stride);
   SPMM_CHECK_SHAPE(group > 0 && R % group == 0, "spmm_decode_attn: R=%d must be a multiple of group=%d", R, group);
   const long waves = (long)R * nH;
   const int nblocks = (int)((waves + 3) / 4);
-  DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, anc, anc_ld, kv_div, group, nblocks,
+  DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, head_stride, anc, anc_ld, kv_div, group, nblocks,
                 (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr, (const bf16*)knew, (const bf16*)vnew, ldn};
   // beams of a molecule on one wave whenever the K/V rows of a group are (mostly) shared: cross-attention (kv_div == group) and
   // self-attention through an ancestry table

@@ -194,8 +194,9 @@ class CachedDecoder:
         assert Lmax <= 256 and H == c.hidden_size and c.hidden_size // c.num_attention_heads == 64
         self.N, self.R, self.Lmax, self.Lp, self.H = N, N * k, Lmax, Lkv, H
         nl = c.num_hidden_layers
-        self.kc = [torch.empty(self.R, Lmax, H, dtype=BF, device=dev) for _ in range(nl)]
-        self.vc = [torch.empty(self.R, Lmax, H, dtype=BF, device=dev) for _ in range(nl)]
+        # head-major cache [R, nH, Lmax, 64]: the positions of a (row, head) are one contiguous 128-B-per-key stream for the wave that reads them
+        self.kc = [torch.empty(self.R, c.num_attention_heads, Lmax, 64, dtype=BF, device=dev) for _ in range(nl)]
+        self.vc = [torch.empty(self.R, c.num_attention_heads, Lmax, 64, dtype=BF, device=dev) for _ in range(nl)]
         self.anc = torch.arange(self.R, dtype=torch.int32, device=dev)[:, None].repeat(1, Lmax).contiguous()
         self.rows = torch.arange(self.R, dtype=torch.int32, device=dev)
         kv_src = prop_embeds.to(dev).to(BF).reshape(N * Lkv, H).contiguous()
@@ -236,7 +237,7 @@ class CachedDecoder:
                         bias=P.fused(pf + "self.", ("query", "key", "value"), "bias", what="w"))
             ctx = self._new(R, H)                       # (the launch also moves the new key / value rows into the cache)
             ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=self.Lmax if t_dev is not None else t + 1,
-                            seq_stride=self.Lmax * H, tok_stride=H, anc=self.anc, group=self.k, t_ptr=t_dev, knew=QKV[:, H:2 * H], vnew=QKV[:, 2 * H:])
+                            seq_stride=self.Lmax * H, tok_stride=64, head_stride=self.Lmax * 64, anc=self.anc, group=self.k, t_ptr=t_dev, knew=QKV[:, H:2 * H], vnew=QKV[:, 2 * H:])
             a = self._attn_out(pf, ctx, x)
             if l >= c.fusion_layer:
                 pf = lp + "crossattention."

@@ -393,15 +393,15 @@ def embed_step_ln_fwd(ids32, pos_index, y, *, word, pos, type0, gamma, beta, eps
     return y
 
 
-def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, anc=None, kv_div=1, group=1, scale=0.125, t_ptr=None, knew=None, vnew=None):
+def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, head_stride=64, anc=None, kv_div=1, group=1, scale=0.125, t_ptr=None, knew=None, vnew=None):
     """Single-query attention over a K/V cache; q/out: [R, >=nH*64] bf16 views, K/V: bf16 views whose element (s, j, h*64+d)
-    sits at s*seq_stride + j*tok_stride + h*64 + d from their first element.  knew / vnew ([R, nH*64] bf16 views, self-attention
+    sits at s*seq_stride + j*tok_stride + h*head_stride + d from their first element (head_stride 64: token-major rows).  knew / vnew ([R, nH*64] bf16 views, self-attention
     only): key / value of the newest position, which the launch also writes into the cache."""
     R = q.shape[0]
     assert q.dtype == BF16 and K.dtype == BF16 and V.dtype == BF16 and out.dtype == BF16
     assert anc is None or (anc.dtype == torch.int32 and anc.shape[0] == R)
     assert (knew is None) == (vnew is None) and (knew is None or (knew.dtype == BF16 and vnew.dtype == BF16 and _row_stride(knew) == _row_stride(vnew)))
-    _call("spmm_decode_attn", _p(q), _row_stride(q), _p(K), _p(V), int(seq_stride), int(tok_stride), _p(anc),
+    _call("spmm_decode_attn", _p(q), _row_stride(q), _p(K), _p(V), int(seq_stride), int(tok_stride), int(head_stride), _p(anc),
           0 if anc is None else _row_stride(anc), int(kv_div), int(group), _p(out), _row_stride(out), R, nH, Lkv, float(scale), _p(t_ptr),
           _p(knew), _p(vnew), 0 if knew is None else _row_stride(knew), _st())
     return out

@@ -1249,34 +1249,44 @@ def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group, co
 
 
 @pytest.mark.parametrize("R,nH,Lkv,Lmax,group", [(15, 12, 37, 64, 5), (10, 2, 1, 16, 1), (35, 4, 9, 16, 7), (500, 12, 100, 103, 5), (12, 2, 54, 64, 6)])
-def test_decode_attention_writes_the_newest_position_into_the_cache(ops, R, nH, Lkv, Lmax, group):
-    """With knew / vnew the launch reads the newest position's key / value from the projection output (a strided view of QKV) and writes
+@pytest.mark.parametrize("head_major", [False, True])
+def test_decode_attention_writes_the_newest_position_into_the_cache(ops, R, nH, Lkv, Lmax, group, head_major):
+    """With knew / vnew the launch takes the newest position's key / value from the projection output (a strided view of QKV) and writes
     them into the cache itself (one copy launch in front of the attention kernel): the output equals the copy-then-attend sequence, the
-    cache afterwards holds the new rows at position Lkv - 1 and nothing else changed."""
+    cache afterwards holds the new rows at position Lkv - 1 and nothing else changed.  head_major: the decoder's cache layout
+    [R, nH, Lmax, 64] (tok_stride 64, head_stride Lmax * 64) against the same data in token-major rows [R, Lmax, H]."""
     H = nH * 64
     g = torch.Generator().manual_seed(R * 7 + Lkv)
     qkv = torch.randn(R, 3 * H, generator=g).to(BF).cuda()
-    Kc, Vc = torch.randn(R, Lmax, H, generator=g).to(BF).cuda(), torch.randn(R, Lmax, H, generator=g).to(BF).cuda()
+    Kt, Vt = torch.randn(R, Lmax, H, generator=g).to(BF).cuda(), torch.randn(R, Lmax, H, generator=g).to(BF).cuda()      # token-major truth
     anc = torch.randint(0, R, (R, Lmax), generator=g).to(torch.int32).cuda()
     anc[:, Lkv - 1:] = torch.arange(R, dtype=torch.int32, device="cuda")[:, None]           # the newest position is the row's own
-    K2, V2 = Kc.clone(), Vc.clone()
+    K2, V2 = Kt.clone(), Vt.clone()
     K2[:, Lkv - 1] = qkv[:, H:2 * H]
     V2[:, Lkv - 1] = qkv[:, 2 * H:]
     want = torch.zeros(R, H, dtype=BF, device="cuda")
     ops.decode_attn(qkv[:, :H], K2, V2, want, nH=nH, Lkv=Lkv, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group)
+
+    def lay(x):          # [R, Lmax, H] -> the layout under test
+        return x.view(R, Lmax, nH, 64).permute(0, 2, 1, 3).contiguous() if head_major else x.clone()
+
+    def back(x):
+        return x.permute(0, 2, 1, 3).reshape(R, Lmax, H) if head_major else x
+
+    strides = dict(seq_stride=Lmax * H, tok_stride=64, head_stride=Lmax * 64) if head_major else dict(seq_stride=Lmax * H, tok_stride=H)
+    Kc, Vc = lay(Kt), lay(Vt)
     got = torch.zeros(R, H, dtype=BF, device="cuda")
-    ops.decode_attn(qkv[:, :H], Kc, Vc, got, nH=nH, Lkv=Lkv, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group, knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:])
-    close(got.float(), want.float(), 8e-3, 8e-3, "decode_attn + cache write")
-    assert torch.equal(Kc, K2) and torch.equal(Vc, V2)
+    ops.decode_attn(qkv[:, :H], Kc, Vc, got, nH=nH, Lkv=Lkv, anc=anc, group=group, knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:], **strides)
+    assert torch.equal(got, want)
+    assert torch.equal(back(Kc), K2) and torch.equal(back(Vc), V2)
     # the same through a device-resident position (graph replay)
-    Kc3, Vc3 = K2.clone(), V2.clone()
-    Kc3[:, Lkv - 1] = 0
+    K3 = K2.clone()
+    K3[:, Lkv - 1] = 0
+    Kc3, Vc3 = lay(K3), lay(V2)
     t_dev = torch.tensor([Lkv - 1], dtype=torch.int32, device="cuda")
     got3 = torch.zeros(R, H, dtype=BF, device="cuda")
-    ops.decode_attn(qkv[:, :H], Kc3, Vc3, got3, nH=nH, Lkv=Lmax, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group, t_ptr=t_dev,
-                    knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:])
-    close(got3.float(), want.float(), 8e-3, 8e-3, "decode_attn + cache write, device position")
-    assert torch.equal(Kc3, K2)
+    ops.decode_attn(qkv[:, :H], Kc3, Vc3, got3, nH=nH, Lkv=Lmax, anc=anc, group=group, t_ptr=t_dev, knew=qkv[:, H:2 * H], vnew=qkv[:, 2 * H:], **strides)
+    assert torch.equal(got3, want) and torch.equal(back(Kc3), K2)
 
 
 def test_decode_attention_rejects_bad_arguments(ops):
