@@ -430,6 +430,20 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread, no extra syncs
+    host_lead = None
+    if os.environ.get("SPMM_BENCH_HOST_LEAD") == "1":          # diagnostic (not the default run): how far ahead of the GPU the host enqueues
+        host_lead, opt_, orig_step_ = [], model.optimizers(), model.optimizers().step
+
+        def step_probe(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reached = e0.query()                                # True: the GPU had already drained everything enqueued before the optimiser
+            r = orig_step_(*a, **k)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            host_lead.append((reached, e0, e1))
+            return r
+        opt_.step = step_probe
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -445,6 +459,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
+    if host_lead is not None:
+        opt_.step = orig_step_
+        el = sorted(a.elapsed_time(b) for _, a, b in host_lead)
+        print(f"[host-lead] optimiser enqueued after the GPU had drained the backward in {sum(r for r, _, _ in host_lead)} of {len(host_lead)} steps; "
+              f"backward end -> optimiser end on the GPU: median {el[len(el) // 2]:.3f} ms, min {el[0]:.3f}, max {el[-1]:.3f}", file=sys.stderr, flush=True)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     spread = {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
               "p90": round(per_step[int(0.9 * (len(per_step) - 1) + 0.5)], 3), "note": "GPU-side interval between consecutive steps' last kernels (this rank)"}
