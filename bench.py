@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+PEAK_FP8_TFLOPS = 5000.0       # dense E4M3 MFMA (same guide: ~5 PF dense)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -524,11 +525,14 @@ def main():
         i2 = sorted(a.elapsed_time(b) for _, (a, b) in pairs)[100]
         ev_overhead_ms = max(0.0, 2 * i1 - i2)
         ops.gemm_nt = timed("gemm", orig_gemm, gemm_flops)
+        orig_f8 = ops.gemm_nt_f8
+        ev["f8"] = []
+        ops.gemm_nt_f8 = timed("f8", orig_f8, lambda A8, sa, W8, sw, C, **k: 2.0 * A8.shape[0] * W8.shape[0] * A8.shape[1])   # (--fp8 only: the E4M3 launches)
         nsteps = min(3, args.steps)
         for i in range(nsteps):
             one_step(i)
         torch.cuda.synchronize()
-        ops.gemm_nt = orig_gemm
+        ops.gemm_nt, ops.gemm_nt_f8 = orig_gemm, orig_f8
         # the metric's kernel: the cross-attention unit (Q/K/V projections + softmax(QK^T)V + output projection, forward),
         # timed as a whole with events around BertAttention(cross) in separate instrumented steps
         eng = model.engine
@@ -594,6 +598,13 @@ def main():
                 "avg_launch_us_raw": round(raw_ms * 1e3 / n_launch, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                 "measured": f"HIP events around every launch, {nsteps} instrumented single-stream steps after the timed region; each interval "
                             "minus the calibrated event-pair overhead (2 I1 - I2 around one / two minimal kernels), which the rocprofv3 kernel trace does not contain"}
+        if ev["f8"]:                                         # the fp8 tier's own launches, against the dense E4M3 peak
+            f8_ms = sum(a.elapsed_time(b) for a, b, _ in ev["f8"]) - len(ev["f8"]) * ev_overhead_ms
+            f8_fl = sum(fl for _, _, fl in ev["f8"])
+            roof["fp8_launches"] = {"kernel": "gemm_nt_p8_kernel<., true> (E4M3 operands, v_mfma_scale_f32_16x16x128_f8f6f4): the FFN forward products of the "
+                                              "fp8 option", "achieved": round(f8_fl / (f8_ms * 1e-3) / 1e12, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(f8_fl / (f8_ms * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4), "launches_per_step": len(ev["f8"]) // nsteps,
+                                    "ms_per_step": round(f8_ms / nsteps, 3)}
         # per-shape table of the same launches (where the family's time goes inside the step): M bucketed to 1 k rows
         by_shape = {}
         for (a, b, _), (M_, N_, K_, epi_, f32_) in zip(ev["gemm"], shape_log):
@@ -660,8 +671,8 @@ def main():
                     "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs"],
                     ("metric", "value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "mfma_frac_of_peak_step", "hbm", "config")),
                 "configs[4] per-GPU shape with the fp8 option (E4M3 FFN forward; B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5",
-                    "--warmup", "4", "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs", "--fp8"],
-                    ("value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "dtype"))}
+                    "--warmup", "4", "--no-cpu-baseline", "--no-other-configs", "--fp8"],
+                    ("value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "dtype", "roofline"))}
         print(json.dumps(out), flush=True)
     if args.check_replicas and world > 1:
         check_replicas(args.warmup + args.steps, fatal=True)
