@@ -199,7 +199,8 @@ def decode_bench(args):
            "config": {"workload": f"d_pv2smiles_batched.py: {N} synthetic PVs, k={k} beams, <= {T} positions, chunks of {chunk} molecules, 12-layer "
                                   "causal text encoder with cross-attention to the 54-token PV embeddings, K/V cache"
                                   + (", one hipGraph replay per position" if (args.decode_graph == "on" or (args.decode_graph == "auto" and chunk * k < decode.GRAPH_BELOW_ROWS)) else ""), "global_batch": chunk, "seq_len": T},
-           "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin, "sep_logit_bias": args.sep_bias}
+           "ms_per_position": round(dt / len(chunks) / (T + 1) * 1e3, 3), "finished_hypotheses": nfin, "sep_logit_bias": args.sep_bias,
+           "last_chunk": dict(decode.last_run)}      # positions run, compactions of the batch (finished molecules dropped) and its final size
     # ---- instrumented chunk (eager, single stream): HIP events around every decode_attn / GEMM / LayerNorm launch
     ev, other = [], {"gemm": [], "layernorm": []}
     orig, orig_gemm, orig_ln = ops.decode_attn, ops.gemm_nt, ops.ln_fwd
@@ -666,7 +667,9 @@ def main():
             torch.cuda.empty_cache()
             out["other_configs"] = {
                 "configs[3] PV->SMILES k-beam decode (1000 PVs, k=5, 100 positions)": child_bench(["--decode", "--no-cpu-baseline"],
-                    ("metric", "value", "unit", "ms_per_position", "finished_hypotheses", "roofline", "position_breakdown_ms")),
+                    ("metric", "value", "unit", "ms_per_position", "finished_hypotheses", "last_chunk", "roofline", "position_breakdown_ms")),
+                "configs[3] with a [SEP] logit bias of 0.5 (molecules finish at different positions: early exit, finished molecules leave the batch)":
+                    child_bench(["--decode", "--no-cpu-baseline", "--sep-bias", "0.5"], ("value", "unit", "ms_per_step", "finished_hypotheses", "last_chunk")),
                 "configs[4] per-GPU shape in bf16 (B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5", "--warmup", "4",
                     "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs"],
                     ("metric", "value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "mfma_frac_of_peak_step", "hbm", "config")),

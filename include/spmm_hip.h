@@ -171,10 +171,12 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, co
  * No mask: beams carry no padding.  t_ptr (optional, device int): the number of valid keys is *t_ptr + 1 (<= Lkv) instead of
  * Lkv -- the step counter of a replayed hipGraph.  knew / vnew (optional, with anc; row stride ldn): key and value of the newest
  * position (the last valid one) of every row, straight from the projection output: copied into the cache row (s = r) by a
- * small launch in front of the attention kernel, so the caller needs no cache-update copies of its own. */
+ * small launch in front of the attention kernel, so the caller needs no cache-update copies of its own.  rowmap (optional, [R]):
+ * the cache row row r's newest position goes to (s = rowmap[r]) -- after the caller dropped finished molecules from its batch, the
+ * rows it still decodes keep writing to the cache rows their ancestry tables name. */
 int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, long head_stride, const int* anc,
                      int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv, float scale,
-                     const int* t_ptr, const void* knew, const void* vnew, long ldn, spmm_stream_t stream);
+                     const int* t_ptr, const void* knew, const void* vnew, long ldn, const int* rowmap, spmm_stream_t stream);
 
 /* One position of the k-beam PV -> SMILES search for N molecules (d_pv2smiles_batched.py:36-50; the top-k branch of
  * `generate`, d_pv2smiles_single.py:41-44) in one launch.  logits [N*k, V] fp32 (row stride ldl): next-token logits of every beam.
@@ -185,10 +187,13 @@ int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long
  * histories; position t receives the new token), cur_p, ids_out [N*k] (the token to feed next; 0 for finished molecules),
  * parent_out (optional) and the K/V ancestry table anc [N*k, anc_ld] of spmm_decode_attn (optional: positions < t inherited from
  * the parent row, positions >= t the row itself).  t = tokens held by every live beam = *t_ptr + t_off when t_ptr is given (a
- * replayed hipGraph), else the argument.  k <= 8, k <= V <= 512, Lmax <= 256. */
+ * replayed hipGraph), else the argument.  mol (optional, [N]): the batch is a compacted subset -- molecule i of logits / ids_out / anc is
+ * molecule mol[i] of the state arrays; rowmap (optional, [N*k]): the K/V cache row of beam row i*k + b (what "the row itself" means in
+ * anc).  k <= 8, k <= V <= 512, Lmax <= 256. */
 int spmm_beam_step(const float* logits, long ldl, int N, int k, int V, int Lmax, int F, int t, const int* t_ptr, int t_off,
                    int* tokens, float* cur_p, float* fin_p, int* fin_len, int* fin_tok, int* fin_n, unsigned char* done,
-                   int* anc, int anc_ld, int* ids_out, int* parent_out, int* n_done, spmm_stream_t stream);
+                   int* anc, int anc_ld, int* ids_out, int* parent_out, int* n_done, const int* mol, const int* rowmap,
+                   spmm_stream_t stream);
 
 /* mode 0: BertEmbeddings.forward xbert.py:193-220 from token ids.  mode 1: the PV path -- property_embed Linear(1,H),
  * bernoulli mask blend with property_mask, property_cls prepend (SPMM_models.py:82-88) fused with BertEmbeddings

@@ -20,6 +20,7 @@ struct DecAttnP {
   bf16* out; long ldo;
   int R, nH, Lkv; float scale;
   const int* t_ptr;             // optional device step index: the cache holds positions 0..*t_ptr, i.e. Lkv = *t_ptr + 1 (graph replay)
+  const int* rowmap;            // optional: cache row that row r's newest position is written to (identity when null)
   const bf16* knew; const bf16* vnew; long ldn;   // optional: key / value of the NEWEST position (Lkv - 1) of every row, not yet in the cache: read from
   //                                                 here (row stride ldn) and written to the cache row by the wave that owns the (row, head)
 };
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void cache_write_kernel(DecAttnP p, int jn) {
   const long r = i / per_row;
   const int ch = (int)(i - r * per_row), h = ch >> 3, c = (ch & 7) * 8;
   const int j = p.t_ptr ? min(*p.t_ptr, p.Lkv - 1) : jn;
-  const long dst = r * p.seq_stride + (long)j * p.tok_stride + h * p.head_stride + c;
+  const long dst = (long)(p.rowmap ? p.rowmap[r] : (int)r) * p.seq_stride + (long)j * p.tok_stride + h * p.head_stride + c;
   *(bf16x8*)((bf16*)p.K + dst) = *(const bf16x8*)(p.knew + r * p.ldn + h * 64 + c);
   *(bf16x8*)((bf16*)p.V + dst) = *(const bf16x8*)(p.vnew + r * p.ldn + h * 64 + c);
 }
@@ -242,7 +243,8 @@ void launch_group(DecAttnP p, hipStream_t stream) {
 
 extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, long head_stride,
                                 const int* anc, int anc_ld, int kv_div, int group, void* out, long ldo, int R, int nH, int Lkv,
-                                float scale, const int* t_ptr, const void* knew, const void* vnew, long ldn, hipStream_t stream) {
+                                float scale, const int* t_ptr, const void* knew, const void* vnew, long ldn, const int* rowmap,
+                                hipStream_t stream) {
   SPMM_CHECK_SHAPE((knew == nullptr) == (vnew == nullptr) && (knew == nullptr || (anc != nullptr && ldn >= (long)nH * 64 && ldn % 8 == 0)),
                    "spmm_decode_attn: knew / vnew come together, with an ancestry table, ldn=%ld a multiple of 8 >= nH*64", ldn);
   SPMM_CHECK_SHAPE(R > 0 && nH > 0 && Lkv > 0 && Lkv <= 256, "spmm_decode_attn: R=%d nH=%d Lkv=%d (Lkv <= 256)", R, nH, Lkv);
@@ -254,7 +256,7 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
   const long waves = (long)R * nH;
   const int nblocks = (int)((waves + 3) / 4);
   DecAttnP p = {(const bf16*)q, ldq, (const bf16*)K, (const bf16*)V, seq_stride, tok_stride, head_stride, anc, anc_ld, kv_div, group, nblocks,
-                (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr, (const bf16*)knew, (const bf16*)vnew, ldn};
+                (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr, rowmap, (const bf16*)knew, (const bf16*)vnew, ldn};
   // beams of a molecule on one wave whenever the K/V rows of a group are (mostly) shared: cross-attention (kv_div == group) and
   // self-attention through an ancestry table
   if (knew) hipLaunchKernelGGL(cache_write_kernel, dim3((unsigned)(((long)R * nH * 8 + 255) / 256)), dim3(256), 0, stream, p, Lkv - 1);
@@ -288,6 +290,8 @@ struct BeamP {
   int t; const int* t_ptr; int t_off;          // tokens held by every live beam: *t_ptr + t_off when t_ptr is given (graph replay), else t
   int* tokens; float* cur_p; float* fin_p; int* fin_len; int* fin_tok; int* fin_n; unsigned char* done;
   int* anc; int anc_ld; int* ids_out; int* parent_out; int* n_done;
+  const int* mol;              // optional: state index (tokens, scores, finals, flags) of compact molecule i -- the live subset after a compaction
+  const int* rowmap;           // optional: K/V cache row of compact beam row i*k + b (the "own row" written into the ancestry table)
 };
 constexpr int BEAM_KMAX = 8, BEAM_SEP = 3;
 
@@ -303,8 +307,9 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {        // ties -
 template <int VJ>
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= p.N) return;                                                 // wave-uniform
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);                   // compact molecule index: rows ci*k .. of logits / ids / anc
+  if (ci >= p.N) return;                                                // wave-uniform
+  const int n = p.mol ? p.mol[ci] : ci;                                 // index of the molecule's state
   const int k = p.k, kk2 = k * k, L = p.Lmax, F1 = p.F + 1;
   const int t = p.t_ptr ? *p.t_ptr + p.t_off : p.t;
   const bool was_done = p.done[n] != 0;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
   float my_lp = NEG;
   int my_tok = 0;
   for (int b = 0; b < k; ++b) {
-    const float* row = p.logits + (long)(n * k + b) * p.ldl;
+    const float* row = p.logits + (long)(ci * k + b) * p.ldl;
     float v[VJ];
 #pragma unroll
     for (int j = 0; j < VJ; ++j) v[j] = lane + 64 * j < p.V ? row[lane + 64 * j] : NEG;
@@ -375,36 +380,37 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
 #pragma unroll
     for (int r = 0; r < BEAM_KMAX; ++r)
       if (r < k) {
-        const long prow = (long)n * k + flat[r] / k;
+        const long prow = (long)n * k + flat[r] / k, crow = (long)ci * k + flat[r] / k;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int pos = lane + 64 * q;
           tk[r][q] = pos < L ? p.tokens[prow * L + pos] : 0;
-          an[r][q] = (p.anc && pos < L) ? p.anc[prow * p.anc_ld + pos] : 0;
+          an[r][q] = (p.anc && pos < L) ? p.anc[crow * p.anc_ld + pos] : 0;
         }
       }
 #pragma unroll
     for (int r = 0; r < BEAM_KMAX; ++r)
       if (r < k) {
-        const long row = (long)n * k + r;
+        const long row = (long)n * k + r, crow = (long)ci * k + r;
+        const int own = p.rowmap ? p.rowmap[crow] : (int)crow;
         const int tokv = __shfl(my_tok, flat[r], 64);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int pos = lane + 64 * q;
           if (pos < L) {
             p.tokens[row * L + pos] = pos == t ? tokv : tk[r][q];
-            if (p.anc) p.anc[row * p.anc_ld + pos] = pos < t ? an[r][q] : (int)row;     // positions < t inherited, the rest the row's own
+            if (p.anc) p.anc[crow * p.anc_ld + pos] = pos < t ? an[r][q] : own;         // positions < t inherited, the rest the row's own
           }
         }
         if (lane == 0) {
           p.cur_p[row] = new_p[r];
-          p.ids_out[row] = tokv;
-          if (p.parent_out) p.parent_out[row] = flat[r] / k;
+          p.ids_out[crow] = tokv;
+          if (p.parent_out) p.parent_out[crow] = flat[r] / k;
         }
       }
   } else if (lane < k) {
-    p.ids_out[(long)n * k + lane] = 0;                                  // a finished molecule keeps decoding [PAD]s nobody reads
-    if (p.parent_out) p.parent_out[(long)n * k + lane] = lane;
+    p.ids_out[(long)ci * k + lane] = 0;                                 // a finished molecule keeps decoding [PAD]s nobody reads
+    if (p.parent_out) p.parent_out[(long)ci * k + lane] = lane;
   }
   if (lane == 0) {
     p.fin_n[n] = fin_n;
@@ -419,12 +425,13 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
 
 extern "C" int spmm_beam_step(const float* logits, long ldl, int N, int k, int V, int Lmax, int F, int t, const int* t_ptr, int t_off,
                               int* tokens, float* cur_p, float* fin_p, int* fin_len, int* fin_tok, int* fin_n, unsigned char* done,
-                              int* anc, int anc_ld, int* ids_out, int* parent_out, int* n_done, hipStream_t stream) {
+                              int* anc, int anc_ld, int* ids_out, int* parent_out, int* n_done, const int* mol, const int* rowmap,
+                              hipStream_t stream) {
   SPMM_CHECK_SHAPE(N > 0 && k >= 1 && k <= BEAM_KMAX && V >= k && V <= 512 && Lmax >= 3 && Lmax <= 256 && F >= k && ldl >= V,
                    "spmm_beam_step: N=%d k=%d V=%d Lmax=%d F=%d (k <= 8, k <= V <= 512, Lmax <= 256, F >= k)", N, k, V, Lmax, F);
   SPMM_CHECK_SHAPE(anc == nullptr || anc_ld >= Lmax, "spmm_beam_step: anc_ld=%d < Lmax=%d", anc_ld, Lmax);
   SPMM_CHECK_SHAPE(t_ptr != nullptr || (t >= 1 && t < Lmax), "spmm_beam_step: t=%d outside [1, Lmax)", t);
-  BeamP p = {logits, ldl, N, k, V, Lmax, F, t, t_ptr, t_off, tokens, cur_p, fin_p, fin_len, fin_tok, fin_n, done, anc, anc_ld, ids_out, parent_out, n_done};
+  BeamP p = {logits, ldl, N, k, V, Lmax, F, t, t_ptr, t_off, tokens, cur_p, fin_p, fin_len, fin_tok, fin_n, done, anc, anc_ld, ids_out, parent_out, n_done, mol, rowmap};
   const dim3 grid((unsigned)((N + 3) / 4));
   if (V <= 320) hipLaunchKernelGGL(beam_step_kernel<5>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(beam_step_kernel<8>, grid, dim3(256), 0, stream, p);

@@ -10,6 +10,8 @@ import torch
 
 CLS_ID, SEP_ID = 2, 3           # vocab_bpe_300.txt:3-4
 GRAPH_BELOW_ROWS = 2500         # beam rows below which a decode position is bound by its launches (bench.py --decode --chunk 250 / 500)
+last_run: dict = {}             # what the last eager beam_search_batched did: molecules, compactions, final_batch, positions
+COMPACT_BELOW = 0.75            # the batch is re-gathered once at most this share of its molecules is still live
 FUSED_BEAM_STEP = True          # beam bookkeeping of a position as one HIP launch (spmm_beam_step); False: the tensor-op form (BeamBook.update)
 
 
@@ -63,6 +65,7 @@ class BeamBook:
         self.fin_n = torch.zeros(N, dtype=it, device=device)
         self.done = torch.zeros(N, dtype=torch.bool, device=device)
         self.n_done = torch.zeros(1, dtype=torch.int32, device=device) if fused else None
+        self.mol = None                                   # fused, after compact(): int32 indices of the molecules still decoded
 
     def first(self, values: torch.Tensor, indices: torch.Tensor):
         """values/indices [N,k]: log-probs and ids of the k best successors of [CLS]."""
@@ -124,13 +127,23 @@ class BeamBook:
         self.done.logical_or_(self.fin_n >= k)
         return parent, tok
 
+    def live_slots(self) -> torch.Tensor:
+        """Positions (in the current, possibly compacted batch) of the molecules that are not done yet."""
+        done = self.done if self.mol is None else self.done[self.mol.long()]
+        return (~done).nonzero().squeeze(1)
+
+    def compact(self, keep: torch.Tensor):
+        """Keep only the batch slots `keep` (from live_slots()); the state arrays stay whole, the kernel indexes them through `mol`."""
+        cur = torch.arange(self.N, dtype=torch.int32, device=self.done.device) if self.mol is None else self.mol
+        self.mol = cur[keep].contiguous()
+
     def step_fused(self, logits: torch.Tensor, anc: torch.Tensor | None = None, t_ptr: torch.Tensor | None = None, t_off: int = 0,
-                   ids_out: torch.Tensor | None = None) -> torch.Tensor:
+                   ids_out: torch.Tensor | None = None, rowmap: torch.Tensor | None = None) -> torch.Tensor:
         """`update` (and the decoder's ancestry reorder) as one HIP launch on the next-token logits [N*k, V]: softmax, the k best successors
         per beam, finals, survivors, token histories, `anc` -- all in place.  Returns the tokens to feed next (int32 [N*k]).  With t_ptr
         (device int32 [1]) the number of tokens held comes from device memory (*t_ptr + t_off) and self.t is left to the caller."""
         from . import ops
-        ids = ops.beam_step(logits, self, t=self.t, t_ptr=t_ptr, t_off=t_off, anc=anc, ids_out=ids_out)
+        ids = ops.beam_step(logits, self, t=self.t, t_ptr=t_ptr, t_off=t_off, anc=anc, ids_out=ids_out, rowmap=rowmap)
         if t_ptr is None:
             self.t += 1
         return ids
@@ -199,6 +212,7 @@ class CachedDecoder:
         self.vc = [torch.empty(self.R, c.num_attention_heads, Lmax, 64, dtype=BF, device=dev) for _ in range(nl)]
         self.anc = torch.arange(self.R, dtype=torch.int32, device=dev)[:, None].repeat(1, Lmax).contiguous()
         self.rows = torch.arange(self.R, dtype=torch.int32, device=dev)
+        self.rowmap = None                               # after compact(): cache row of every beam row still decoded (None: the row itself)
         kv_src = prop_embeds.to(dev).to(BF).reshape(N * Lkv, H).contiguous()
         self.xkv = {}
         for l in range(c.fusion_layer, nl):
@@ -209,6 +223,20 @@ class CachedDecoder:
 
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.BF, device=self.anc.device)
+
+    @torch.no_grad()
+    def compact(self, keep: torch.Tensor):
+        """Drop every molecule but the batch slots `keep` (int64, ascending) from the decoded batch: activations shrink to len(keep) * k
+        rows.  The K/V caches are NOT moved -- the ancestry table keeps naming the cache rows, and `rowmap` says where a surviving row
+        writes its next position -- only the ancestry rows and the (per-molecule) cross-attention keys / values are gathered."""
+        k, L, Lp = self.k, self.Lmax, self.Lp
+        cur = self.rows if self.rowmap is None else self.rowmap
+        self.rowmap = cur.view(self.N, k)[keep].reshape(-1).contiguous()
+        self.anc = self.anc.view(self.N, k, L)[keep].reshape(-1, L).contiguous()
+        for l, KV in self.xkv.items():
+            self.xkv[l] = KV.view(self.N, Lp, KV.shape[1])[keep].reshape(-1, KV.shape[1]).contiguous()
+        self.N = int(keep.numel())
+        self.R = self.N * k
 
     def _attn_out(self, pf, ctx, resid):
         ops, P, c = self.ops, self.P, self.c
@@ -237,7 +265,8 @@ class CachedDecoder:
                         bias=P.fused(pf + "self.", ("query", "key", "value"), "bias", what="w"))
             ctx = self._new(R, H)                       # (the launch also moves the new key / value rows into the cache)
             ops.decode_attn(QKV[:, :H], self.kc[l], self.vc[l], ctx, nH=nH, Lkv=self.Lmax if t_dev is not None else t + 1,
-                            seq_stride=self.Lmax * H, tok_stride=64, head_stride=self.Lmax * 64, anc=self.anc, group=self.k, t_ptr=t_dev, knew=QKV[:, H:2 * H], vnew=QKV[:, 2 * H:])
+                            seq_stride=self.Lmax * H, tok_stride=64, head_stride=self.Lmax * 64, anc=self.anc, group=self.k, t_ptr=t_dev, knew=QKV[:, H:2 * H], vnew=QKV[:, 2 * H:],
+                            rowmap=self.rowmap)
             a = self._attn_out(pf, ctx, x)
             if l >= c.fusion_layer:
                 pf = lp + "crossattention."
@@ -273,7 +302,7 @@ class CachedDecoder:
 @torch.no_grad()
 def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int = 100, cached: bool | None = None,
                         sync_every: int = 4, prop_mask: torch.Tensor | None = None, stochastic: bool = False,
-                        generator=None, graph: bool | None = None) -> List[List[Tuple[float, List[int]]]]:
+                        generator=None, graph: bool | None = None, compact: bool = True) -> List[List[Tuple[float, List[int]]]]:
     """The reference's beam search for N molecules at once (props [N,53]); result[n] is what the one-molecule search
     (oracle/decode_oracle.py::beam_search) returns for props[n].
     cached=True (default on the HIP model) decodes one token per step against the K/V cache; cached=False re-runs the prefix
@@ -282,7 +311,8 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     taking the k most probable (d_pv2smiles_single.py:37-40); `generator` seeds those draws.  graph=True (cached, deterministic)
     captures one decode position -- ~230 launches -- as a hipGraph and replays it: the per-position host cost drops from ~2.3 ms
     of launch overhead to one graph launch, which is what small batches are bound by.  graph=None (default): replay when the batch
-    is launch-bound -- fewer than GRAPH_BELOW_ROWS beam rows -- and the search is deterministic."""
+    is launch-bound -- fewer than GRAPH_BELOW_ROWS beam rows -- and the search is deterministic.  compact=True (eager fused path): finished
+    molecules are dropped from the batch as the search goes (same results; the reference decodes one molecule at a time and simply stops)."""
     if cached is None:
         cached = hasattr(model, "engine")
     if graph is None:
@@ -301,17 +331,37 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     ids = indices.reshape(N * k)
     if graph and cached and not stochastic:
         return _decode_graphed(dec, book, ids, N, k, max_steps, sync_every)
+    n_cur = N
+    last_run.update(molecules=N, compactions=0, final_batch=N, positions=0)
     for s in range(max_steps):
         logits = dec.step(ids, s + 1)
         if fused:
-            ids = book.step_fused(logits, dec.anc)
+            ids = book.step_fused(logits, dec.anc, rowmap=dec.rowmap)
         else:
             values, indices = _pick(torch.softmax(logits.view(N, k, -1).float(), dim=-1), k, stochastic, generator)
             parent, tok = book.update(values, indices)
             dec.reorder(parent, s + 2)
             ids = tok.reshape(N * k)
-        if s % sync_every == sync_every - 1 and book.all_done():
-            break
+        if s % sync_every == sync_every - 1:
+            if not fused:
+                if book.all_done():
+                    break
+                continue
+            n_live = N - int(book.n_done.item())         # the one host read of the loop
+            if n_live == 0:
+                break
+            if compact:
+                # molecules that hold their k finals stop costing anything: once a quarter of the batch is done the rest is gathered into
+                # a smaller batch (caches stay where they are, CachedDecoder.compact)
+                if n_live <= COMPACT_BELOW * n_cur and n_cur - n_live >= 4:
+                    keep = book.live_slots()
+                    dec.compact(keep)
+                    book.compact(keep)
+                    ids = ids.view(n_cur, k)[keep].reshape(-1).contiguous()
+                    n_cur = int(keep.numel())
+                    last_run["compactions"] += 1
+                    last_run["final_batch"] = n_cur
+        last_run["positions"] = s + 1
     return book.results()
 
 

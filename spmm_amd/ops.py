@@ -393,7 +393,8 @@ def embed_step_ln_fwd(ids32, pos_index, y, *, word, pos, type0, gamma, beta, eps
     return y
 
 
-def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, head_stride=64, anc=None, kv_div=1, group=1, scale=0.125, t_ptr=None, knew=None, vnew=None):
+def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, head_stride=64, anc=None, kv_div=1, group=1, scale=0.125, t_ptr=None, knew=None, vnew=None,
+                rowmap=None):
     """Single-query attention over a K/V cache; q/out: [R, >=nH*64] bf16 views, K/V: bf16 views whose element (s, j, h*64+d)
     sits at s*seq_stride + j*tok_stride + h*head_stride + d from their first element (head_stride 64: token-major rows).  knew / vnew ([R, nH*64] bf16 views, self-attention
     only): key / value of the newest position, which the launch also writes into the cache."""
@@ -403,15 +404,18 @@ def decode_attn(q, K, V, out, *, nH, Lkv, seq_stride, tok_stride, head_stride=64
     assert (knew is None) == (vnew is None) and (knew is None or (knew.dtype == BF16 and vnew.dtype == BF16 and _row_stride(knew) == _row_stride(vnew)))
     _call("spmm_decode_attn", _p(q), _row_stride(q), _p(K), _p(V), int(seq_stride), int(tok_stride), int(head_stride), _p(anc),
           0 if anc is None else _row_stride(anc), int(kv_div), int(group), _p(out), _row_stride(out), R, nH, Lkv, float(scale), _p(t_ptr),
-          _p(knew), _p(vnew), 0 if knew is None else _row_stride(knew), _st())
+          _p(knew), _p(vnew), 0 if knew is None else _row_stride(knew), _p(rowmap), _st())
     return out
 
 
-def beam_step(logits, book, *, t=0, t_ptr=None, t_off=0, anc=None, ids_out=None, parent_out=None):
+def beam_step(logits, book, *, t=0, t_ptr=None, t_off=0, anc=None, ids_out=None, parent_out=None, rowmap=None):
     """One position of the batched k-beam search on a decode.BeamBook with int32 state (csrc/decode.hip::beam_step_kernel): updates
     the book (and the ancestry table `anc` of the K/V cache) in place and returns the tokens to feed next, int32 [N*k]."""
-    N, k, L = book.tokens.shape
+    _, k, L = book.tokens.shape
+    mol = getattr(book, "mol", None)                      # int32 [N]: the live molecules of a compacted batch (None: all of them)
+    N = book.tokens.shape[0] if mol is None else mol.numel()
     assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[0] == N * k and logits.stride(1) == 1
+    assert (mol is None or mol.dtype == torch.int32) and (rowmap is None or (rowmap.dtype == torch.int32 and rowmap.numel() == N * k))
     assert book.tokens.dtype == torch.int32 and book.fin_tok.dtype == torch.int32 and book.fin_len.dtype == torch.int32 and book.fin_n.dtype == torch.int32
     assert book.tokens.is_contiguous() and book.fin_tok.is_contiguous() and book.cur_p.is_contiguous() and book.fin_p.is_contiguous()
     assert anc is None or (anc.dtype == torch.int32 and anc.shape[0] == N * k and anc.stride(1) == 1)
@@ -419,7 +423,7 @@ def beam_step(logits, book, *, t=0, t_ptr=None, t_off=0, anc=None, ids_out=None,
         ids_out = torch.empty(N * k, dtype=torch.int32, device=logits.device)
     _call("spmm_beam_step", _p(logits), logits.stride(0), N, k, logits.shape[1], L, book.F, int(t), _p(t_ptr), int(t_off), _p(book.tokens),
           _p(book.cur_p), _p(book.fin_p), _p(book.fin_len), _p(book.fin_tok), _p(book.fin_n), _p(book.done), _p(anc),
-          0 if anc is None else anc.stride(0), _p(ids_out), _p(parent_out), _p(book.n_done), _st())
+          0 if anc is None else anc.stride(0), _p(ids_out), _p(parent_out), _p(book.n_done), _p(mol), _p(rowmap), _st())
     return ids_out
 
 

@@ -872,6 +872,29 @@ def test_batched_decode_against_the_reference_search(env, golden_dir):
     assert same >= props.shape[0] - 2, diff
 
 
+@pytest.mark.parametrize("seed,gap,scale", [(5, 0.9, 10.0), (2, 0.9, 2.0)])
+def test_batched_decode_drops_finished_molecules(env, seed, gap, scale):
+    """Molecules that hold their k finals leave the decoded batch (decode.beam_search_batched(compact=True): activations, ancestry rows and
+    cross-attention keys / values are gathered for the live ones, the K/V caches stay in place behind a row map): the hypotheses are those
+    of the run that keeps every molecule to the end -- token for token, scores within 1e-4 -- on a model whose molecules finish at different
+    positions (some never collect five finals), and the batch really shrank."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd import decode
+    sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), seed=seed, sep_gap=gap)
+    m = _mk(SPMM, tiny_config(), sd).eval()
+    props = torch.randn(32, 53, generator=torch.Generator().manual_seed(12)) * scale
+    whole = decode.beam_search_batched(m, props, k=5, max_steps=40, compact=False, graph=False)      # (eager: a replayed graph has a fixed batch)
+    assert decode.last_run["compactions"] == 0
+    small = decode.beam_search_batched(m, props, k=5, max_steps=40, compact=True, graph=False)
+    run = dict(decode.last_run)
+    print(f"decode with compaction: {run}")
+    assert run["compactions"] >= 1 and run["final_batch"] < 32
+    assert [[h[1] for h in mol] for mol in small] == [[h[1] for h in mol] for mol in whole]
+    for a, b in zip(small, whole):
+        for (pa, _), (pb, _) in zip(a, b):
+            assert abs(pa - pb) < 1e-4
+
+
 def _check_cached_beam_search(O, SPMM, tiny_config, decode, sep_gap):
     sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), sep_gap=sep_gap)
     m = _mk(SPMM, tiny_config(), sd).eval()
