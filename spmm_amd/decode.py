@@ -9,7 +9,9 @@ from typing import List, Tuple
 import torch
 
 CLS_ID, SEP_ID = 2, 3           # vocab_bpe_300.txt:3-4
-GRAPH_BELOW_ROWS = 2500         # beam rows below which a decode position is bound by its launches (bench.py --decode --chunk 250 / 500)
+GRAPH_BELOW_ROWS = 200          # beam rows below which one hipGraph replay per position is the default: with the bookkeeping in one launch a position is a
+#                                 chain of ~130 dependent kernels (1.95 ms at 100 rows, 2.2 at 1 000, 3.6 at 5 000) and replay gains 7 % at 100 rows, 2 % at
+#                                 250, nothing from 500 on -- and a replayed graph has a fixed batch: no compaction of finished molecules
 last_run: dict = {}             # what the last eager beam_search_batched did: molecules, compactions, final_batch, positions
 COMPACT_BELOW = 0.75            # the batch is re-gathered once at most this share of its molecules is still live
 FUSED_BEAM_STEP = True          # beam bookkeeping of a position as one HIP launch (spmm_beam_step); False: the tensor-op form (BeamBook.update)
