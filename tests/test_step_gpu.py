@@ -1364,17 +1364,25 @@ def test_conditional_and_stochastic_generation(env):
 
 def test_graph_replayed_decode_equals_eager(env):
     """beam_search_batched(graph=True): one decode position captured as a hipGraph (step index, cache slot, ancestry column and
-    beam bookkeeping all in device memory) and replayed -- same hypotheses and scores as the eager loop."""
+    beam bookkeeping all in device memory) and replayed -- same hypotheses and scores as the eager loop; and the same again with the
+    beam bookkeeping as tensor operations instead of the one-launch kernel (the fallback for more than 8 beams)."""
     O, SPMM, tiny_config, *_ = env
     from spmm_amd import decode
     for sep_gap in (0.4, 0.7):
         sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), sep_gap=sep_gap)
         m = _mk(SPMM, tiny_config(), sd).eval()
         props = torch.randn(6, 53, generator=torch.Generator().manual_seed(4)) * 2
-        eager = decode.beam_search_batched(m, props, k=5, max_steps=14)
+        eager = decode.beam_search_batched(m, props, k=5, max_steps=14, graph=False)
         graphed = decode.beam_search_batched(m, props, k=5, max_steps=14, graph=True)
-        assert len(eager) == len(graphed)
-        for a, b in zip(eager, graphed):
-            assert [s for _, s in a] == [s for _, s in b]
-            assert all(abs(pa - pb) < 1e-5 for (pa, _), (pb, _) in zip(a, b))
+        runs = [graphed]
+        decode.FUSED_BEAM_STEP = False                # the tensor-op bookkeeping (BeamBook.update / update_dev), eager and replayed
+        try:
+            runs += [decode.beam_search_batched(m, props, k=5, max_steps=14, graph=False), decode.beam_search_batched(m, props, k=5, max_steps=14, graph=True)]
+        finally:
+            decode.FUSED_BEAM_STEP = True
+        for other in runs:
+            assert len(eager) == len(other)
+            for a, b in zip(eager, other):
+                assert [s for _, s in a] == [s for _, s in b]
+                assert all(abs(pa - pb) < 1e-5 for (pa, _), (pb, _) in zip(a, b))
         assert sum(len(h) for h in eager) >= 6
