@@ -108,8 +108,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
 // bytes, G times the load instructions and L1 / L2 requests.  Ancestor indices are staged in LDS first (coalesced), so the key loads
 // do not wait for a dependent index load.  Arithmetic per (row, head) is the per-beam kernel's (fp32 dots over 8 lanes x 8 elements,
 // two passes, bf16-rounded probabilities in front of V).
+// Round 4: the kernel waits (SQ_WAIT_ANY 0.66 of wave cycles), so its loads are issued in batches: the whole prologue (query rows and
+// ancestry entries) before anything is consumed, and -- where some beam of an iteration sits on another cache row -- every beam's row
+// back to back behind ONE wave-uniform branch instead of a load behind its own divergent branch per beam (one memory latency each).
+// 4 waves per SIMD is both what the LDS arrays allow and what the register budget is held to (amdgpu_waves_per_eu: left alone the batched
+// form takes 168 registers, three waves, and loses what the batching wins).  5 000 rows x 12 heads, last six positions on own rows:
+// 60.5 -> 48.1 us at 25 keys, 83.7 -> 64.5 at 50, 130 -> 105 at 100 (tools/bench_decode_attn.py).
 template <int G, bool ALLSAME>   // ALLSAME: no ancestry table, every beam of the molecule reads the same key/value rows (cross-attention)
-__global__ __launch_bounds__(256) void decode_attn_group_kernel(DecAttnP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_attn_group_kernel(DecAttnP p) {
   __shared__ float ssc[4][G][256];                   // scores of the wave's G (row, head) pairs
   __shared__ int sanc[4][G][256];                    // cache row of position j for each beam (16 waves per CU at G = 5; sized by Lkv with
   //                                                    run-time strides -- 32 waves per CU -- it measured SLOWER: 99 vs 84 us per launch,
@@ -125,47 +131,86 @@ __global__ __launch_bounds__(256) void decode_attn_group_kernel(DecAttnP p) {
   const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
   const int niter = (Lkv + 7) >> 3;
   float qf[G][8];
+  {
+    // every load of the prologue is issued before the first one is consumed (query rows, then the ancestry entries lane, lane + 64, ...
+    // of every beam: a loop that loads and stores one entry at a time waits out a memory latency per entry -- 5 to 10 of them in a row)
+    bf16x8 qv[G];
+    int av[ALLSAME ? 1 : G][4];
 #pragma unroll
-  for (int b = 0; b < G; ++b) {
-    const int r = n * G + b;
-    const bf16x8 qv = *(const bf16x8*)(p.q + (long)r * p.ldq + h * 64 + c * 8);
+    for (int b = 0; b < G; ++b) qv[b] = *(const bf16x8*)(p.q + (long)(n * G + b) * p.ldq + h * 64 + c * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qf[b][e] = (float)qv[e] * p.scale;
-    if (!ALLSAME || b == 0)
-      for (int j = lane; j < niter * 8; j += 64)
-        sanc[wave][b][j] = p.anc ? (j < Lkv ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
+    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u, r = n * G + b;
+        av[b][u] = p.anc ? ((j < Lkv) ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
+      }
+#pragma unroll
+    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < niter * 8) sanc[wave][b][lane + 64 * u] = av[b][u];
+#pragma unroll
+    for (int b = 0; b < G; ++b)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[b][e] = (float)qv[b][e] * p.scale;
   }
   __builtin_amdgcn_wave_barrier();
   const long hoff = h * p.head_stride + c * 8;
   float mx[G];
 #pragma unroll
   for (int b = 0; b < G; ++b) mx[b] = -INFINITY;
+  // one key's partial dot products for beam B from row KB (8 lanes x 8 elements, reduced over the key's 8 lanes)
+#define DA_SCORE(B, KB)                                                                                          \
+  do {                                                                                                           \
+    float part = 0.f;                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) part += (float)(KB)[e] * qf[B][e];                            \
+    part += dpp_f<0xB1>(part); part += dpp_f<0x4E>(part); part += dpp_f<0x141>(part);                            \
+    if (valid) {                                                                                                 \
+      if (c == 0) ssc[wave][B][j] = part;                                                                        \
+      mx[B] = fmaxf(mx[B], part);                                                                                \
+    }                                                                                                            \
+  } while (0)
   for (int i = 0; i < niter; ++i) {
     const int j = i * 8 + g;
     const bool valid = j < Lkv;
     const long joff = (long)j * p.tok_stride + hoff;
-    const int a0 = sanc[wave][0][j];
+    int ab[G];
+#pragma unroll
+    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
+    const int a0 = ab[0];
+    bool diff = false;
+    if (!ALLSAME) {
+#pragma unroll
+      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
+    }
     bf16x8 k0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) k0[e] = (bf16)0.f;
     if (valid) k0 = *(const bf16x8*)(p.K + (long)a0 * p.seq_stride + joff);
+    if (!ALLSAME && __any(valid && diff)) {
+      // some beam of some key of this iteration sits on another cache row (the last few positions of a hypothesis): every beam's row is
+      // loaded, back to back with no control flow in between (a load per differing beam behind its own branch waits out one memory
+      // latency per beam; the rows that do not differ hit the line beam 0 just fetched)
+      bf16x8 kb[G];
 #pragma unroll
-    for (int b = 0; b < G; ++b) {
-      bf16x8 kb = k0;
-      if (!ALLSAME && b > 0) {
-        const int ab = sanc[wave][b][j];
-        if (valid && ab != a0) kb = *(const bf16x8*)(p.K + (long)ab * p.seq_stride + joff);
+      for (int b = 1; b < G; ++b) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kb[b][e] = (bf16)0.f;
       }
-      float part = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) part += (float)kb[e] * qf[b][e];
-      part += dpp_f<0xB1>(part); part += dpp_f<0x4E>(part); part += dpp_f<0x141>(part);     // over the key's 8 lanes
       if (valid) {
-        if (c == 0) ssc[wave][b][j] = part;
-        mx[b] = fmaxf(mx[b], part);
+#pragma unroll
+        for (int b = 1; b < G; ++b) kb[b] = *(const bf16x8*)(p.K + (long)ab[b] * p.seq_stride + joff);
       }
+      DA_SCORE(0, k0);
+#pragma unroll
+      for (int b = 1; b < G; ++b) DA_SCORE(b, kb[b]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < G; ++b) DA_SCORE(b, k0);
     }
   }
+#undef DA_SCORE
 #pragma unroll
   for (int b = 0; b < G; ++b) mx[b] = wave_max(mx[b]);
   __builtin_amdgcn_wave_barrier();
@@ -176,28 +221,51 @@ __global__ __launch_bounds__(256) void decode_attn_group_kernel(DecAttnP p) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[b][d] = 0.f;
   }
-#pragma unroll 2
+#define DA_ACC(B, VB)                                                                                            \
+  do {                                                                                                           \
+    const float e_ = valid ? __expf(ssc[wave][B][j] - mx[B]) : 0.f;                                              \
+    sum[B] += e_;                                                                                                \
+    const float pe_ = (float)(bf16)e_;             /* the tiled training kernel feeds bf16 probabilities to the PV MFMA */ \
+    _Pragma("unroll") for (int d = 0; d < 8; ++d) acc[B][d] += pe_ * (float)(VB)[d];                            \
+  } while (0)
+#pragma unroll 1
   for (int i = 0; i < niter; ++i) {
     const int j = i * 8 + g;
-    if (j < Lkv) {
-      const long joff = (long)j * p.tok_stride + hoff;
-      const int a0 = sanc[wave][0][j];
-      const bf16x8 v0 = *(const bf16x8*)(p.V + (long)a0 * p.seq_stride + joff);
+    const bool valid = j < Lkv;
+    const long joff = (long)j * p.tok_stride + hoff;
+    int ab[G];
 #pragma unroll
-      for (int b = 0; b < G; ++b) {
-        bf16x8 vb = v0;
-        if (!ALLSAME && b > 0) {
-          const int ab = sanc[wave][b][j];
-          if (ab != a0) vb = *(const bf16x8*)(p.V + (long)ab * p.seq_stride + joff);
-        }
-        const float e = __expf(ssc[wave][b][j] - mx[b]);
-        sum[b] += e;
-        const float pe = (float)(bf16)e;             // the tiled training kernel feeds bf16 probabilities to the PV MFMA
+    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
+    const int a0 = ab[0];
+    bool diff = false;
+    if (!ALLSAME) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[b][d] += pe * (float)vb[d];
+      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
+    }
+    bf16x8 v0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) v0[d] = (bf16)0.f;
+    if (valid) v0 = *(const bf16x8*)(p.V + (long)a0 * p.seq_stride + joff);
+    if (!ALLSAME && __any(valid && diff)) {
+      bf16x8 vb[G];
+#pragma unroll
+      for (int b = 1; b < G; ++b) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) vb[b][d] = (bf16)0.f;
       }
+      if (valid) {
+#pragma unroll
+        for (int b = 1; b < G; ++b) vb[b] = *(const bf16x8*)(p.V + (long)ab[b] * p.seq_stride + joff);
+      }
+      DA_ACC(0, v0);
+#pragma unroll
+      for (int b = 1; b < G; ++b) DA_ACC(b, vb[b]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < G; ++b) DA_ACC(b, v0);
     }
   }
+#undef DA_ACC
 #pragma unroll
   for (int b = 0; b < G; ++b) {
 #pragma unroll
