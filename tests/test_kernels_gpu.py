@@ -1313,12 +1313,13 @@ def test_embed_step_matches_full_embedding(ops):
         assert torch.equal(y, full.view(n, L, H)[:, t])
 
 
-def test_beam_step_kernel_matches_tensor_bookkeeping():
+@pytest.mark.parametrize("N,k,V", [(37, 5, 300), (9, 8, 300), (20, 1, 70), (6, 3, 500)])
+def test_beam_step_kernel_matches_tensor_bookkeeping(N, k, V):
     """csrc/decode.hip::beam_step_kernel (one launch per decode position) against decode.BeamBook.update + CachedDecoder.reorder (the
     tensor-op form of d_pv2smiles_batched.py:36-50) on random logits in which [SEP] is a frequent top-k member: same finals in the same
     slots, same survivors, token histories, scores, ancestry table and tokens to feed, position by position until every molecule is done."""
     from spmm_amd import decode
-    N, k, V, T = 37, 5, 300, 16
+    T = 16
     L, R = T + 3, N * k
     g = torch.Generator().manual_seed(3)
     ref, fus = decode.BeamBook(N, k, T, "cuda"), decode.BeamBook(N, k, T, "cuda", fused=True)
@@ -1360,6 +1361,6 @@ def test_beam_step_kernel_matches_tensor_bookkeeping():
         n_fin = int(ref.fin_n.sum())
         if bool(ref.done.all()):
             break
-    assert n_fin > 2 * N and bool(ref.done.any())
+    assert n_fin >= min(N, 8) and bool(ref.done.any())
     got, want = fus.results(), ref.results()
     assert [[h[1] for h in m] for m in got] == [[h[1] for h in m] for m in want]
