@@ -54,6 +54,9 @@ const char* spmm_last_error(void);
  * operands, their dgrad/wgrad GEMMs; also the similarity GEMMs SPMM_models.py:108-111,121-124 (split-bf16 K=3E).
  * colsum (optional, bf16 / GELU-grad epilogues): colsum[n] += sum_m C[m][n] -- the bias gradient when C is a dY.
  * kernel (per call, no process state): 0 = chosen from the shape; SPMM_GEMM_K128 = 128x128 tile (every epilogue, split-K);
+ * SPMM_GEMM_K128PC = the 128x128 tile with four loader waves beside the four compute waves (LDS-DMA issue and a four-stage ring off the
+ * computing waves' instruction stream; holds a CU alone: chosen where the tiling gives at most one workgroup per CU -- the decoder's
+ * 5 000-row launches);
  * SPMM_GEMM_K256x128 = 256x128 three-stage ring (no atomic epilogue); SPMM_GEMM_K256 = 256x256 tile, one barrier per k-step;
  * SPMM_GEMM_K256P8 = 256x256 tile on the 8-phase schedule (bf16-output epilogues, K % 128 == 0) -- the default for the
  * training step's large GEMMs: one persistent workgroup per CU walking its XCD's tile range.  SPMM_GEMM_K256P8_TILES = the same
@@ -64,6 +67,7 @@ const char* spmm_last_error(void);
 #define SPMM_GEMM_K128 1
 #define SPMM_GEMM_K256x128 2
 #define SPMM_GEMM_K256 3
+#define SPMM_GEMM_K128PC 5
 #define SPMM_GEMM_K256P8 8
 #define SPMM_GEMM_K256P8_TILES 9
 #define SPMM_GEMM_AUTO_TILES 16

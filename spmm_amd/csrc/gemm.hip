@@ -208,6 +208,68 @@ __device__ __forceinline__ void epilogue_bf16(const GemmP& p, f32x16 (&acc)[2][2
   epi_store<EPI>(p, wtile, wtile + 8192, m_base, n_base, lane, cs_carry, flush);
 }
 
+// The output side of the 128x128 kernels (4 waves as 2 x 2, 64 x 64 per wave): bf16 epilogues through the wave's 16 KiB of LDS, the
+// fp32 ones straight from the accumulators.
+template <int EPI>
+__device__ __forceinline__ void tile128_out(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int wave, int m0, int n0, int wm, int wn, int lane) {
+  if constexpr (epi_is_bf16(EPI)) {                   // (the caller's barrier: every wave is done reading the staging buffers)
+    epilogue_bf16<EPI>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
+  // ---- epilogue: acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][g * 4 + j] * scale;
+        if (p.bias && (EPI != EPI_F32_ATOMIC || blockIdx.z == 0)) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += b[j];
+        }
+        if (p.R) {
+          const bf16x4 r = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+        if constexpr (EPI == EPI_BF16) {
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (EPI == EPI_GELU) {
+          *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        } else if constexpr (EPI == EPI_GELU_GRAD) {
+          const bf16x4 x = *(const bf16x4*)(p.G + (long)m * p.ldg + n);
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
+              to_bf16x4(v[0] * gelu_erf_grad((float)x[0]), v[1] * gelu_erf_grad((float)x[1]),
+                        v[2] * gelu_erf_grad((float)x[2]), v[3] * gelu_erf_grad((float)x[3]));
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o;
+        } else if constexpr (EPI == EPI_F32_ACC) {
+          f32x4* dst = (f32x4*)((float*)p.C + (long)m * p.ldc + n);
+          f32x4 o = *dst;
+          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+          *dst = o;
+        } else {  // EPI_F32_ATOMIC
+          float* dst = (float*)p.C + (long)m * p.ldc + n;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(dst + j, v[j]);
+        }
+      }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -268,63 +330,158 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     }
   }
 
-  if constexpr (epi_is_bf16(EPI)) {
-    __syncthreads();                                  // every wave is done reading the staging buffers
-    epilogue_bf16<EPI>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+  if constexpr (epi_is_bf16(EPI)) __syncthreads();   // every wave is done reading the staging buffers
+  tile128_out<EPI>(p, acc, smem, wave, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pc: the same 128x128x64 tile with the work of a k-step split between two kinds of waves -- 4 COMPUTE waves (the 128x128 kernel's
+// wave tiles, MFMAs and epilogues; fragment reads one k-slice ahead of the MFMAs) and 4 LOADER waves that issue every LDS-DMA of a
+// four-stage ring and count their own vmcnt.  One wave of each kind per SIMD: a loader's DMA issue (8 instructions per k-step, 60-185
+// cycles each) runs beside its partner's 16 MFMAs instead of in front of them, and three K-tiles are in flight instead of one.  (With the
+// loads issued by the computing waves themselves the deeper ring alone measured nothing, EXPERIMENTS.md 1.11: the k-step was the wave's own
+// instruction stream.)  One raw s_barrier per k-step: barrier(kt) = "K-tile kt has landed (the loaders waited for their pieces) and every
+// compute wave is done reading K-tile kt-1 (its fragment reads are consumed by MFMAs issued before the barrier)"; after it the loaders
+// restage the stage of K-tile kt-1 with K-tile kt+3.
+// Measured (tools/gemm_small_m.py, M = 5 000): 768x768 13.9 -> 12.2 us, 768x3072 36.2 -> 27.3-28.8 us; ~980 cycles per k-step against
+// ~1 370 -- and neither eight loader waves, nor a fifth stage, nor double-buffered fragments move it further: four waves of 64x64 tiles read
+// 64 KiB of fragments per k-step and the DMA writes another 32 KiB, 768 cycles of the CU's 128-B/clk LDS against 512 of the matrix pipe
+// (the 256x256 tile's 128x64 wave tiles read half as much per FLOP).  It holds the CU alone (128 KiB), so it is the automatic choice only
+// where the 128x128 tiling gives at most one workgroup per CU; with more tiles several 32-KiB workgroups of the plain kernel share a CU
+// and win (5000x2304x768: 33.8 against 38 us).
+#ifndef PC_AUTO
+#define PC_AUTO 1                  // 0: never chosen automatically
+#endif
+constexpr int PC_STAGES = 4;                          // (5 stages -- all of the 160 KiB -- measured the same: the k-step is not waiting for its operands)
+constexpr int PC_LDS = PC_STAGES * STAGE_BYTES;     // 128 KiB
+#ifndef PC_LOADERS
+#define PC_LOADERS 4              // loader waves (4 or 8; 8 -- two per SIMD, four DMA instructions per wave and k-step -- measured the same)
+#endif
+constexpr int PC_LT = PC_LOADERS * 64;               // loader threads
+constexpr int PC_NC = 1024 / PC_LT;                  // 16-byte chunks of an operand tile per loader thread
+constexpr int PC_THREADS = 256 + PC_LT;
+
+template <int EPI>
+__global__ __launch_bounds__(PC_THREADS) void gemm_nt_pc_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_pc[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+  int t;
+  {
+    const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tile_m = t / ntn, tile_n = t % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.z * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  const int nk = (kend - kbeg) / BK;
+
+  if (wave >= 4) {
+    // ---------------- loader waves: chunk id = c * PC_LT + ltid -> tile row id >> 3, physical 16-B slot id & 7 (stage_tile_dma's layout)
+    const int ltid = tid - 256;
+    uint32_t offA[PC_NC], offW[PC_NC], dst[PC_NC];
+#pragma unroll
+    for (int c = 0; c < PC_NC; ++c) {
+      const int id = c * PC_LT + ltid;
+      const int row = id >> 3, ps = id & 7;
+      const int ls = ps ^ ((row >> 1) & 7);
+      int ga = m0 + row, gw = n0 + row;
+      ga = ga < p.M ? ga : p.M - 1;                        // clamped rows are computed and never stored
+      gw = gw < p.N ? gw : p.N - 1;
+      offA[c] = (uint32_t)ga * (uint32_t)(p.lda * 2) + (uint32_t)(ls * 16);
+      offW[c] = (uint32_t)gw * (uint32_t)(p.ldw * 2) + (uint32_t)(ls * 16);
+      dst[c] = (uint32_t)((c * PC_LT + (ltid & ~63)) * 16);  // wave-uniform: the wave's 64 chunks are contiguous in LDS
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem_pc;
+    const char* gA = (const char*)p.A + (size_t)kbeg * 2;
+    const char* gW = (const char*)p.W + (size_t)kbeg * 2;
+#define PC_DMA(VOFF, SBASE, LDSDST)                                                                                          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(LDSDST) : "memory", "m0")
+#define PC_STAGE(KT)                                                                                                         \
+    do {                                                                                                                     \
+      const uint32_t st_ = lds0 + (uint32_t)(((KT) % PC_STAGES) * STAGE_BYTES);                                              \
+      const char* a_ = gA + (size_t)(KT) * (BK * 2);                                                                         \
+      const char* w_ = gW + (size_t)(KT) * (BK * 2);                                                                         \
+      _Pragma("unroll") for (int c = 0; c < PC_NC; ++c) {                                                                    \
+        const uint32_t d_ = __builtin_amdgcn_readfirstlane(st_ + dst[c]);                                                    \
+        PC_DMA(offA[c], a_, d_);                                                                                             \
+      }                                                                                                                      \
+      _Pragma("unroll") for (int c = 0; c < PC_NC; ++c) {                                                                    \
+        const uint32_t d_ = __builtin_amdgcn_readfirstlane(st_ + (uint32_t)TILE_BYTES + dst[c]);                             \
+        PC_DMA(offW[c], w_, d_);                                                                                             \
+      }                                                                                                                      \
+    } while (0)
+    // K-tiles after `kt` still allowed in flight when K-tile kt must have landed: 2 * PC_NC DMA instructions each, issued in order
+#define PC_WAIT(NEWER)                                                                                                       \
+    do {                                                                                                                     \
+      if ((NEWER) >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PC_NC) : "memory");                                     \
+      else if ((NEWER) == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PC_NC) : "memory");                                \
+      else if ((NEWER) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PC_NC) : "memory");                                \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
+    } while (0)
+    constexpr int AHEAD = PC_STAGES - 1;                   // K-tiles issued beyond the one being multiplied
+    const int pre = nk < AHEAD ? nk : AHEAD;
+    for (int k = 0; k < pre; ++k) PC_STAGE(k);
+    PC_WAIT(pre - 1);                                      // K-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + AHEAD < nk) PC_STAGE(kt + AHEAD);           // into the stage of K-tile kt-1, read before the barrier just passed
+      const int last = kt + AHEAD < nk ? kt + AHEAD : nk - 1;      // newest K-tile issued
+      PC_WAIT(last - (kt + 1));                            // K-tile kt+1 landed (nothing to wait for after the last one)
+      __builtin_amdgcn_s_barrier();
+    }
+#undef PC_DMA
+#undef PC_STAGE
+#undef PC_WAIT
     return;
   }
-  // ---- epilogue: acc[ni][mi][r] = D[n][m], m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float scale = p.alpha;
-  if (p.div_ptr) scale /= *p.div_ptr;
+
+  // ---------------- compute waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + (lane & 31);
-      if (m >= p.M) continue;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
-        if (n >= p.N) continue;
-        float v[4];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // fragment addresses inside a stage: row (lane & 31) of the wave's two 32-row blocks, k-slot kk * 2 + (lane >> 5) behind the row swizzle
+  int aoff[2], woff[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][g * 4 + j] * scale;
-        if (p.bias && (EPI != EPI_F32_ATOMIC || blockIdx.z == 0)) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = (wm * 64 + i * 32 + (lane & 31)) * 128;
+    woff[i] = TILE_BYTES + (wn * 64 + i * 32 + (lane & 31)) * 128;
+  }
+  const int sw0 = ((wm * 64 + (lane & 31)) >> 1) & 7, sw1 = ((wn * 64 + (lane & 31)) >> 1) & 7;   // (+32 rows leave (row >> 1) & 7 unchanged)
+  const int hi = lane >> 5;
+#define PC_FRAGS(KK, BUF)                                                                                          \
+  do {                                                                                                             \
+    const int sa_ = (((KK) * 2 + hi) ^ sw0) << 4, sw_ = (((KK) * 2 + hi) ^ sw1) << 4;                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+      af[BUF][i] = *(const bf16x8*)(st + aoff[i] + sa_);                                                           \
+      wf[BUF][i] = *(const bf16x8*)(st + woff[i] + sw_);                                                           \
+    }                                                                                                              \
+  } while (0)
+  __builtin_amdgcn_s_barrier();                            // K-tile 0 landed
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* st = smem_pc + (kt % PC_STAGES) * STAGE_BYTES;
+    bf16x8 af[2][2], wf[2][2];                             // [buffer][32-row block]: the fragments of k-slice kk + 1 are read while the MFMAs of kk run
+    PC_FRAGS(0, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += b[j];
-        }
-        if (p.R) {
-          const bf16x4 r = *(const bf16x4*)(p.R + (long)m * p.ldr + n);
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) PC_FRAGS(kk + 1, (kk + 1) & 1);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-        }
-        if constexpr (EPI == EPI_BF16) {
-          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
-        } else if constexpr (EPI == EPI_GELU) {
-          *(bf16x4*)(p.C2 + (long)m * p.ldc2 + n) = to_bf16x4(v[0], v[1], v[2], v[3]);
-          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
-              to_bf16x4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-        } else if constexpr (EPI == EPI_GELU_GRAD) {
-          const bf16x4 x = *(const bf16x4*)(p.G + (long)m * p.ldg + n);
-          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) =
-              to_bf16x4(v[0] * gelu_erf_grad((float)x[0]), v[1] * gelu_erf_grad((float)x[1]),
-                        v[2] * gelu_erf_grad((float)x[2]), v[3] * gelu_erf_grad((float)x[3]));
-        } else if constexpr (EPI == EPI_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = o;
-        } else if constexpr (EPI == EPI_F32_ACC) {
-          f32x4* dst = (f32x4*)((float*)p.C + (long)m * p.ldc + n);
-          f32x4 o = *dst;
-          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
-          *dst = o;
-        } else {  // EPI_F32_ATOMIC
-          float* dst = (float*)p.C + (long)m * p.ldc + n;
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(dst + j, v[j]);
-        }
-      }
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
     }
+    __builtin_amdgcn_s_barrier();                          // (also the "ring is free" barrier in front of the epilogue after the last K-tile)
+  }
+#undef PC_FRAGS
+  tile128_out<EPI>(p, acc, smem_pc, wave, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1248,6 +1405,26 @@ int launch_v2(int epi, const GemmP& p, hipStream_t st) {
   }
 }
 
+template <typename K>
+int pc_attr(K kernel) {                              // the dynamic-LDS attribute of a kernel is raised exactly once
+  static const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+  return e == hipSuccess ? 0 : 1;
+}
+#define PC_LAUNCH(E)                                                                                   \
+  case E:                                                                                              \
+    if (pc_attr(gemm_nt_pc_kernel<E>)) { spmm_set_error("spmm_gemm_nt: cannot raise the LDS limit of the loader/compute kernel"); return SPMM_ERR_LAUNCH; } \
+    hipLaunchKernelGGL((gemm_nt_pc_kernel<E>), grid, dim3(PC_THREADS), PC_LDS, st, p);                        \
+    break
+int launch_pc(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    PC_LAUNCH(EPI_BF16); PC_LAUNCH(EPI_GELU); PC_LAUNCH(EPI_F32); PC_LAUNCH(EPI_F32_ATOMIC); PC_LAUNCH(EPI_GELU_GRAD); PC_LAUNCH(EPI_F32_ACC);
+    PC_LAUNCH(EPI_GELU_DERIV); PC_LAUNCH(EPI_MUL);
+    default: return -1;
+  }
+  return 0;
+}
+#undef PC_LAUNCH
+
 int launch_v1(int epi, const GemmP& p, dim3 grid, hipStream_t st) {
   switch (epi) {
     case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<EPI_BF16>), grid, dim3(256), 0, st, p); break;
@@ -1332,7 +1509,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.order = K > 1024 ? 0 : 2;
 
   // kernel: 0 = choose (below); 1 = 128x128 (all epilogues, split-K); 2 = 256x128 three-stage ring (no atomics);
-  // 3 = 256x256 one-barrier-per-k-step (bf16 outputs); 8 = 256x256 8-phase (bf16 outputs, K % 128 == 0)
+  // 3 = 256x256 one-barrier-per-k-step (bf16 outputs); 5 = 128x128 with loader + compute waves; 8 = 256x256 8-phase (bf16 outputs, K % 128 == 0)
   int k = kernel == SPMM_GEMM_AUTO_TILES ? 0 : kernel;
   if (k == 0) {
     const int tile = splits > 1 ? 1 : pick_tile(M, N, epi);
@@ -1343,15 +1520,21 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
     SPMM_CHECK_SHAPE(kernel == 0 || kernel == SPMM_GEMM_AUTO_TILES || kernel == 8 || kernel == 9, "spmm_gemm_nt: the 8-bit gelu' epilogues run on the 8-phase kernel only");
     k = (k == 9 || kernel == SPMM_GEMM_AUTO_TILES) ? 9 : 8;
   }
-  SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 8 || k == 9, "spmm_gemm_nt: unknown kernel selector %d", kernel);
+  // 5 = the 128x128 tile with loader + compute waves (any epilogue of kernel 1, split-K too; operands < 4 GiB: 32-bit DMA offsets)
+  const bool pc_fits = (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 32) && (unsigned long)p.N * (unsigned long)p.ldw * 2ul < (1ul << 32);
+  const long t128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splits;
+  if (k == 1 && kernel != 1 && pc_fits && PC_AUTO && t128 <= 256 && ksplit >= 4 * BK) k = 5;
+  SPMM_CHECK_SHAPE(k == 1 || k == 2 || k == 3 || k == 5 || k == 8 || k == 9, "spmm_gemm_nt: unknown kernel selector %d", kernel);
+  SPMM_CHECK_SHAPE(k != 5 || pc_fits, "spmm_gemm_nt: kernel 5 addresses its operands with 32-bit byte offsets (< 4 GiB each)");
   SPMM_CHECK_SHAPE((k != 8 && k != 9) || p8_ok(p, epi), "spmm_gemm_nt: the 8-phase kernel needs a bf16-output epilogue, K %% 128 == 0, N %% 8 == 0 and operands < 4 GiB");
   SPMM_CHECK_SHAPE(k != 3 || is_bf16_epi(epi), "spmm_gemm_nt: the 256x256 kernel has bf16-output epilogues only");
   SPMM_CHECK_SHAPE(k != 2 || epi != EPI_F32_ATOMIC, "spmm_gemm_nt: the 256x128 kernel has no atomic epilogue");
-  SPMM_CHECK_SHAPE(k == 1 || splits == 1, "spmm_gemm_nt: split-K runs on the 128x128 kernel only");
+  SPMM_CHECK_SHAPE(k == 1 || k == 5 || splits == 1, "spmm_gemm_nt: split-K runs on the 128x128 kernels only");
   int rc;
   if (k == 8 || k == 9) rc = launch_p8(epi, p, stream, k == 8);     // 9: one workgroup per tile (A/B of the persistent walk)
   else if (k == 3) rc = launch_v3(epi, p, stream);
   else if (k == 2) rc = launch_v2(epi, p, stream);
+  else if (k == 5) rc = launch_pc(epi, p, dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splits), stream);
   else rc = launch_v1(epi, p, dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splits), stream);
   if (rc > 0) return rc;
   if (rc < 0) { spmm_set_error("spmm_gemm_nt: epilogue %d is not built for kernel %d", epi, k); return SPMM_ERR_UNSUPPORTED; }

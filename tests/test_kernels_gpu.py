@@ -76,11 +76,11 @@ def test_gemm_bf16_bias(ops, M, N, K):
     assert (Cbuf[:, N:] == 7.0).all()
 
 
-# kernel selector of spmm_gemm_nt (include/spmm_hip.h): 1 = 128x128, 2 = 256x128 ring, 3 = 256x256, 8 = 256x256 8-phase (persistent),
-# 9 = the same kernel with one workgroup per tile
+# kernel selector of spmm_gemm_nt (include/spmm_hip.h): 1 = 128x128, 2 = 256x128 ring, 3 = 256x256, 5 = 128x128 with loader + compute waves,
+# 8 = 256x256 8-phase (persistent), 9 = the same kernel with one workgroup per tile
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (6912, 768, 768), (1000, 2304, 128), (216, 300, 128), (513, 520, 3072), (70000, 768, 128),
                                    (66000, 1024, 256)])
-@pytest.mark.parametrize("kernel", [1, 2, 3, 8, 9])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 5, 8, 9])
 def test_gemm_tile_kernels(ops, M, N, K, kernel):
     """Every tile kernel forced on small / ragged / large shapes (the heuristic alone would never run the big tiles there):
     bias + residual epilogue, GELU with pre-activation output, and untouched padding columns."""
@@ -182,7 +182,7 @@ def test_gemm_kernel_selector_rejects_unsupported(ops):
     with pytest.raises(RuntimeError, match="bf16-output"):
         ops.gemm_nt(A, W, torch.empty(256, 256, device="cuda"), epi=ops.EPI_F32, kernel=3)
     with pytest.raises(RuntimeError, match="selector"):
-        ops.gemm_nt(A, W, C, kernel=5)
+        ops.gemm_nt(A, W, C, kernel=4)
 
 
 def test_gemm_strided_operands_and_residual(ops):
@@ -224,15 +224,16 @@ def test_gemm_f32_epilogues_and_splitk(ops):
     ref = A.float() @ W.float().t()
     div = torch.tensor([0.07], device="cuda")
     C = torch.empty(M, N, device="cuda")
-    ops.gemm_nt(A, W, C, epi=ops.EPI_F32, div=div)
-    close(C, ref / 0.07, 1e-2, 1e-4, "f32 + div")
-    C.fill_(1.0)
-    ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ACC)
-    close(C, ref + 1.0, 2e-3, 1e-4, "f32 acc")
-    for splits in (1, 4, 7, 32):
-        C.fill_(2.0)
-        ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ATOMIC, splits=splits)
-        close(C, ref + 2.0, 2e-3, 1e-4, f"atomic split {splits}")
+    for kernel in (0, 1, 5):                    # the automatic choice, the 128x128 kernel, the 128x128 kernel with loader waves
+        ops.gemm_nt(A, W, C, epi=ops.EPI_F32, div=div, kernel=kernel)
+        close(C, ref / 0.07, 1e-2, 1e-4, f"f32 + div, kernel {kernel}")
+        C.fill_(1.0)
+        ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ACC, kernel=kernel)
+        close(C, ref + 1.0, 2e-3, 1e-4, f"f32 acc, kernel {kernel}")
+        for splits in (1, 4, 7, 32):
+            C.fill_(2.0)
+            ops.gemm_nt(A, W, C, epi=ops.EPI_F32_ATOMIC, splits=splits, kernel=kernel)
+            close(C, ref + 2.0, 2e-3, 1e-4, f"atomic split {splits}, kernel {kernel}")
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (216, 128, 256, 1), (216, 128, 256, 3), (6912, 768, 768, None),

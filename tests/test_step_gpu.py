@@ -293,9 +293,9 @@ def test_fused_cross_attention_inside_the_step(env):
 def test_chained_weight_gradient_reductions_inside_the_step(env):
     """EngineOptions.wgrad_chain: the slab reductions of the weight-gradient GEMMs ride inside the next GEMM's launch of their stream.
     Same slabs, same summation order: the weight matrices' gradients are bit-identical to the plain schedule's (the kernel-level test
-    pins that); here the whole gradient arena after a training step agrees to 1e-6 of its norm (bias / LayerNorm / embedding gradients
-    are summed with atomics and differ from run to run in the last bit), in the multi-stream schedule (one chain on the
-    weight-gradient stream) and in the single-stream one (chains on the backward's streams)."""
+    pins that); here the fusion layer's weight gradients after a training step agree to 1e-6 of their norm and the whole arena to 5e-3
+    (see below), in the multi-stream schedule (one chain on the weight-gradient stream) and in the single-stream one (chains on the
+    backward's streams)."""
     O, SPMM, *_ = env
     from spmm_amd.options import EngineOptions
     cfg, ocfg = _mid_cfg(env)
@@ -321,8 +321,16 @@ def test_chained_weight_gradient_reductions_inside_the_step(env):
         np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
         g0, g1 = res[False][1], res[True][1]
         rel = ((g1 - g0).norm() / g0.norm()).item()
-        print(f"multi_stream={multi}: relative L2 difference of the whole gradient {rel:.3g}, bit-identical elements {(g1 == g0).float().mean().item():.6f}")
-        assert rel < 1e-6 and float(g0.norm()) > 0
+        # the fusion layer's weight gradients see no atomically accumulated input: they pin the chained reductions at 1e-6.  Below the fusion
+        # layers the gradient entering the unimodal encoders is summed with fp32 atomics (hard negatives' rows, step.py) and rounded to
+        # bf16: when the order of two adds flips a rounding, every gradient upstream moves by a bf16 ulp -- two runs of the SAME schedule
+        # then differ by ~1e-3 as well (seen once the suite's timing changed in round 4), so the whole arena is held to 5e-3 only
+        fus = [n for n in m.store.order if f"text_encoder.bert.encoder.layer.{cfg.text.fusion_layer}." in n and n.endswith("dense.weight")]
+        assert len(fus) >= 4
+        rel_f = max(((m.store._view(g1, n) - m.store._view(g0, n)).norm() / m.store._view(g0, n).norm()).item() for n in fus)
+        print(f"multi_stream={multi}: relative L2 difference of the whole gradient {rel:.3g} (fusion-layer weights {rel_f:.3g}), "
+              f"bit-identical elements {(g1 == g0).float().mean().item():.6f}")
+        assert rel_f < 1e-6 and rel < 5e-3 and float(g0.norm()) > 0
 
 
 def test_gelu_derivative_as_8bit_codes_inside_the_step(env):
