@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
 // form takes 168 registers, three waves, and loses what the batching wins).  5 000 rows x 12 heads, last six positions on own rows:
 // 60.5 -> 48.1 us at 25 keys, 83.7 -> 64.5 at 50, 130 -> 105 at 100 (tools/bench_decode_attn.py).
 template <int G, bool ALLSAME>   // ALLSAME: no ancestry table, every beam of the molecule reads the same key/value rows (cross-attention)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_attn_group_kernel(DecAttnP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 : 3, 4))) void decode_attn_group_kernel(DecAttnP p) {
   __shared__ float ssc[4][G][256];                   // scores of the wave's G (row, head) pairs
   __shared__ int sanc[4][G][256];                    // cache row of position j for each beam (16 waves per CU at G = 5; sized by Lkv with
   //                                                    run-time strides -- 32 waves per CU -- it measured SLOWER: 99 vs 84 us per launch,
