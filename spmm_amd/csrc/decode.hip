@@ -284,6 +284,203 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 
   }
 }
 
+// The same kernel with beam 0's row of every iteration -- the row most beams of most iterations read -- arriving through a per-wave LDS ring
+// filled by LDS-DMA DA_DEPTH iterations ahead (global_load_lds: a gather of 16 B per lane that needs no registers, so the bytes a wave keeps
+// in flight are bounded by LDS, not by the register budget that holds the plain kernel at one or two loads per wave).  Score / index arrays
+// for at most 128 keys (the decoder's 103-position caches) so that the ring fits beside them at four workgroups per CU; caches below
+// 4 GiB (32-bit DMA offsets).  Rows of differing beams still come by ordinary loads (rare: the last few positions).
+constexpr int DA_DEPTH = 4;
+template <int G, bool ALLSAME>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 : 3, 4))) void decode_attn_dma_kernel(DecAttnP p) {
+  __shared__ float ssc[4][G][128];                   // scores of the wave's G (row, head) pairs
+  __shared__ int sanc[4][G][128];                    // cache row of position j for each beam
+  __shared__ __attribute__((aligned(16))) char sring[4][DA_DEPTH][1024];   // beam 0's rows of DA_DEPTH iterations: lane l's 16 bytes at l * 16
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per_xcd = (p.nblocks + 7) >> 3;
+  const long lb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const long gw = lb * 4 + wave;
+  const int nmol = p.R / G;
+  if (lb >= p.nblocks || gw >= (long)nmol * p.nH) return;
+  const int n = (int)(gw / p.nH), h = (int)(gw - (long)n * p.nH);
+  const int g = lane >> 3, c = lane & 7;
+  const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
+  const int niter = (Lkv + 7) >> 3;
+  float qf[G][8];
+  {
+    // every load of the prologue is issued before the first one is consumed (query rows, then the ancestry entries lane, lane + 64, ...
+    // of every beam: a loop that loads and stores one entry at a time waits out a memory latency per entry -- 5 to 10 of them in a row)
+    bf16x8 qv[G];
+    int av[ALLSAME ? 1 : G][2];
+#pragma unroll
+    for (int b = 0; b < G; ++b) qv[b] = *(const bf16x8*)(p.q + (long)(n * G + b) * p.ldq + h * 64 + c * 8);
+#pragma unroll
+    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = lane + 64 * u, r = n * G + b;
+        av[b][u] = p.anc ? ((j < Lkv) ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
+      }
+#pragma unroll
+    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < niter * 8) sanc[wave][b][lane + 64 * u] = av[b][u];
+#pragma unroll
+    for (int b = 0; b < G; ++b)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[b][e] = (float)qv[b][e] * p.scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const long hoff = h * p.head_stride + c * 8;
+  const uint32_t ring0 = (uint32_t)(uintptr_t)(LDS_AS char*)&sring[wave][0][0];
+  // LDS-DMA of beam 0's row of iteration I (keys past the end re-fetch the last valid one; they are masked where they are used)
+#define DA_DMA(I, SRC)                                                                                           \
+  do {                                                                                                           \
+    int j_ = (I) * 8 + g;                                                                                        \
+    j_ = j_ < Lkv ? j_ : Lkv - 1;                                                                                \
+    const uint32_t off_ = (uint32_t)(((long)sanc[wave][0][j_] * p.seq_stride + (long)j_ * p.tok_stride + hoff) * 2); \
+    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)(((I) % DA_DEPTH) * 1024));           \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_), "s"(SRC), "s"(dst_) : "memory", "m0"); \
+  } while (0)
+  // iteration I's row has landed: at most min(DA_DEPTH - 1, niter - 1 - I) newer DMAs may still be in flight (vmcnt retires in order)
+#define DA_LANDED(I)                                                                                             \
+  do {                                                                                                           \
+    const int newer_ = niter - 1 - (I);                                                                          \
+    if (newer_ >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                            \
+    else if (newer_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                       \
+    else if (newer_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                       \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+  } while (0)
+  static_assert(DA_DEPTH == 4, "DA_LANDED counts up to three newer loads");
+  for (int i = 0; i < DA_DEPTH && i < niter; ++i) DA_DMA(i, p.K);
+  float mx[G];
+#pragma unroll
+  for (int b = 0; b < G; ++b) mx[b] = -INFINITY;
+  // one key's partial dot products for beam B from row KB (8 lanes x 8 elements, reduced over the key's 8 lanes)
+#define DA_SCORE(B, KB)                                                                                          \
+  do {                                                                                                           \
+    float part = 0.f;                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) part += (float)(KB)[e] * qf[B][e];                            \
+    part += dpp_f<0xB1>(part); part += dpp_f<0x4E>(part); part += dpp_f<0x141>(part);                            \
+    if (valid) {                                                                                                 \
+      if (c == 0) ssc[wave][B][j] = part;                                                                        \
+      mx[B] = fmaxf(mx[B], part);                                                                                \
+    }                                                                                                            \
+  } while (0)
+  for (int i = 0; i < niter; ++i) {
+    const int j = i * 8 + g;
+    const bool valid = j < Lkv;
+    const long joff = (long)j * p.tok_stride + hoff;
+    int ab[G];
+#pragma unroll
+    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
+    const int a0 = ab[0];
+    bool diff = false;
+    if (!ALLSAME) {
+#pragma unroll
+      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
+    }
+    DA_LANDED(i);
+    const bf16x8 k0 = *(const bf16x8*)&sring[wave][i % DA_DEPTH][lane * 16];
+    if (!ALLSAME && __any(valid && diff)) {
+      // some beam of some key of this iteration sits on another cache row (the last few positions of a hypothesis): every beam's row is
+      // loaded, back to back with no control flow in between (a load per differing beam behind its own branch waits out one memory
+      // latency per beam; the rows that do not differ hit the line beam 0 just fetched)
+      bf16x8 kb[G];
+#pragma unroll
+      for (int b = 1; b < G; ++b) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kb[b][e] = (bf16)0.f;
+      }
+      if (valid) {
+#pragma unroll
+        for (int b = 1; b < G; ++b) kb[b] = *(const bf16x8*)(p.K + (long)ab[b] * p.seq_stride + joff);
+      }
+      DA_SCORE(0, k0);
+#pragma unroll
+      for (int b = 1; b < G; ++b) DA_SCORE(b, kb[b]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < G; ++b) DA_SCORE(b, k0);
+    }
+    if (i + DA_DEPTH < niter) DA_DMA(i + DA_DEPTH, p.K);      // (the slot's row is in registers: k0 was consumed above)
+  }
+#undef DA_SCORE
+  for (int i = 0; i < DA_DEPTH && i < niter; ++i) DA_DMA(i, p.V);   // the ring is free: every key row has been consumed
+#pragma unroll
+  for (int b = 0; b < G; ++b) mx[b] = wave_max(mx[b]);
+  __builtin_amdgcn_wave_barrier();
+  float acc[G][8], sum[G];
+#pragma unroll
+  for (int b = 0; b < G; ++b) {
+    sum[b] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[b][d] = 0.f;
+  }
+#define DA_ACC(B, VB)                                                                                            \
+  do {                                                                                                           \
+    const float e_ = valid ? __expf(ssc[wave][B][j] - mx[B]) : 0.f;                                              \
+    sum[B] += e_;                                                                                                \
+    const float pe_ = (float)(bf16)e_;             /* the tiled training kernel feeds bf16 probabilities to the PV MFMA */ \
+    _Pragma("unroll") for (int d = 0; d < 8; ++d) acc[B][d] += pe_ * (float)(VB)[d];                            \
+  } while (0)
+#pragma unroll 1
+  for (int i = 0; i < niter; ++i) {
+    const int j = i * 8 + g;
+    const bool valid = j < Lkv;
+    const long joff = (long)j * p.tok_stride + hoff;
+    int ab[G];
+#pragma unroll
+    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
+    const int a0 = ab[0];
+    bool diff = false;
+    if (!ALLSAME) {
+#pragma unroll
+      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
+    }
+    DA_LANDED(i);
+    const bf16x8 v0 = *(const bf16x8*)&sring[wave][i % DA_DEPTH][lane * 16];
+    if (!ALLSAME && __any(valid && diff)) {
+      bf16x8 vb[G];
+#pragma unroll
+      for (int b = 1; b < G; ++b) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) vb[b][d] = (bf16)0.f;
+      }
+      if (valid) {
+#pragma unroll
+        for (int b = 1; b < G; ++b) vb[b] = *(const bf16x8*)(p.V + (long)ab[b] * p.seq_stride + joff);
+      }
+      DA_ACC(0, v0);
+#pragma unroll
+      for (int b = 1; b < G; ++b) DA_ACC(b, vb[b]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < G; ++b) DA_ACC(b, v0);
+    }
+    if (i + DA_DEPTH < niter) DA_DMA(i + DA_DEPTH, p.V);
+  }
+#undef DA_ACC
+#undef DA_DMA
+#undef DA_LANDED
+#pragma unroll
+  for (int b = 0; b < G; ++b) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {               // combine the 8 key slots (lanes with equal c)
+      sum[b] += __shfl_xor(sum[b], o, 64);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[b][d] += __shfl_xor(acc[b][d], o, 64);
+    }
+    if (g == 0) {
+      const float inv = 1.f / sum[b];
+      bf16x8 o;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) o[d] = (bf16)(acc[b][d] * inv);
+      *(bf16x8*)(p.out + (long)(n * G + b) * p.ldo + h * 64 + c * 8) = o;
+    }
+  }
+}
+
 // the newest position's key / value rows into the cache, in front of the attention launch (one launch for both; folding it into the
 // attention kernel itself -- the rows read from the projection output, written by the wave that owns the (row, head) -- was built and
 // measured: 40 more live registers or an exposed load between the two passes, 1.61 -> 1.78-1.92 ms of decode_attn per position)
@@ -303,6 +500,13 @@ template <int G>
 void launch_group(DecAttnP p, hipStream_t stream) {
   const long waves = (long)(p.R / G) * p.nH;
   p.nblocks = (int)((waves + 3) / 4);
+  static const bool no_dma = getenv("SPMM_DECODE_NO_DMA") != nullptr;          // (debugging aid, like SPMM_DECODE_PER_BEAM)
+  const long nsrc = p.anc ? p.R : (p.R + p.kv_div - 1) / (p.kv_div > 0 ? p.kv_div : 1);
+  if (!no_dma && p.Lkv <= 128 && (unsigned long)nsrc * (unsigned long)p.seq_stride * 2ul < (1ul << 32)) {
+    if (p.anc) hipLaunchKernelGGL((decode_attn_dma_kernel<G, false>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((decode_attn_dma_kernel<G, true>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
+    return;
+  }
   if (p.anc) hipLaunchKernelGGL((decode_attn_group_kernel<G, false>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((decode_attn_group_kernel<G, true>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
 }

@@ -77,4 +77,5 @@ class EngineOptions:
 # Debugging aids outside EngineOptions (they change no result): SPMM_DEBUG_SYNC=1 names every launch and drains the GPU after it
 # (ops.py); SPMM_BENCH_WATCHDOG=<s> makes bench.py dump all Python stacks and exit non-zero after <s> seconds;
 # SPMM_DIST_BACKEND=gloo lets the test harness put two ranks on one GPU (bench.py / pretrain.py); SPMM_DECODE_PER_BEAM=1 makes
-# spmm_decode_attn take its one-wave-per-beam-row kernel instead of the one-wave-per-molecule one (csrc/decode.hip, same results).
+# spmm_decode_attn take its one-wave-per-beam-row kernel instead of the one-wave-per-molecule one, SPMM_DECODE_NO_DMA=1 the one-wave-per-molecule kernel without its LDS-DMA ring
+# (csrc/decode.hip, same results).
