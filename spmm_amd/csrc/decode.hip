@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 
 // The same kernel with beam 0's row of every iteration -- the row most beams of most iterations read -- arriving through a per-wave LDS ring
 // filled by LDS-DMA DA_DEPTH iterations ahead (global_load_lds: a gather of 16 B per lane that needs no registers, so the bytes a wave keeps
 // in flight are bounded by LDS, not by the register budget that holds the plain kernel at one or two loads per wave).  Score / index arrays
-// for at most 128 keys (the decoder's 103-position caches) so that the ring fits beside them at four workgroups per CU; caches below
-// 4 GiB (32-bit DMA offsets).  Rows of differing beams still come by ordinary loads (rare: the last few positions).
+// for at most 128 keys (the decoder's 103-position caches) so that the ring fits beside them at four workgroups per CU (64-bit per-lane
+// DMA addresses: after a compaction the ancestry table names cache rows beyond the launch's own row count).  Rows of differing beams still come by ordinary loads (rare: the last few positions).
 constexpr int DA_DEPTH = 4;
 template <int G, bool ALLSAME>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 : 3, 4))) void decode_attn_dma_kernel(DecAttnP p) {
@@ -338,9 +338,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 
   do {                                                                                                           \
     int j_ = (I) * 8 + g;                                                                                        \
     j_ = j_ < Lkv ? j_ : Lkv - 1;                                                                                \
-    const uint32_t off_ = (uint32_t)(((long)sanc[wave][0][j_] * p.seq_stride + (long)j_ * p.tok_stride + hoff) * 2); \
+    const bf16* src_ = (SRC) + ((long)sanc[wave][0][j_] * p.seq_stride + (long)j_ * p.tok_stride + hoff);        \
     const uint32_t dst_ = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)(((I) % DA_DEPTH) * 1024));           \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_), "s"(SRC), "s"(dst_) : "memory", "m0"); \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_), "s"(dst_) : "memory", "m0"); \
   } while (0)
   // iteration I's row has landed: at most min(DA_DEPTH - 1, niter - 1 - I) newer DMAs may still be in flight (vmcnt retires in order)
 #define DA_LANDED(I)                                                                                             \
@@ -501,8 +501,7 @@ void launch_group(DecAttnP p, hipStream_t stream) {
   const long waves = (long)(p.R / G) * p.nH;
   p.nblocks = (int)((waves + 3) / 4);
   static const bool no_dma = getenv("SPMM_DECODE_NO_DMA") != nullptr;          // (debugging aid, like SPMM_DECODE_PER_BEAM)
-  const long nsrc = p.anc ? p.R : (p.R + p.kv_div - 1) / (p.kv_div > 0 ? p.kv_div : 1);
-  if (!no_dma && p.Lkv <= 128 && (unsigned long)nsrc * (unsigned long)p.seq_stride * 2ul < (1ul << 32)) {
+  if (!no_dma && p.Lkv <= 128) {
     if (p.anc) hipLaunchKernelGGL((decode_attn_dma_kernel<G, false>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((decode_attn_dma_kernel<G, true>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
     return;
