@@ -315,6 +315,7 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     of launch overhead to one graph launch, which is what small batches are bound by.  graph=None (default): replay when the batch
     is launch-bound -- fewer than GRAPH_BELOW_ROWS beam rows -- and the search is deterministic.  compact=True (eager fused path): finished
     molecules are dropped from the batch as the search goes (same results; the reference decodes one molecule at a time and simply stops)."""
+    last_run.clear()
     if cached is None:
         cached = hasattr(model, "engine")
     if graph is None:
