@@ -83,13 +83,7 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
 int spmm_gemm_tn_splits(int M, int N, int K, int kernel);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
                  long ldc, float* workspace, int kernel, spmm_stream_t stream);
-/* The same product with its slab reduction left PENDING: *ns_out slabs of N*K floats stay in `workspace` (0: C is complete) and the
- * NEXT chained call on the same stream folds them into its own launch (prev_*: workspace, slab count, N, K, C, ldc of that earlier
- * call; prev_ws null = nothing pending); spmm_gemm_tn_reduce finishes the last one.  The ~100 reduction launches of a backward pass
- * between the weight-gradient GEMMs become one.  The caller keeps `workspace` alive until it has been folded or reduced. */
-int spmm_gemm_tn_chain(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
-                       long ldc, float* workspace, const float* prev_ws, int prev_ns, int prev_N, int prev_K, float* prev_C,
-                       long prev_ldc, int* ns_out, int kernel, spmm_stream_t stream);
+/* C[n*ldc + k] += sum over ns slabs of N*K floats in `ws`: the split reduction spmm_gemm_tn runs itself, as an entry of its own. */
 int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream);
 int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
 

@@ -491,43 +491,6 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
 template <bool SLAB>
 __global__ __launch_bounds__(512) void gemm_tn_p8_kernel(TnP p) { tn_p8_body<SLAB>(p, blockIdx.x, blockIdx.z); }
 
-// A slab reduction left PENDING by an earlier launch on the same stream (spmm_gemm_tn_chain): C[n*ldc + k] += sum_z slab[z][n][k].
-// The chained launch folds it in behind its own tiles: every workgroup sums 1/gridDim.x of it after its stores, so the separate
-// reduction launches between the weight-gradient GEMMs (99 per step, each waiting for CUs behind the persistent GEMMs of the other
-// streams) disappear; the workgroups that finish early do this in the tail of the launch.
-struct TnFold { const float* slab; int ns, N, K4; float* C; long ldc; };
-__device__ __forceinline__ void tn_fold(const TnFold& f, const int bidx, const int nwg, const int tid) {
-  const long total = (long)f.N * f.K4;
-  for (long e = (long)bidx * 512 + tid; e < total; e += (long)nwg * 512) {
-    const int n = (int)(e / f.K4), k = (int)(e - (long)n * f.K4) * 4;
-    // (eight slabs' loads in flight at a time -- one workgroup per CU has no occupancy to hide a dependent chain of loads behind --
-    // summed in slab order, as slab_reduce_kernel does: the result is bit-identical to the separate launch's)
-    const float* sp = f.slab + e * 4;
-    f32x4* d = (f32x4*)(f.C + (long)n * f.ldc + k);
-    f32x4 o = *d;
-    f32x4 s = *(const f32x4*)sp;
-    int z = 1;
-    for (; z + 8 <= f.ns; z += 8) {
-      f32x4 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(sp + (long)(z + j) * total * 4);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s[0] += v[j][0]; s[1] += v[j][1]; s[2] += v[j][2]; s[3] += v[j][3]; }
-    }
-    for (; z < f.ns; ++z) {
-      const f32x4 v = *(const f32x4*)(sp + (long)z * total * 4);
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-    }
-    o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
-    *d = o;
-  }
-}
-template <bool SLAB>
-__global__ __launch_bounds__(512) void gemm_tn_p8_fold_kernel(TnP p, TnFold f) {
-  tn_p8_body<SLAB>(p, blockIdx.x, blockIdx.z);
-  tn_fold(f, blockIdx.x, gridDim.x, threadIdx.x);
-}
-
 // C[n*ldc + k] += sum_z slab[z][n][k]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int N, int K4, float* __restrict__ C,
                                                           long ldc) {
@@ -640,10 +603,8 @@ static void tn_reduce_launch(const float* ws, int ns, int N, int K, float* C, lo
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, ns, N, K / 4, C, ldc);
 }
 
-// prev: a pending slab reduction to fold into this launch (or to run first when this launch cannot carry it); ns_out: null = reduce
-// this call's slabs right away (spmm_gemm_tn), else leave them pending and report their count (0 = C is complete)
 static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C, long ldc,
-                  float* workspace, int kernel, hipStream_t stream, const TnFold* prev, int* ns_out) {
+                  float* workspace, int kernel, hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(N % 4 == 0 && K % 4 == 0 && ldc % 4 == 0, "spmm_gemm_tn: N=%d K=%d ldc=%ld must be multiples of 4", N, K, ldc);
 #ifndef P8_PROFILE   // (the profiling build of tools/ aliases all rows onto row 0 with lda = ldb = 0: cache-resident operands)
@@ -662,12 +623,6 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
   p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
   p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha; p.nsplit = 0;
   auto reduce = [&](int nsplit) { tn_reduce_launch(workspace, nsplit, N, K, C, ldc, stream); };
-  if (ns_out) *ns_out = 0;
-  bool fold = prev != nullptr && prev->slab != nullptr;
-  auto flush_prev = [&]() {
-    if (fold) tn_reduce_launch(prev->slab, prev->ns, prev->N, prev->K4 * 4, prev->C, prev->ldc, stream);
-    fold = false;
-  };
   if (k8) {
     static const hipError_t attr_rc = [] {
       hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS);
@@ -688,20 +643,11 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
     if (ns == 1) { p.rlast = ((M + 127) / 128) * 128 > M ? (M / 128) * 128 : M; p.ndup = 0; }   // a single slice cannot overlap anything
     const int single_left = ns == 1 ? M - p.rlast : 0;
     dim3 grid(((N + 255) / 256) * ((K + 255) / 256) * ns, 1, 1);
-    if (fold && ns == 1) {
-      // a direct-mode launch adds into C from its tiles' workgroups: it cannot also fold a pending reduction into the same matrix
-      const char *c0 = (const char*)C, *c1 = (const char*)(C + (long)(N - 1) * ldc + K);
-      const char *q0 = (const char*)prev->C, *q1 = (const char*)(prev->C + (long)(prev->N - 1) * prev->ldc + prev->K4 * 4);
-      if (c0 < q1 && q0 < c1) flush_prev();
-    }
     if (ns > 1) {
-      if (fold) hipLaunchKernelGGL(gemm_tn_p8_fold_kernel<true>, grid, dim3(512), TP_LDS, stream, p, *prev);
-      else hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
-      if (ns_out) *ns_out = ns;
-      else reduce(ns);
+      hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
+      reduce(ns);
     } else {
-      if (fold) hipLaunchKernelGGL(gemm_tn_p8_fold_kernel<false>, grid, dim3(512), TP_LDS, stream, p, *prev);
-      else hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, grid, dim3(512), TP_LDS, stream, p);
+      hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, grid, dim3(512), TP_LDS, stream, p);
     }
     if (single_left > 0) {                              // one slice = rows [M % 128, M); the first M % 128 rows: one pass of the 128x128 kernel, accumulated into C
       TnP q = p;
@@ -712,7 +658,6 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
     SPMM_LAUNCH_CHECK("spmm_gemm_tn(8-phase)");
     return SPMM_OK;
   }
-  flush_prev();                                         // (the 128x128 kernel carries no fold)
   int rsplit = (((M + BR - 1) / BR + splits - 1) / splits) * BR;
   splits = (M + rsplit - 1) / rsplit;
   p.rsplit = rsplit;
@@ -730,17 +675,7 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
 
 extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha,
                             float* C, long ldc, float* workspace, int kernel, spmm_stream_t stream) {
-  return tn_run(A, lda, B, ldb, M, N, K, splits, alpha, C, ldc, workspace, kernel, stream, nullptr, nullptr);
-}
-
-extern "C" int spmm_gemm_tn_chain(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha,
-                                  float* C, long ldc, float* workspace, const float* prev_ws, int prev_ns, int prev_N, int prev_K,
-                                  float* prev_C, long prev_ldc, int* ns_out, int kernel, spmm_stream_t stream) {
-  SPMM_CHECK_SHAPE(ns_out != nullptr, "spmm_gemm_tn_chain: ns_out is where the pending slab count is reported");
-  SPMM_CHECK_SHAPE(prev_ws == nullptr || (prev_ns >= 1 && prev_N > 0 && prev_K > 0 && prev_K % 4 == 0 && prev_C != nullptr && prev_ldc % 4 == 0),
-                   "spmm_gemm_tn_chain: pending reduction ns=%d N=%d K=%d ldc=%ld", prev_ns, prev_N, prev_K, prev_ldc);
-  const TnFold f = {prev_ws, prev_ns, prev_N, prev_K / 4, prev_C, prev_ldc};
-  return tn_run(A, lda, B, ldb, M, N, K, splits, alpha, C, ldc, workspace, kernel, stream, &f, ns_out);
+  return tn_run(A, lda, B, ldb, M, N, K, splits, alpha, C, ldc, workspace, kernel, stream);
 }
 
 extern "C" int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream) {

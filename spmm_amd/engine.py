@@ -140,7 +140,6 @@ class Engine:
             streams.bind_in_order(device, ("side0", "side1", "wgrad"))
         self.force_one_stream = False     # set by the data-parallel schedule check (model.py::_schedule_check)
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
-        self._tn_pend = {}                                  # chained weight-gradient GEMMs: stream handle -> slab reduction still pending there
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
         self.tape = None
@@ -151,7 +150,6 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ helpers
     def _fork(self, which: int = 0):
         """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
-        self._tn_flush()
         if not self.multi_stream or self._one_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
         side = streams.get(self.dev, f"side{which}")        # process-wide: every model of a process shares the same streams
@@ -162,8 +160,6 @@ class Engine:
 
     def _join(self, side):
         if side is not None:
-            with torch.cuda.stream(side):
-                self._tn_flush()
             ev = torch.cuda.Event()
             ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
@@ -202,7 +198,7 @@ class Engine:
         if ws is None:
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            self._tn(dY, X, C)
+            ops.gemm_tn(dY, X, C)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -210,26 +206,11 @@ class Engine:
         with torch.cuda.stream(ws):
             if gb is not None:
                 ops.colsum_bf16(dY, gb)
-            self._tn(dY, X, C)
+            ops.gemm_tn(dY, X, C)
         # The operands must outlive the side stream's use of them.  They are simply kept referenced until the next join
         # (`record_stream` on ~100 tensors per step makes the caching allocator poll events on every allocation).
         self._wg_keep.append((dY, X))
         self._wg_pending = True
-
-    def _tn(self, dY, X, C):
-        """One weight-gradient product on the current stream.  EngineOptions.wgrad_chain: its slab reduction is left pending and rides
-        inside the next product's launch on this stream (ops.gemm_tn_chain); _tn_flush finishes the last one of a stream."""
-        if not self.opt.wgrad_chain or ops._DRY_RUN or self.dev.type != "cuda":
-            return ops.gemm_tn(dY, X, C)
-        key = torch.cuda.current_stream().cuda_stream
-        pend = ops.gemm_tn_chain(dY, X, C, self._tn_pend.pop(key, None))
-        if pend is not None:
-            self._tn_pend[key] = pend
-
-    def _tn_flush(self):
-        """Finish the pending slab reduction of the CURRENT stream (before anything may read the gradients written through it)."""
-        if self._tn_pend:
-            ops.gemm_tn_flush(self._tn_pend.pop(torch.cuda.current_stream().cuda_stream, None))
 
     def _wgrad_side(self):
         if not self.wgrad_async or self._one_stream or self.dev.type != "cuda" or ops._DRY_RUN:
@@ -239,10 +220,7 @@ class Engine:
 
     def wgrad_join(self, release: bool = False):
         """The current stream waits for every weight-gradient launch issued so far."""
-        self._tn_flush()
         if self._wg_stream is not None and self._wg_pending:
-            with torch.cuda.stream(self._wg_stream):
-                self._tn_flush()
             ev = torch.cuda.Event()
             ev.record(self._wg_stream)
             torch.cuda.current_stream().wait_event(ev)

@@ -115,31 +115,6 @@ def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0):
     return C
 
 
-def gemm_tn_chain(A, B, C, pending=None, *, alpha=1.0, kernel=0):
-    """gemm_tn whose slab reduction is left pending: -> None (C is complete) or the tuple to hand to the NEXT gemm_tn_chain call on the
-    same stream (which folds that reduction into its own launch) or to gemm_tn_flush.  `pending` is such a tuple from the previous call."""
-    M, N = A.shape
-    K = B.shape[1]
-    assert A.dtype == BF16 and B.dtype == BF16 and C.dtype == torch.float32 and B.shape[0] == M and tuple(C.shape) == (N, K)
-    if _DRY_RUN:
-        gemm_tn(A, B, C, alpha=alpha, kernel=kernel)
-        return None
-    splits = lib().cdll.spmm_gemm_tn_splits(M, N, K, int(kernel))
-    ws = torch.empty(splits * N * K, dtype=torch.float32, device=C.device) if splits > 1 else None
-    ns = ctypes.c_int(0)
-    pws, pns, pN, pK, pC = pending if pending is not None else (None, 0, 0, 0, None)
-    _call("spmm_gemm_tn_chain", _p(A), _row_stride(A), _p(B), _row_stride(B), M, N, K, splits, float(alpha), _p(C), _row_stride(C), _p(ws),
-          _p(pws), pns, pN, pK, _p(pC), 0 if pC is None else _row_stride(pC), ctypes.c_void_p(ctypes.addressof(ns)), int(kernel), _st())
-    return (ws, ns.value, N, K, C) if ns.value > 0 else None
-
-
-def gemm_tn_flush(pending):
-    """Finish the slab reduction a gemm_tn_chain call left pending (on the current stream: the one the chain ran on)."""
-    if pending is not None:
-        ws, ns, N, K, C = pending
-        _call("spmm_gemm_tn_reduce", _p(ws), ns, N, K, _p(C), _row_stride(C), _st())
-
-
 def colsum_bf16(x, out):
     R, C = x.shape
     _call("spmm_colsum_bf16", _p(x), _row_stride(x), R, C, _p(out), _st())

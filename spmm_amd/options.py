@@ -18,7 +18,6 @@ _ENV = {
     "fp8": ("SPMM_FP8", lambda s: s == "1"),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
     "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
-    "wgrad_chain": ("SPMM_WGRAD_CHAIN", lambda s: s != "0"),
     "gelu_deriv_u8": ("SPMM_GELU_DERIV_U8", lambda s: s != "0"),
     "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
     "grad_wire": ("SPMM_GRAD_WIRE", str),
@@ -35,8 +34,6 @@ class EngineOptions:
     pack_text: bool = True        # drop padding-token rows from the text passes whose losses read only position 0
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
-    wgrad_chain: bool = False     # the slab reduction of a weight-gradient GEMM rides inside the NEXT one's launch on its stream (one reduction
-    #                               launch per chain instead of one per GEMM; csrc/gemm_tn.hip spmm_gemm_tn_chain)
     gelu_deriv_u8: bool = False   # gelu'(x) kept for the FFN backward as 8-bit codes instead of bf16 (half the bytes written and re-read;
     #                               6e-4 of the whole gradient, profiles/r03_gelu_deriv_u8_error.txt)
     fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)

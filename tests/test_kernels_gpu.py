@@ -35,33 +35,6 @@ def close(got, ref, atol, rtol, name=""):
                           f"(ref max {ref.abs().max().item():.4g}) first bad idx {bad.nonzero()[0].tolist()}"
 
 
-def test_chained_weight_gradient_reductions(ops):
-    """spmm_gemm_tn_chain / spmm_gemm_tn_reduce: every product's slab reduction rides inside the NEXT product's launch, the last one is
-    flushed.  Bit-identical to the plain launches (same slabs, same summation order), incl. two products accumulating into the SAME
-    matrix (slab mode after slab mode, then a small one on the 128x128 kernel, which carries no fold: the pending reduction runs first),
-    a direct-mode launch (one row slice) that folds another matrix's pending reduction, and ragged M."""
-    shapes = [(13824, 2304, 768), (20001, 768, 768), (16384, 768, 768), (900, 768, 768), (16384, 1536, 768), (8192, 3072, 3072), (300, 256, 128),
-              (13824, 768, 3072)]
-    same_as = {2: 1, 3: 1}                       # problems 2 and 3 accumulate into problem 1's matrix
-    mats, plain = {}, {}
-    for i, (M, N, K) in enumerate(shapes):
-        if i not in same_as:
-            mats[i] = torch.randn(N, K, device="cuda")
-            plain[i] = mats[i].clone()
-    ops_in = [(rnd(M, N, seed=300 + i, scale=0.5), rnd(M, K, seed=400 + i, scale=0.5)) for i, (M, N, K) in enumerate(shapes)]
-    pend, n_pending = None, 0
-    for i, (A, B) in enumerate(ops_in):
-        j = same_as.get(i, i)
-        ops.gemm_tn(A, B, plain[j])
-        pend = ops.gemm_tn_chain(A, B, mats[j], pend)
-        n_pending += pend is not None
-    ops.gemm_tn_flush(pend)
-    torch.cuda.synchronize()
-    assert n_pending >= 4, n_pending             # (the big shapes really went through the pending path)
-    for j in mats:
-        assert torch.equal(mats[j], plain[j]), f"matrix {j}: max |diff| {(mats[j] - plain[j]).abs().max().item():.3g}"
-
-
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (216, 300, 128), (6912, 768, 768), (100, 64, 3072),
                                    (512, 2304, 768)])
