@@ -47,6 +47,13 @@ PEAK_FP8_TFLOPS = 5000.0       # dense E4M3 MFMA (same guide: ~5 PF dense)
 PEAK_HBM_GBS = 8000.0
 
 
+def smi_sampler(period_s=0.05):
+    """Shader clock / socket power sampler (tools/smi_sampler.py: amdsmi, then rocm-smi; read-only).  Measurement plumbing only."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from smi_sampler import Sampler
+    return Sampler(period_s=period_s, index=int(os.environ.get("LOCAL_RANK", "0")))
+
+
 def synthetic_batch(B, Lt, seed, device):
     """SURVEY.md section 8d recipe (same as oracle.synthetic_batch; restated so the product never imports oracle/)."""
     g = torch.Generator().manual_seed(seed)
@@ -446,6 +453,11 @@ def main():
             host_lead.append((reached, e0, e1))
             return r
         opt_.step = step_probe
+    if hasattr(sync, "wait_events"):
+        sync.wait_events = []             # event pair around the compute stream's wait in OverlappedGradSync.finish(), one per timed step
+    smp = smi_sampler() if rank == 0 else None       # clock / power of GPU 0 over the timed region (a 20-Hz reader thread on the host)
+    if smp is not None:
+        smp.__enter__()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -456,6 +468,14 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    power = None
+    if smp is not None:
+        smp.__exit__(None, None, None)
+        power = smp.summary()
+    comm_wait = None
+    if hasattr(sync, "wait_events"):
+        comm_wait = [a.elapsed_time(b) for a, b in (sync.wait_events or [])]
+        sync.wait_events = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -469,6 +489,24 @@ def main():
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     spread = {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
               "p90": round(per_step[int(0.9 * (len(per_step) - 1) + 0.5)], 3), "note": "GPU-side interval between consecutive steps' last kernels (this rank)"}
+    dp_diag = None
+    if world > 1 or comm_wait is not None:
+        # Per rank, gathered: median / p90 step, the time the compute stream waited for the exchange at the end of the backward
+        # (communication the backward did not hide), so that a scaling run explains itself: which rank is slow, and whether it waits.
+        mine = torch.tensor([spread["median"], spread["p90"], (sum(comm_wait) / len(comm_wait)) if comm_wait else -1.0,
+                             max(comm_wait) if comm_wait else -1.0], dtype=torch.float32, device=dev)
+        allr = mine[None, :]
+        if world > 1:
+            allr = torch.empty(world, 4, dtype=torch.float32, device=dev)
+            torch.distributed.all_gather_into_tensor(allr, mine[None, :].contiguous())
+        allr = allr.cpu().tolist()
+        slow = max(range(len(allr)), key=lambda r_: allr[r_][0])
+        dp_diag = {"per_rank": [{"rank": r_, "step_ms_median": round(v[0], 3), "step_ms_p90": round(v[1], 3),
+                                 "comm_exposed_ms": None if v[2] < 0 else round(v[2], 3), "comm_exposed_ms_max": None if v[3] < 0 else round(v[3], 3)}
+                                for r_, v in enumerate(allr)],
+                   "slowest_rank": slow, "slowest_rank_step_ms": {"median": round(allr[slow][0], 3), "p90": round(allr[slow][1], 3)},
+                   "note": "comm_exposed_ms = GPU time the compute stream spends in OverlappedGradSync.finish() waiting for the gradient exchange "
+                           "(mean over the timed steps; includes the sweep of the ~2 % of the arena no layer covers)"}
     final_losses = [float(x) for x in losses.cpu()]
     mst = torch.cuda.memory_stats(dev)
     hbm = {"peak_allocated_gb": round(mst.get("allocated_bytes.all.peak", 0) / 2**30, 2), "peak_reserved_gb": round(mst.get("reserved_bytes.all.peak", 0) / 2**30, 2),
@@ -534,6 +572,20 @@ def main():
             one_step(i)
         torch.cuda.synchronize()
         ops.gemm_nt, ops.gemm_nt_f8 = orig_gemm, orig_f8
+        # sustained shader clock of the single-stream schedule these intervals come from: the same steps again, un-instrumented, under
+        # the sampler (the events' host work would otherwise thin the load the clock responds to)
+        smp1 = smi_sampler() if rank == 0 else None
+        if smp1 is not None:
+            with smp1:
+                for i in range(max(10, nsteps)):
+                    one_step(i)
+                torch.cuda.synchronize()
+            clk1 = smp1.summary()
+        else:
+            clk1 = None
+            for i in range(max(10, nsteps)):
+                one_step(i)
+            torch.cuda.synchronize()
         # the metric's kernel: the cross-attention unit (Q/K/V projections + softmax(QK^T)V + output projection, forward),
         # timed as a whole with events around BertAttention(cross) in separate instrumented steps
         eng = model.engine
@@ -599,6 +651,19 @@ def main():
                 "avg_launch_us_raw": round(raw_ms * 1e3 / n_launch, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                 "measured": f"HIP events around every launch, {nsteps} instrumented single-stream steps after the timed region; each interval "
                             "minus the calibrated event-pair overhead (2 I1 - I2 around one / two minimal kernels), which the rocprofv3 kernel trace does not contain"}
+        # `frac` divides by the 2.4-GHz sheet peak; the part runs this step well below that clock (power-limited), so the same rate is
+        # also quoted against the MFMA peak AT THE SUSTAINED CLOCK: peak x clock / 2 400 MHz.  Clock = mean sclk of GPU 0 over ten
+        # single-stream steps (the schedule the per-launch intervals come from); the timed region's own clock / power is in `power`.
+        if clk1 is not None and clk1.get("clock_mhz"):
+            roof["clock_mhz"] = clk1["clock_mhz"]
+            roof["power_w"] = clk1.get("power_w")
+            roof["peak_at_clock"] = round(PEAK_BF16_TFLOPS * clk1["clock_mhz"] / 2400.0, 1)
+            roof["frac_at_clock"] = round(ach / (PEAK_BF16_TFLOPS * clk1["clock_mhz"] / 2400.0), 4)
+            roof["clock_note"] = (f"mean of {clk1['samples']} samples ({clk1['source']}) over 10 un-instrumented single-stream steps; "
+                                  "per kernel family: profiles/r05_power.txt")
+        else:
+            roof["clock_mhz"] = None
+            roof["clock_note"] = f"no clock source on this box: {clk1}"
         if ev["f8"]:                                         # the fp8 tier's own launches, against the dense E4M3 peak
             f8_ms = sum(a.elapsed_time(b) for a, b, _ in ev["f8"]) - len(ev["f8"]) * ev_overhead_ms
             f8_fl = sum(fl for _, _, fl in ev["f8"])
@@ -642,8 +707,15 @@ def main():
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses, "hbm": hbm}
+    if power is not None:
+        out["power"] = dict(power, note="GPU 0 over the timed region (three-stream schedule): mean shader clock and socket power")
+        if power.get("clock_mhz"):
+            out["mfma_frac_of_peak_step_at_clock"] = round(flops / (dt / args.steps) / 1e12 / (PEAK_BF16_TFLOPS * power["clock_mhz"] / 2400.0), 4)
+    if dp_diag is not None:
+        out["data_parallel"] = dp_diag
     if n_check:
         out["schedule_check_steps"] = n_check
+        out["schedule_check"] = model.schedule_decision()
     from spmm_amd import streams
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks

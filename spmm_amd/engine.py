@@ -135,8 +135,11 @@ class Engine:
         # A stream takes its hardware queue at its FIRST USE and there are only a handful of queues: a foreign stream first used between
         # side0 and side1 ran the plain step at 71.6 ms instead of 59.4 (tools/first_steps.py, EXPERIMENTS.md 2.7b).  So the step's
         # streams take their queues here, in one go.  (Data-parallel processes do it in parallel.grad_sync_fn, RCCL's stream first.)
-        if (self.multi_stream and torch.device(device).type == "cuda" and not ops._DRY_RUN
-                and not (torch.distributed.is_available() and torch.distributed.is_initialized())):
+        # (A process that merely HOLDS a one-rank group -- torchrun --nproc 1, user code -- gets no exchange from grad_sync_fn and so no
+        # binding there: what decides is whether a data-parallel exchange will run, not whether torch.distributed is initialised.)
+        dist_ = torch.distributed
+        will_exchange = dist_.is_available() and dist_.is_initialized() and (dist_.get_world_size() > 1 or self.opt.force_dist)
+        if self.multi_stream and torch.device(device).type == "cuda" and not ops._DRY_RUN and not will_exchange:
             streams.bind_in_order(device, ("side0", "side1", "wgrad"))
         self.force_one_stream = False     # set by the data-parallel schedule check (model.py::_schedule_check)
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []

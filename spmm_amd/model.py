@@ -364,24 +364,28 @@ class SPMM(_Base):
             check.record(torch.cuda.current_stream())
         return losses
 
-    # Data-parallel runs only (EngineOptions.schedule_check): the first SCHEDULE_CHECK_STEPS steps try both schedules -- steps 0-3 on the
-    # side streams to warm up (allocator pools grow while batches of new packed sizes arrive), 4-6 timed, 7-8 on one stream to warm its
-    # pool, 9-11 timed -- and the faster one runs from step 12 on, the single stream only if its median wins by 13 % or more.  On every node
-    # measured so far the three-stream schedule is 5-9 % faster; with some orders of stream creation next to RCCL's stream it runs at 80 ms
-    # instead of 60 (EXPERIMENTS.md 1.4), and this package has never run next to a multi-rank communicator.  Both schedules give the same
-    # results bit for bit; the events are read once, at the decision.
-    SCHEDULE_CHECK_STEPS = 12
+    # Data-parallel runs only (EngineOptions.schedule_check): the first SCHEDULE_CHECK_STEPS steps THAT CARRY A GRADIENT EXCHANGE try both
+    # schedules -- 3 steps on the side streams and 3 on one stream to warm up (allocator pools grow while batches of new packed sizes
+    # arrive), then 10 timed steps ALTERNATING between the two (five samples each, neither schedule always measured on the warmer clocks /
+    # pools) -- and the faster one runs from then on, the single stream only if its median wins by 13 % or more.  On every node measured so
+    # far the three-stream schedule is 5-9 % faster; with some orders of stream creation next to RCCL's stream it runs at 80 ms instead of
+    # 60 (EXPERIMENTS.md 1.4), and this package has never run next to a multi-rank communicator.  Both schedules give the same results
+    # bit for bit; the events are read once, at the decision, which is logged with both medians (streams.log()).
+    SCHEDULE_CHECK_STEPS = 16
+    _SCHED_WARM = (3, 3)              # untimed warm-up steps: three streams, then one stream
 
     def _schedule_check_begin(self, grad_sync):
         eng = self.engine
+        if grad_sync is None:         # a warm-up / evaluation-style step without an exchange neither counts nor latches the decision
+            return None
         st = getattr(self, "_sched", None)
         if st is None:
-            on = (grad_sync is not None and eng.opt.schedule_check and eng.multi_stream and self.device_.type == "cuda"
-                  and not getattr(ops, "_DRY_RUN", False))
+            on = (eng.opt.schedule_check and eng.multi_stream and self.device_.type == "cuda" and not getattr(ops, "_DRY_RUN", False))
             st = self._sched = {"n": 0, "on": on, "ev": []}
         if not st["on"]:
             return None
         n = st["n"]
+        w3, w1 = self._SCHED_WARM
         if n >= self.SCHEDULE_CHECK_STEPS:
             ms = {"three streams": [], "one stream": []}
             for e0, e1, which in st["ev"]:
@@ -397,17 +401,26 @@ class SPMM(_Base):
             keep_single = single <= 0.87 * multi
             eng.force_one_stream = keep_single
             st["on"], st["ev"] = False, []
+            st["decision"] = {"three_streams_ms": round(multi, 2), "one_stream_ms": round(single, 2), "samples_each": len(ms["one stream"]),
+                              "kept": "one stream" if keep_single else "three streams"}
             from . import streams
-            streams.note(f"schedule check: median {multi:.1f} ms on three streams, {single:.1f} ms on one -> " + ("ONE stream kept" if keep_single else "three streams kept"))
+            streams.note(f"schedule check: median {multi:.1f} ms on three streams, {single:.1f} ms on one ({len(ms['one stream'])} alternating samples each) -> "
+                         + ("ONE stream kept" if keep_single else "three streams kept"))
             return None
-        eng.force_one_stream = n >= 7
         st["n"] = n + 1
-        if n in (4, 5, 6, 9, 10, 11):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream())
-            st["ev"].append((e0, e1, "three streams" if n < 7 else "one stream"))
-            return e1
-        return None
+        if n < w3 + w1:
+            eng.force_one_stream = n >= w3
+            return None
+        single = (n - w3 - w1) % 2 == 1
+        eng.force_one_stream = single
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        st["ev"].append((e0, e1, "one stream" if single else "three streams"))
+        return e1
+
+    def schedule_decision(self):
+        """-> the data-parallel schedule check's decision and the medians it rests on (None before it was taken / when it did not run)."""
+        return (getattr(self, "_sched", None) or {}).get("decision")
 
     def fused_step_graphed(self, prop, ids, mask, alpha, *, mpm_mask=None, neg_idx=None):
         """The same step as ONE hipGraph launch (single rank; SPMM_models.py:348-380 has no counterpart -- this removes the ~26 ms

@@ -45,8 +45,8 @@ class EngineOptions:
     grad_wire: str = "fp32"       # "fp32": all-reduce on the arena; "bf16": cast + reduce-scatter + all-gather (half the link bytes)
     nt_under_comm: str = "tiles"  # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile) or "persistent"
     force_dist: bool = False      # run the N>1 code path with a one-rank process group (tests on a one-GPU box)
-    schedule_check: bool = True   # data-parallel runs try both schedules during their first 12 steps (three streams: 4 warm-up + 3 timed steps,
-    #                               one stream: 2 + 3) and keep the single stream only if its median is >= 13 % faster: the stream-order
+    schedule_check: bool = True   # data-parallel runs try both schedules during their first 16 steps with an exchange (3 + 3 warm-up steps, then
+    #                               5 + 5 timed steps alternating) and keep the single stream only if its median is >= 13 % faster: the stream-order
     #                               dependent 80-ms mode of EXPERIMENTS.md 1.4 cannot be ruled out on a node this package has never run on
     #                               (results are identical either way; bench.py runs these steps before its warm-up)
     probe_streams: bool = False   # diagnostic: at start-up of a data-parallel run, check that RCCL's stream and the compute streams sit on

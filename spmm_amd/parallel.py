@@ -92,6 +92,8 @@ class OverlappedGradSync:
         # (three chip-filling streams side by side ran the step in 76-78 ms against 61-62)
         self.exclusive = True
         self.trace = None            # set to [] to record (lo, hi, issue event, done event) per slice (tests / timeline checks)
+        self.wait_events = None      # set to [] to record, per step, an event pair around finish()'s wait on the compute stream: the
+        #                              communication time the backward did NOT hide (bench.py `comm_exposed_ms`)
 
     def begin(self, grad: torch.Tensor):
         assert grad.numel() == self.total
@@ -144,8 +146,15 @@ class OverlappedGradSync:
             for a in range(pos, lo, BUCKET_ELEMS):
                 self._reduce(a, min(lo, a + BUCKET_ELEMS))
             pos = max(pos, hi)
+        timed = self.wait_events is not None and self._grad is not None and self._grad.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._work:
             w.wait()
+        if timed:
+            e1.record()
+            self.wait_events.append((e0, e1))
         for lo, hi, buf, shard in self._staged:
             self._grad[lo:hi].copy_(buf[:hi - lo])
             if buf.is_cuda:                                      # allocated in the issuing stream's pool, last read here

@@ -1107,8 +1107,9 @@ def test_rccl_code_path_single_rank(env):
 
 
 def test_data_parallel_schedule_check_times_both_schedules_and_decides(env):
-    """EngineOptions.schedule_check (data-parallel runs): the first 12 steps try the three-stream and the one-stream schedule (bench.py runs
-    them before its warm-up), the decision is reported in `stream_placement`; the losses of the run equal those of a run without the check at
+    """EngineOptions.schedule_check (data-parallel runs): the first 16 steps try the three-stream and the one-stream schedule (6 warm-up, then
+    10 alternating timed steps; bench.py runs them before its warm-up), the decision and its medians are reported in `stream_placement` and
+    `schedule_check`; the losses of the run equal those of a run without the check at
     the same step count (both schedules give the same results).  One-rank RCCL group."""
     import subprocess, sys, json, socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1116,7 +1117,7 @@ def test_data_parallel_schedule_check_times_both_schedules_and_decides(env):
             "--queue", "64", "--no-cpu-baseline", "--no-kernel-timing", "--eval-mode"]
     res = {}
     for chk in ("1", "0"):
-        cmd = base + ["--warmup", "2" if chk == "1" else "14"]          # 12 check steps + 2 = 14 untimed steps either way
+        cmd = base + ["--warmup", "2" if chk == "1" else "18"]          # 16 check steps + 2 = 18 untimed steps either way
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root,
                              env=dict(os.environ, SPMM_FORCE_DIST="1", SPMM_SCHEDULE_CHECK=chk, MASTER_PORT=str(port)))
@@ -1124,7 +1125,9 @@ def test_data_parallel_schedule_check_times_both_schedules_and_decides(env):
         res[chk] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     notes = " | ".join(res["1"].get("stream_placement", []))
     print(notes)
-    assert "schedule check:" in notes and ("three streams kept" in notes or "ONE stream kept" in notes) and res["1"]["schedule_check_steps"] == 12
+    assert "schedule check:" in notes and ("three streams kept" in notes or "ONE stream kept" in notes) and res["1"]["schedule_check_steps"] == 16
+    dec = res["1"]["schedule_check"]
+    assert dec["samples_each"] == 5 and dec["kept"] in ("three streams", "one stream") and dec["three_streams_ms"] > 0 and dec["one_stream_ms"] > 0
     assert "schedule check:" not in " | ".join(res["0"].get("stream_placement", []))
     np.testing.assert_allclose(res["1"]["losses"], res["0"]["losses"], rtol=3e-3, atol=0)
 

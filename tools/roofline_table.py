@@ -3,9 +3,14 @@
 divided by the measured launch time (HIP events, 20 launches after 3 warm-ups).  Writes a markdown table."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 import torch
 from spmm_amd import ops
+from smi_sampler import Sampler            # tools/smi_sampler.py (this directory is sys.path[0])
 BF = torch.bfloat16
+# ROOFLINE_POWER=1: every row additionally runs back to back for ~1.2 s under the clock / power sampler -> columns MHz, W, and the
+# fraction of the MFMA peak AT THE SUSTAINED CLOCK (2 500 TF/s x MHz / 2 400); written to gpurun_out/power_table.txt
+POWER = os.environ.get("ROOFLINE_POWER") == "1"
 dev = "cuda"
 PEAK_BW, PEAK_TF = 8000.0, 2500.0
 
@@ -31,8 +36,27 @@ def add(name, shape, fn, nbytes=None, flops=None, n=20):
     tfs = flops / us / 1e6 if flops else None
     bound = "HBM" if (flops is None or (nbytes and flops / nbytes < 300)) else "MFMA"
     frac = gbs / PEAK_BW if bound == "HBM" else tfs / PEAK_TF
-    rows.append((name, shape, us, gbs, tfs, bound, frac))
-    print(f"{name:34s} {shape:28s} {us:9.1f} us  {'' if gbs is None else f'{gbs:7.0f} GB/s':>12s}  {'' if tfs is None else f'{tfs:7.1f} TF/s':>12s}  {bound:4s} {frac:6.3f}", flush=True)
+    pw = None
+    if POWER:
+        reps = max(n, int(1.2e6 / max(us, 1.0)))
+        with Sampler(period_s=0.02) as smp:
+            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+        pw = smp.summary()
+        pw["us_sustained"] = e0.elapsed_time(e1) / reps * 1e3
+    rows.append((name, shape, us, gbs, tfs, bound, frac, pw))
+    extra = ""
+    if pw and pw.get("clock_mhz"):
+        tf_s = flops / pw["us_sustained"] / 1e6 if flops else None
+        extra = f"  | sustained {pw['us_sustained']:8.1f} us  {pw['clock_mhz']:6.0f} MHz  {pw['power_w'] or 0:6.0f} W"
+        if tf_s and bound == "MFMA":
+            at_clk = tf_s / (PEAK_TF * pw["clock_mhz"] / 2400.0)
+            extra += f"  {tf_s:7.1f} TF/s = {at_clk:5.3f} of the peak at that clock"
+    print(f"{name:34s} {shape:28s} {us:9.1f} us  {'' if gbs is None else f'{gbs:7.0f} GB/s':>12s}  {'' if tfs is None else f'{tfs:7.1f} TF/s':>12s}  {bound:4s} {frac:6.3f}{extra}", flush=True)
 
 
 M, H, I = 84256, 768, 3072
@@ -99,6 +123,22 @@ rows.sort(key=lambda r: 0)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
     f.write("| kernel | shape | us / launch | GB/s | TFLOP/s | bound | fraction of peak |\n|---|---|---|---|---|---|---|\n")
-    for name, shape, us, gbs, tfs, bound, frac in rows:
+    for name, shape, us, gbs, tfs, bound, frac, _pw in rows:
         f.write(f"| {name} | {shape} | {us:.1f} | {'' if gbs is None else f'{gbs:.0f}'} | {'' if tfs is None else f'{tfs:.1f}'} | {bound} | {frac:.3f} |\n")
 print("wrote", out)
+if POWER:
+    out2 = os.path.join(os.path.dirname(out), "power_table.txt")
+    with open(out2, "w") as f:
+        f.write("kernel family at its dominant shape, back-to-back launches for ~1.2 s each (tools/roofline_table.py, ROOFLINE_POWER=1; clock / power: tools/smi_sampler.py)\n")
+        f.write(f"{'kernel':42s} {'shape':28s} {'us first':>9s} {'us sust.':>9s} {'MHz':>6s} {'W':>6s} {'TF/s':>8s} {'of 2.5 PF':>9s} {'at clock':>9s}\n")
+        for name, shape, us, gbs, tfs, bound, frac, pw in rows:
+            if not pw or not pw.get("clock_mhz"):
+                f.write(f"{name:42s} {shape:28s} {us:9.1f}  (no clock / power source: {pw})\n")
+                continue
+            fl = tfs * us * 1e6 if tfs else None
+            tf_s = fl / pw["us_sustained"] / 1e6 if fl else None
+            at_clk = None if tf_s is None else tf_s / (PEAK_TF * pw["clock_mhz"] / 2400.0)
+            f.write(f"{name:42s} {shape:28s} {us:9.1f} {pw['us_sustained']:9.1f} {pw['clock_mhz']:6.0f} {pw['power_w'] or 0:6.0f} "
+                    f"{'' if tf_s is None else f'{tf_s:8.1f}':>8s} {'' if tf_s is None else f'{tf_s / PEAK_TF:9.3f}':>9s} "
+                    f"{'' if at_clk is None else f'{at_clk:9.3f}':>9s}\n")
+    print("wrote", out2)
