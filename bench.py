@@ -108,6 +108,17 @@ def padding_saving(B, Lt, n_valid, Lp=54, H=768, I=3072, n_text=12, fusion=6):
     return pad * (3 * fusion * self_tok + 2 * fusion * self_tok + 3 * 2 * (n_text - fusion) * fus_tok + (n_text - fusion) * fus_tok)
 
 
+def cls_top_saving(B, Lt, n_valid, Lp=54, H=768, I=3072):
+    """FLOPs not executed in the LAST fusion layer: the three ITM pass pairs feed only position 0 of their last hidden states to a loss
+    (SPMM_models.py:199-201), so that layer runs its query / output / FFN work for those sequences on position 0 alone and keeps only
+    the self-attention key / value projections of their other rows (spmm_amd/step.py::_s6_forward_cls).  Rows as executed: PV queries
+    3B x Lp, packed text queries 2 x n_valid, dense text negatives B x Lt; forward + backward = 3 x forward, as in step_flops."""
+    dead = 3 * B * (Lp - 1) + 2 * (n_valid - B) + B * (Lt - 1)
+    gemm = dead * (8 * H * H + 4 * H * I)                      # self Q + self out + cross Q + cross out + FFN; self K / V stay
+    core = 4 * H * (3 * B * (Lp - 1) * (Lp + Lt) + 3 * B * (Lt - 1) * (Lt + Lp))     # attention cores of the dead queries (upper bound: dense Lt)
+    return 3 * (gemm + core)
+
+
 def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):
     """Fused cross-attention unit (Q/K/V projections + core + out-proj), BASELINE.md section 3."""
     return nseq * (4 * H * H * Lq + 4 * H * H * Lkv + 4 * Lq * Lkv * H)
@@ -703,7 +714,9 @@ def main():
                        "; per-layer gradient exchange overlapped with the backward, weight gradients on the backward's stream meanwhile"))},
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
-                                         - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= ops.ATTN_MAXL else 0.0)) / 1e12, 2),
+                                         - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= ops.ATTN_MAXL else 0.0)
+                                         - (cls_top_saving(B, Lt, n_valid) if (Lt <= ops.ATTN_MAXL and opts.cls_only_top and opts.pack_text
+                                                                               and not opts.resid_fp32) else 0.0)) / 1e12, 2),
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses, "hbm": hbm}

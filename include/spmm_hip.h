@@ -221,6 +221,33 @@ int spmm_acc_rows(float* dst, long ldd, const void* src, long lds, const long* i
                   spmm_stream_t stream);
 int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int H, spmm_stream_t stream);
 
+/* Row bookkeeping of a step as device kernels (csrc/plan.hip) -- what SPMM.forward does with torch.cat / indexing on whole
+ * tensors (SPMM_models.py:139-150,166-199: the ITM passes' query / key-value pairings and hard negatives; :95,105,201: only
+ * position 0 of those passes is read), here on packed rows and without a tensor-library launch per index array.
+ *  spmm_gather_rows2: dst[r] = idx[r] < 0 ? 0 : (idx[r] & 2^40 ? srcB : srcA)[idx[r] & (2^40 - 1)]  (rows of H bf16, H % 8 == 0).
+ *  spmm_add_rows_bf16: dst[idx[r]] += src[r], every idx at most once.   spmm_zero_bytes / spmm_zero_rows: 16-byte granular fill with zeros
+ *   (contiguous / `rows` pieces of row_bytes at a stride).
+ *  spmm_gelu_bwd: out = dz * gelu'(pre), erf-GELU (the transform of BertLMPredictionHead xbert.py:673 and the GELU of
+ *   property_mtr_head SPMM_models.py:39, backward).
+ *  spmm_pack_plan: from the attention mask [B, Lt] and the host's count M of valid tokens: per sequence length / first packed row
+ *   (lens32, row0_32, row0_64), rows[M] = dense row of every packed row, gidx2[M + B Lt] / gidx4[2M] = gather indices that build the
+ *   [packed | dense] and [packed | packed] batches of the text encoders from their dense [2B Lt] embeddings, inv[2 B Lt] = packed row of
+ *   every dense row (-1: padding) for the way back; *bad |= 1 when the mask is not B non-empty prefixes with M tokens in all.
+ *  spmm_fusion_plan: index arrays of the fusion batch (layout in csrc/plan.hip) from the sampled negatives neg[2B] (prop | text):
+ *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]), maskcat [2B, Lt] key masks of
+ *   the dense text group, neg_rows [B Lt] (packed row of every token of a text negative, M = none), idx_top (rows the top fusion layer
+ *   keeps: position 0 of the 6B ITM sequences, every row of the LM and causal-PV passes), small32 [39 B] (sequence -> key/value
+ *   source maps, packed row tables, CSR inverse maps of the two shared key/value sources). */
+int spmm_gather_rows2(void* dst, const void* srcA, const void* srcB, const long* idx, long rows, int H, spmm_stream_t stream);
+int spmm_add_rows_bf16(void* dst, const long* idx, const void* src, long rows, int H, spmm_stream_t stream);
+int spmm_zero_bytes(void* p, long nbytes, spmm_stream_t stream);
+int spmm_zero_rows(void* p, long rows, long row_bytes, long stride_bytes, spmm_stream_t stream);
+int spmm_gelu_bwd(const void* dz, const void* pre, void* out, long n, spmm_stream_t stream);
+int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32, int* row0_32, long* row0_64, long* rows, long* gidx2,
+                   long* gidx4, long* inv, int* bad, spmm_stream_t stream);
+int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, const int* mask, int B, int Lt, int Lp, int M,
+                     long* idx6, int* maskcat, long* neg_rows, long* idx_top, int* small32, spmm_stream_t stream);
+
 /* F.normalize(proj(cls), dim=-1) SPMM_models.py:92,95,101,105; also emits split-bf16 GEMM operands. */
 int spmm_l2norm_fwd(const float* x, long ldx, float* y, float* nrm, void* a3, void* w3, void* yT, long ldt, int rows, int E,
                     spmm_stream_t stream);

@@ -58,6 +58,11 @@ class KVSource:
         self.nseq += idx.numel()
         return off
 
+    def preset(self, nseq: int, start: torch.Tensor, lst: torch.Tensor):
+        """The inverse map computed elsewhere (csrc/plan.hip::fusion_plan_kernel) instead of finalize(); consumers then `bind`."""
+        self.nseq, self.start, self.list = nseq, start, lst
+        return self
+
     def finalize(self):
         idx = torch.cat(self._idx)
         order = torch.sort(idx, stable=True).indices
@@ -66,6 +71,15 @@ class KVSource:
         start[1:] = torch.cumsum(counts, 0)             # (torch.bincount reads max(idx) back to the host: a hidden sync per source)
         self.start, self.list = start, order.to(torch.int32)
         return self
+
+
+@dataclass
+class SelfKV:
+    """Private SELF-attention key/value source of groups that keep only some query rows of their sequences (the CLS-only top fusion
+    layer, step.py): keys / values are projected from `x` -- rows of the layer input, every token of the sequences -- with the layer's own
+    key / value weights; a group's sequence s owns skv_len[s] rows from row skv_row0[s] of x.  Backward writes d(loss)/dx into `dx`."""
+    x: torch.Tensor
+    dx: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -86,11 +100,20 @@ class Group:
     src: Optional[KVSource] = None         # shared cross-attention source ...
     kv_idx: Optional[torch.Tensor] = None  # ... int32 [nseq]: the source sequence each query sequence attends
     kv_off: int = 0                        # ... offset of this group's sequences in the source's consumer numbering
+    self_src: Optional[SelfKV] = None      # self-attention keys / values from the full sequences (query rows are a subset) ...
+    skv_row0: Optional[torch.Tensor] = None    # ... int32 [nseq]: first row of sequence s in self_src.x
+    skv_len: Optional[torch.Tensor] = None     # ... int32 [nseq]
+    skv_L: int = 0                             # ... longest sequence
 
     @property
     def rows(self):
         n = self.nrows if self.nrows >= 0 else self.nseq * self.L
         return slice(self.row0, self.row0 + n)
+
+    def bind(self, src: KVSource, kv_idx: torch.Tensor, kv_off: int) -> "Group":
+        """attend() for a source whose consumer numbering is preset: kv_idx int32 [nseq], kv_off = this group's offset in it."""
+        self.src, self.Lkv, self.kv_idx, self.kv_off = src, src.Lkv, kv_idx, kv_off
+        return self
 
     def attend(self, src: KVSource, idx: torch.Tensor) -> "Group":
         self.src, self.Lkv = src, src.Lkv
@@ -175,7 +198,7 @@ class Engine:
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
     def _zeros(self, *shape, dtype=BF):
-        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        return ops.zero_(torch.empty(*shape, dtype=dtype, device=self.dev))
 
     def _next_salt(self):
         self._salt += 1
@@ -274,13 +297,24 @@ class Engine:
             QKV = self._new(M, 3 * H)
             ops.gemm_nt(X, Wqkv, QKV, bias=bqkv)
             sv["QKV"] = QKV
+            skv = sv["SKV"] = {}                                 # K/V of the groups' private self-attention sources (SelfKV), one GEMM each
             for g in groups:
                 lse = self._new(g.nseq, nH, g.L, dtype=torch.float32) if save else None
                 salt = self._next_salt()
                 r = g.rows
-                self._attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
-                             kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt,
-                             q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
+                if g.self_src is not None:
+                    # query rows = a subset of their sequences' rows (here: position 0 only); keys / values = every token of the
+                    # sequence, projected from the layer input with the key / value rows of the fused weight
+                    if id(g.self_src) not in skv:
+                        skv[id(g.self_src)] = ops.gemm_nt(g.self_src.x, Wqkv[H:], self._new(g.self_src.x.shape[0], 2 * H), bias=bqkv[H:])
+                    KVs = skv[id(g.self_src)]
+                    self._attn_fwd(QKV[r, :H], KVs[:, :H], KVs[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.skv_L,
+                                   kmask=None, causal_from=g.nseq, dropout_p=pa, seed=self.seed, salt=salt,
+                                   q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.skv_row0, kv_len=g.skv_len)
+                else:
+                    self._attn_fwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L,
+                                   kmask=g.kmask, causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=salt,
+                                   q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
         else:
@@ -378,15 +412,29 @@ class Engine:
         if not sv["cross"]:
             QKV = sv["QKV"]
             dQKV = self._new(M, 3 * H)
+            gWqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="g")
+            gbqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="g")
+            dskv = {}
             for i, g in enumerate(groups):
                 r = g.rows
+                if g.self_src is not None:
+                    if id(g.self_src) not in dskv:               # rows no sequence owns (zero rows past a negative's length) stay zero
+                        dskv[id(g.self_src)] = (g.self_src, self._zeros(g.self_src.x.shape[0], 2 * H))
+                    KVs, dKVs = sv["SKV"][id(g.self_src)], dskv[id(g.self_src)][1]
+                    self._attn_bwd(QKV[r, :H], KVs[:, :H], KVs[:, H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H], dKVs[:, :H], dKVs[:, H:],
+                                   nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.skv_L, kmask=None, causal_from=g.nseq, dropout_p=pa, seed=self.seed,
+                                   salt=sv["salt_a"][i], q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.skv_row0, kv_len=g.skv_len)
+                    ops.zero_(dQKV[r, H:])                       # the batch rows' own keys / values were never attended
+                    continue
                 self._attn_bwd(QKV[r, :H], QKV[r, H:2 * H], QKV[r, 2 * H:], sv["ctx"][r], sv["lse"][i], dctx[r], dQKV[r, :H],
                              dQKV[r, H:2 * H], dQKV[r, 2 * H:], nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.L, kmask=g.kmask,
                              causal_from=g.causal_from, dropout_p=pa, seed=self.seed, salt=sv["salt_a"][i],
                              q_row0=g.q_row0, q_len=g.q_len, kv_row0=g.q_row0, kv_len=g.q_len)
-            self._wgrad(dQKV, X, P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="g"),
-                        P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="g"))
+            self._wgrad(dQKV, X, gWqkv, gbqkv)
             WT = self._wT(pfx + ".self.qkv", P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="w"))
+            for src, dKVs in dskv.values():                      # key / value projections of the private sources: weight and data gradient
+                self._wgrad(dKVs, src.x, gWqkv[H:], gbqkv[H:])
+                ops.gemm_nt(dKVs, WT[:, H:], src.dx)
             ops.gemm_nt(dQKV, WT, dX, R=dz)
         else:
             Qc = sv["Qc"]
@@ -416,7 +464,7 @@ class Engine:
                 W = src.Lkv * 2 * H
                 dKVu = ops.segment_sum_bf16(dKV.view(src.nseq, W), src.start, src.list, self._new(src.U, W)).view(-1, 2 * H)
                 if src.pack_idx is not None:
-                    dKVu = dKVu.index_select(0, src.pack_idx)
+                    dKVu = ops.gather_rows(self._new(src.pack_idx.numel(), 2 * H), dKVu, src.pack_idx)
                 self._wgrad(dKVu, src.kv, gWkv, gbkv)
                 ops.gemm_nt(dKVu, WkvT, dkv_acc[id(src)], epi=ops.EPI_F32_ACC)
             self._wgrad(dQc, X, P.g(pfx + ".self.query.weight"), P.g(pfx + ".self.query.bias"))
@@ -565,7 +613,7 @@ class Engine:
         ops.gemm_nt(y, P.wb(pfx + "cls.predictions.decoder.weight"), logits, bias=P.w(pfx + "cls.predictions.bias"), epi=ops.EPI_F32)
         return logits, dict(X=X, pre=pre, z=t, mean=mean, rstd=rstd, y=y)
 
-    def lm_head_bwd(self, pfx, c, sv, dlogits):
+    def lm_head_bwd(self, pfx, c, sv, dlogits, out=None):
         """dlogits bf16 [M, Vpad] (zero padded) -> dX bf16 [M,H]; the decoder is tied to the word embeddings."""
         P, H, V, M = self.P, c.hidden_size, c.vocab_size, dlogits.shape[0]
         Vp = dlogits.shape[1]
@@ -586,7 +634,7 @@ class Engine:
         # through the erf-GELU: dpre = dz * gelu'(pre)  (identity GEMM would be wasteful: reuse the GELU-grad epilogue of the dgrad)
         dpre = self._gelu_bwd(dz, sv["pre"])
         self._wgrad(dpre, sv["X"], P.g(pfx + "cls.predictions.transform.dense.weight"), P.g(pfx + "cls.predictions.transform.dense.bias"))
-        dX = self._new(M, H)
+        dX = self._new(M, H) if out is None else out
         ops.gemm_nt(dpre, self._wT(pfx + "cls.transform", P.w(pfx + "cls.predictions.transform.dense.weight")), dX)
         return dX
 
@@ -595,11 +643,8 @@ class Engine:
             self.P._wT[key][:, :V].copy_(self.P.w(name).t())
 
     def _gelu_bwd(self, dz, pre):
-        """elementwise dz * gelu'(pre) (small head tensors only) -- torch elementwise ops as plumbing."""
-        x = pre.float()
-        cdf = 0.5 * (1.0 + torch.erf(x * 0.7071067811865476))
-        pdf = torch.exp(-0.5 * x * x) * 0.3989422804014327
-        return (dz.float() * (cdf + x * pdf)).to(BF)
+        """elementwise dz * gelu'(pre) (small head tensors only)."""
+        return ops.gelu_bwd(dz, pre)
 
     # ---------------------------------------------------------------------------------------------- features
     def _feat_fwd(self, proj, X, L, B, save, cls_rows=None, X32=None):

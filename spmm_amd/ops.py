@@ -244,6 +244,93 @@ def gather_rows(dst, src, idx):
     return dst
 
 
+SRC_B = 1 << 40        # gather_rows2: index bit that selects the second source (csrc/plan.hip)
+
+
+def gather_rows2(dst, srcA, idx, srcB=None):
+    """dst[r] = 0 if idx[r] < 0 else (srcB if idx[r] & SRC_B else srcA)[idx[r] & (SRC_B - 1)]; rows of H bf16-sized elements."""
+    rows, H = dst.shape
+    assert idx.dtype == torch.int64 and idx.numel() >= rows and dst.is_contiguous() and srcA.is_contiguous() and (srcB is None or srcB.is_contiguous())
+    assert dst.dtype == BF16 and srcA.dtype == BF16 and srcA.shape[1] == H and (srcB is None or (srcB.dtype == BF16 and srcB.shape[1] == H))
+    _call("spmm_gather_rows2", _p(dst), _p(srcA), _p(srcB), _p(idx), rows, H, _st())
+    return dst
+
+
+def add_rows_bf16(dst, idx, src):
+    """dst[idx[r]] += src[r] (bf16 rows, every index at most once)."""
+    rows, H = src.shape
+    assert dst.dtype == BF16 and src.dtype == BF16 and idx.dtype == torch.int64 and dst.is_contiguous() and src.is_contiguous() and dst.shape[1] == H
+    _call("spmm_add_rows_bf16", _p(dst), _p(idx), _p(src), rows, H, _st())
+    return dst
+
+
+def zero_(t):
+    """t.zero_() without a tensor-library launch (contiguous, 16-byte granular)."""
+    n = t.numel() * t.element_size()
+    if n == 0:
+        return t
+    if not t.is_contiguous():                      # a column slice of a row-major matrix: rows of equal length at a constant stride
+        es = t.element_size()
+        if t.dim() == 2 and t.stride(1) == 1 and (t.shape[1] * es) % 16 == 0 and (t.stride(0) * es) % 16 == 0 and t.data_ptr() % 16 == 0:
+            _call("spmm_zero_rows", _p(t), t.shape[0], t.shape[1] * es, t.stride(0) * es, _st())
+            return t
+        return t.zero_()
+    if n % 16 or t.data_ptr() % 16:
+        return t.zero_()
+    _call("spmm_zero_bytes", _p(t), n, _st())
+    return t
+
+
+def gelu_bwd(dz, pre, out=None):
+    """out = dz * gelu'(pre) (erf-GELU), bf16."""
+    assert dz.dtype == BF16 and pre.dtype == BF16 and dz.is_contiguous() and pre.is_contiguous() and dz.shape == pre.shape
+    out = torch.empty_like(dz) if out is None else out
+    _call("spmm_gelu_bwd", _p(dz), _p(pre), _p(out), dz.numel(), _st())
+    return out
+
+
+def pack_plan(mask32, M, bad):
+    """Packed-row plan of the text passes from the [B, Lt] attention mask and the host's valid-token count M (csrc/plan.hip)."""
+    B, Lt = mask32.shape
+    dev = mask32.device
+    alloc = torch.zeros if _DRY_RUN else torch.empty          # (dry runs launch nothing: index 0 keeps the host-side indexing valid)
+    i32 = alloc(2 * B, dtype=torch.int32, device=dev)
+    i64 = alloc(B + M + (M + B * Lt) + 2 * M + 2 * B * Lt, dtype=torch.int64, device=dev)
+    o = [0]
+
+    def cut(n):
+        o[0] += n
+        return i64[o[0] - n:o[0]]
+    row0_64, rows, gidx2, gidx4, inv = cut(B), cut(M), cut(M + B * Lt), cut(2 * M), cut(2 * B * Lt)
+    _call("spmm_pack_plan", _p(mask32), B, Lt, M, _p(i32[:B]), _p(i32[B:]), _p(row0_64), _p(rows), _p(gidx2), _p(gidx4), _p(inv), _p(bad), _st())
+    return dict(M=M, rows=rows, row0=i32[B:], row0_64=row0_64, len=i32[:B], gidx2=gidx2, gidx4=gidx4, inv=inv)
+
+
+FUSION_SMALL = dict(ar=(0, 1), kvidx_pv=(1, 3), kvidx_tp=(4, 2), kvidx_td=(6, 2), kvidx_ctx=(8, 3), qrow0_tp=(11, 2), qlen_tp=(13, 2),
+                    skv_row0_pv=(15, 3), skv_len_pv=(18, 3), skv_row0_tx=(21, 3), skv_len_tx=(24, 3), start_t=(27, 2), list_t=(29, 4),
+                    start_p=(33, 2), list_p=(35, 4))          # (offset, length) in units of B: the layout csrc/plan.hip writes
+
+
+def fusion_plan(neg, pk, mask32, Lp):
+    """Index arrays of the fusion batch from the sampled negatives (csrc/plan.hip::fusion_plan_kernel) -> dict of views."""
+    B, Lt = mask32.shape
+    M, dev = pk["M"], mask32.device
+    R6 = 4 * B * Lp + 2 * M + 2 * B * Lt
+    ntop = 6 * B + B * Lt + B * Lp
+    alloc = torch.zeros if _DRY_RUN else torch.empty
+    i64 = alloc(R6 + B * Lt + ntop, dtype=torch.int64, device=dev)
+    idx6, neg_rows, idx_top = i64[:R6], i64[R6:R6 + B * Lt], i64[R6 + B * Lt:]
+    maskcat = alloc(2 * B, Lt, dtype=torch.int32, device=dev)
+    small = alloc(39 * B, dtype=torch.int32, device=dev)
+    _call("spmm_fusion_plan", _p(neg), _p(pk["len"]), _p(pk["row0"]), _p(mask32), B, Lt, Lp, M, _p(idx6), _p(maskcat), _p(neg_rows), _p(idx_top),
+          _p(small), _st())
+    out = dict(idx6=idx6, neg_rows=neg_rows, idx_top=idx_top, maskcat=maskcat, R6=R6)
+    for k, (o, n) in FUSION_SMALL.items():
+        out[k] = small[o * B:(o + n) * B]
+    out["start_t"], out["start_p"] = out["start_t"][:B + 1], out["start_p"][:B + 1]
+    return out
+
+
 def l2norm_fwd(x, y, nrm, *, a3=None, w3=None, yT=None):
     rows, E = y.shape
     _call("spmm_l2norm_fwd", _p(x), _row_stride(x), _p(y), _p(nrm), _p(a3), _p(w3), _p(yT),

@@ -13,6 +13,7 @@ from dataclasses import dataclass
 # field -> (environment variable, parser)
 _ENV = {
     "pack_text": ("SPMM_PACK_TEXT", lambda s: s != "0"),
+    "cls_only_top": ("SPMM_CLS_ONLY_TOP", lambda s: s != "0"),
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
     "fp8": ("SPMM_FP8", lambda s: s == "1"),
@@ -32,6 +33,8 @@ _ENV = {
 class EngineOptions:
     # --- schedule of one step (spmm_amd/step.py, engine.py) ---
     pack_text: bool = True        # drop padding-token rows from the text passes whose losses read only position 0
+    cls_only_top: bool = True     # last fusion layer of the ITM passes on position 0 only (what the ITM head reads, SPMM_models.py:199-201); their other
+    #                               rows stay keys / values of its self-attention.  Packed path only; exact
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
     gelu_deriv_u8: bool = False   # gelu'(x) kept for the FFN backward as 8-bit codes instead of bf16 (half the bytes written and re-read;

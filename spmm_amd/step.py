@@ -6,7 +6,7 @@ from typing import Callable, Optional, Tuple
 import torch
 
 from . import ops
-from .engine import STREAM_TOKENS_MAX, BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, KVSource, _ceil
+from .engine import STREAM_TOKENS_MAX, BF, LOSS_ITA, LOSS_ITM, LOSS_MLM, LOSS_MPM, Engine, Group, KVSource, SelfKV, _ceil
 
 
 class PretrainStep(Engine):
@@ -17,32 +17,78 @@ class PretrainStep(Engine):
         that every mask row is a non-empty prefix, which is what padding='longest' produces) or it is read back from the device,
         one blocking read per step.  Returns None -- dense fallback -- when a sequence does not start with a valid token
         (position 0 is what the losses read) or nothing would be saved."""
-        lens = mask32.sum(1)
         if n_tokens is not None:
             M = int(n_tokens)
             if M >= B * Lt:
                 return None
             # The caller vouches for the hint (SPMM.training_step derives it from the tokenizer's host mask itself).  Best effort
-            # against a wrong one, without a read-back: the mismatch is detected on the device and raises the NaN flag (AdamW, EMA
-            # and enqueue become no-ops, as for a non-finite loss, SPMM_models.py:132-134), and the per-sequence bookkeeping below
-            # is clamped to the rows the hint sized; launches sized from other derived quantities may still misbehave.
-            prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
-            bad = (lens.sum() != M) | (lens.min() < 1) | ~prefix.all()
-            self.hint_bad.copy_(bad.to(self.hint_bad.dtype))
+            # against a wrong one, without a read-back: the mismatch is detected on the device (spmm_pack_plan raises `hint_bad`) and
+            # raises the NaN flag (AdamW, EMA and enqueue become no-ops, as for a non-finite loss, SPMM_models.py:132-134), and the
+            # per-sequence bookkeeping is clamped to the rows the hint sized; launches sized from other derived quantities may still misbehave.
         else:
+            lens = mask32.sum(1)
             prefix = (torch.arange(Lt, device=mask32.device)[None, :] < lens[:, None]) == (mask32 != 0)
             stats = torch.stack([lens.sum(), (lens > 0).sum(), prefix.all().to(lens.dtype)]).cpu()
             M, nonempty, is_prefix = int(stats[0]), int(stats[1]), int(stats[2])
             if nonempty != B or not is_prefix or M >= B * Lt:   # holes in the mask: the packed index would not be the position
                 return None
-        rows = torch.argsort((mask32.view(-1) == 0), stable=True)[:M]          # valid rows first, original order kept
-        row0 = torch.cumsum(lens, 0) - lens
-        if n_tokens is not None:            # whatever the hint was, no launch may index past the M rows it sized (the step is skipped then)
-            if M < 1:
-                return None
-            row0 = row0.clamp(max=M - 1)
-            lens = torch.minimum(lens, M - row0).clamp(min=1)
-        return dict(M=M, rows=rows, row0=row0.to(torch.int32), row0_64=row0.to(torch.int64), len=lens.to(torch.int32))
+        if M < 1:
+            return None
+        # valid rows first, original order kept; whatever the hint was, no index leaves the M rows it sized (csrc/plan.hip)
+        return ops.pack_plan(mask32, M, self.hint_bad)
+
+    # ------------------------------------------------------------------------------- fusion batch, packed path
+    def _s6_forward_cls(self, B, Lt, M, pk, mask32, neg, y1, y2, prop_embeds, text_embeds, save):
+        """The seven student fusion passes (:137-198, :224-231, :243-250) as one batch, with the TOP fusion layer reduced to the rows a
+        loss reads.  The three ITM pass pairs feed only position 0 of their last hidden states to the ITM head (:199-201), so in the last
+        layer their other rows matter only as self-attention keys / values: that layer runs on [6B position-0 rows | every row of the LM
+        pass | every row of the causal PV pass], the position-0 queries attending keys / values projected from the full sequences
+        (engine.SelfKV).  Exact: the rows left out reach no loss, and their gradients are exactly zero in the reference too.
+        Every index array comes from ONE launch (spmm_fusion_plan); the batch and the top layer's input are two row gathers.
+        Batch layout (csrc/plan.hip): [PV queries pe | pe[neg] | pe] [text packed te | te] [text negatives, dense] [LM pass] [causal PV]."""
+        cfg = self.cfg
+        ct = cfg.text
+        H, Lp, f, n = ct.hidden_size, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
+        fp = ops.fusion_plan(neg, pk, mask32, Lp)
+        o_tp = 3 * B * Lp
+        o_tn = o_tp + 2 * M
+        o_lm = o_tn + B * Lt
+        o_12 = o_lm + B * Lt
+        X6 = ops.gather_rows2(self._new(fp["R6"], H), y1, fp["idx6"], y2)
+        src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp).preset(4 * B, fp["start_p"], fp["list_p"])
+        src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"]).preset(4 * B, fp["start_t"], fp["list_t"])
+        g_lo = [Group(0, 3 * B, Lp, None, 3 * B).bind(src_text, fp["kvidx_pv"], 0),
+                Group(o_tp, 2 * B, Lt, None, 2 * B, q_row0=fp["qrow0_tp"], q_len=fp["qlen_tp"], nrows=2 * M).bind(src_pv, fp["kvidx_tp"], 0),
+                Group(o_tn, 2 * B, Lt, fp["maskcat"], B).bind(src_pv, fp["kvidx_td"], 2 * B),
+                Group(o_12, B, Lp, None, 0).bind(src_text, fp["ar"], 3 * B)]
+        y, tape_lo = self.stack_fwd("text_encoder.bert.", ct, range(f, n - 1), True, X6, g_lo, save)
+        ntop = 6 * B + B * Lt + B * Lp
+        Xtop = ops.gather_rows2(self._new(ntop, H), y, fp["idx_top"])
+        skv = SelfKV(y[:o_lm])
+        g_top = [Group(0, 3 * B, 1, None, 3 * B, self_src=skv, skv_row0=fp["skv_row0_pv"], skv_len=fp["skv_len_pv"], skv_L=Lp).bind(src_text, fp["kvidx_pv"], 0),
+                 Group(3 * B, 3 * B, 1, None, 3 * B, self_src=skv, skv_row0=fp["skv_row0_tx"], skv_len=fp["skv_len_tx"], skv_L=Lt).bind(src_pv, fp["kvidx_ctx"], 0),
+                 Group(6 * B, B, Lt, mask32, 0).bind(src_pv, fp["ar"], 3 * B),
+                 Group(6 * B + B * Lt, B, Lp, None, 0).bind(src_text, fp["ar"], 3 * B)]
+        ytop, sv_top, _ = self._layer_fwd(f"text_encoder.bert.encoder.layer.{n - 1}.", ct, True, Xtop, g_top, save)
+        return dict(fp=fp, ytop=ytop, sv_top=sv_top, g_top=g_top, skv=skv, g_lo=g_lo, tape_lo=tape_lo, src_text=src_text, src_pv=src_pv,
+                    o_tp=o_tp, o_tn=o_tn, o_lm=o_lm, o_12=o_12, ntop=ntop)
+
+    def _s6_backward_cls(self, T, dYtop, d_pe, d_te):
+        """Backward of `_s6_forward_cls`: dYtop = d(loss)/d(top layer output) on its [6B | B Lt | B Lp] rows -> d(loss)/d(batch rows)."""
+        S6, B, Lt, M = T["S6"], T["B"], T["Lt"], T["M"]
+        cfg = self.cfg
+        ct = cfg.text
+        H, Lp, f, n = ct.hidden_size, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
+        fp, o_lm = S6["fp"], S6["o_lm"]
+        dkv_acc = {id(S6["src_text"]): d_te[:M], id(S6["src_pv"]): d_pe.view(B * Lp, H)}
+        dX6 = self._new(fp["R6"], H)
+        S6["skv"].dx = dX6[:o_lm]                                # the ITM sequences' rows: gradient through the top layer's keys / values ...
+        dXtop = self._layer_bwd(f"text_encoder.bert.encoder.layer.{n - 1}.", ct, S6["sv_top"], dYtop, S6["g_top"], dkv_acc)
+        if self.layer_done_cb is not None:
+            self._layer_done(f"text_encoder.bert.encoder.layer.{n - 1}.")
+        ops.add_rows_bf16(dX6, fp["idx_top"][:6 * B], dXtop[:6 * B])     # ... plus, at position 0, what came through the queries
+        dX6[o_lm:].copy_(dXtop[6 * B:])
+        return self.stack_bwd("text_encoder.bert.", ct, range(f, n - 1), S6["tape_lo"], dX6, S6["g_lo"], dkv_acc=dkv_acc)
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, prop: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, *, mpm_mask: Optional[torch.Tensor] = None,
@@ -93,7 +139,8 @@ class PretrainStep(Engine):
             # never attended as a key, so its rows influence nothing: those passes run on the packed valid rows.  The
             # student's LM pass (P10) keeps every row -- its loss counts the padding targets (:233).
             if pk:
-                x2 = torch.cat([x2[:B * Lt].index_select(0, pk["rows"]), x2[B * Lt:]])
+                x2d = x2
+                x2 = ops.gather_rows2(self._new(M + B * Lt, H), x2d, pk["gidx2"])
                 if r32:
                     x2_32 = torch.cat([x2_32[:B * Lt].index_select(0, pk["rows"]), x2_32[B * Lt:]])
                 g2 = [Group(0, B, Lt, None, B, q_row0=pk["row0"], q_len=pk["len"], nrows=M), Group(M, B, Lt, mask32, 0)]
@@ -118,7 +165,8 @@ class PretrainStep(Engine):
             if pk:
                 # The teacher's LM logits are read only where the label is a real token (:236-237), and a causal position
                 # sees nothing to its right: P9 (unlike P10) is packed too.
-                x4 = torch.cat([x4[:B * Lt].index_select(0, pk["rows"]), x4[B * Lt:].index_select(0, pk["rows"])])
+                x4d = x4
+                x4 = ops.gather_rows2(self._new(2 * M, H), x4d, pk["gidx4"])
                 if r32:
                     x4_32 = torch.cat([x4_32[:B * Lt].index_select(0, pk["rows"]), x4_32[B * Lt:].index_select(0, pk["rows"])])
                 g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
@@ -151,7 +199,13 @@ class PretrainStep(Engine):
             y5, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(f, n), True, hidden9, g5, False, X32=hidden9_32)
             logits_m, _ = self.lm_head_fwd("text_encoder_m.", ct, y5, False)
             if pk:                                               # the loss kernel indexes [B, Lt, V]
-                logits_m = torch.zeros(B * Lt, logits_m.shape[1], dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
+                V_ = logits_m.shape[1]
+                if V_ % 4 == 0:                                  # rows of 4 V bytes = 2 V bf16-sized elements: the row gather serves them
+                    dense = torch.empty(B * Lt, V_, dtype=logits_m.dtype, device=self.dev)
+                    ops.gather_rows2(dense.view(BF), logits_m.view(BF), pk["inv"])
+                    logits_m = dense
+                else:
+                    logits_m = torch.zeros(B * Lt, V_, dtype=logits_m.dtype, device=self.dev).index_copy_(0, pk["rows"], logits_m)
 
         # ---- features, similarity banks, ITA loss and its gradient w.r.t. the student features (:92-131)
         bank = self._banks(B)
@@ -189,62 +243,76 @@ class PretrainStep(Engine):
         ops.sample_neg(S_text[:B], B, neg[B:], forced=ft, seed=self.seed, salt=self._next_salt())
 
         # ---- S6: the fusion layers over all seven student fusion passes at once (:137-198, :224-231, :243-250)
-        # Cross-attention sources: the four PV-query passes read [te, te, te[neg], te], the four text-query passes
-        # [pe, pe[neg], pe, pe] -- B unique sequences each (KVSource): K/V are projected once on the unique rows and the
-        # attention kernels follow the sequence -> source map.
-        pe = prop_embeds.view(B, Lp * H)
-        pe_neg = ops.gather_rows(self._new(B, Lp * H), pe, neg[:B])
-        ar = torch.arange(B, dtype=torch.int64, device=self.dev)
-        mask_neg = mask32.index_select(0, neg[B:])
-        qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
-        if r32:
-            pe32 = prop_embeds_32.view(B, Lp * H)
-            qpv_32 = torch.cat([pe32, pe32.index_select(0, neg[:B]), pe32, prop_embeds_causal_32.view(B, Lp * H)]).view(4 * B * Lp, H)
-        src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp)
-        if pk:
-            src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"])
-            neg_rows = pk["row0_64"].index_select(0, neg[B:])[:, None] + torch.arange(Lt, device=self.dev)[None, :]
-            neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)   # dense (i, l) -> row of te
-            r0 = 4 * B * Lp
-            # Text negatives as queries (second half of P8) stay dense [B, Lt]: which sequences were drawn is device data, and
-            # packing them behind a second host read measured no gain.  Rows past the negative's length are zero-filled and
-            # masked as keys.
+        # Layout, index arrays and the CLS-only top layer of the packed path: `_s6_forward_cls` (csrc/plan.hip); the general form below
+        # serves dense masks, `aux` inspection and the fp32 residual stream.
+        cls_top = bool(pk) and self.opt.cls_only_top and not r32 and aux is None
+        if cls_top:
+            S6 = self._s6_forward_cls(B, Lt, M, pk, mask32, neg, y1, y2, prop_embeds, text_embeds, save)
+            ytop = S6["ytop"]
+            ops.itm_head(ytop[:3 * B], H, ytop[3 * B:6 * B], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
+                         slot=LOSS_ITM, logits=None)
+            ytext = hid10_cls = ytop[6 * B:6 * B + B * Lt]
+            ypv = ypv_h = ytop                                   # (tape names of the general path)
+            hp12_cls = ytop[6 * B + B * Lt:]
+            src_text = src_pv = neg_rows = cls_text = itm_text = g6 = tape6 = None
             Mn = B * Lt
-            te_neg = torch.cat([text_embeds, self._zeros(1, H)]).index_select(0, neg_rows)
-            qtext = torch.cat([text_embeds, text_embeds, te_neg, hidden10])
-            if r32:
-                te_neg_32 = torch.cat([text_embeds_32, self._zeros(1, H, dtype=torch.float32)]).index_select(0, neg_rows)
-                qtext_32 = torch.cat([text_embeds_32, text_embeds_32, te_neg_32, hidden10_32])
-            gt = [Group(r0, 2 * B, Lt, None, 2 * B, q_row0=torch.cat([pk["row0"], pk["row0"] + M]), q_len=torch.cat([pk["len"], pk["len"]]),
-                        nrows=2 * M).attend(src_pv, torch.cat([ar, neg[:B]])),
-                  Group(r0 + 2 * M, 2 * B, Lt, torch.cat([mask_neg, mask32]), B).attend(src_pv, torch.cat([ar, ar]))]
-            cls_text = torch.cat([pk["row0_64"], pk["row0_64"] + M, 2 * M + ar * Lt])
-            kvmask_qpv = None                                   # key padding is implied by the source lengths
         else:
-            src_text = KVSource(text_embeds, B, Lt)
-            te = text_embeds.view(B, Lt * H)
-            te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
-            qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
+            # Cross-attention sources: the four PV-query passes read [te, te, te[neg], te], the four text-query passes
+            # [pe, pe[neg], pe, pe] -- B unique sequences each (KVSource): K/V are projected once on the unique rows and the
+            # attention kernels follow the sequence -> source map.
+            pe = prop_embeds.view(B, Lp * H)
+            pe_neg = ops.gather_rows(self._new(B, Lp * H), pe, neg[:B])
+            ar = torch.arange(B, dtype=torch.int64, device=self.dev)
+            mask_neg = mask32.index_select(0, neg[B:])
+            qpv = torch.cat([pe, pe_neg, pe, prop_embeds_causal.view(B, Lp * H)]).view(4 * B * Lp, H)
             if r32:
-                te32 = text_embeds_32.view(B, Lt * H)
-                qtext_32 = torch.cat([te32, te32, te32.index_select(0, neg[B:]), hidden10_32.view(B, Lt * H)]).view(4 * B * Lt, H)
-            kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
-            gt = [Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B).attend(src_pv, torch.cat([ar, neg[:B], ar, ar]))]
-            neg_rows, cls_text, Mn = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt, B * Lt
-        X6 = torch.cat([qpv, qtext])
-        g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv_mask=kvmask_qpv).attend(src_text, torch.cat([ar, ar, neg[B:], ar]))] + gt
-        src_text.finalize()
-        src_pv.finalize()
-        y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save, X32=torch.cat([qpv_32, qtext_32]) if r32 else None)
-        ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
-        # the loss heads read the fp32 twins in that mode (forward and backward: the tape keeps what the forward read)
-        ypv_h, ytext_h = (self.last32[:4 * B * Lp], self.last32[4 * B * Lp:]) if r32 else (ypv, ytext)
+                pe32 = prop_embeds_32.view(B, Lp * H)
+                qpv_32 = torch.cat([pe32, pe32.index_select(0, neg[:B]), pe32, prop_embeds_causal_32.view(B, Lp * H)]).view(4 * B * Lp, H)
+            src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp)
+            if pk:
+                src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"])
+                neg_rows = pk["row0_64"].index_select(0, neg[B:])[:, None] + torch.arange(Lt, device=self.dev)[None, :]
+                neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)   # dense (i, l) -> row of te
+                r0 = 4 * B * Lp
+                # Text negatives as queries (second half of P8) stay dense [B, Lt]: which sequences were drawn is device data, and
+                # packing them behind a second host read measured no gain.  Rows past the negative's length are zero-filled and
+                # masked as keys.
+                Mn = B * Lt
+                te_neg = torch.cat([text_embeds, self._zeros(1, H)]).index_select(0, neg_rows)
+                qtext = torch.cat([text_embeds, text_embeds, te_neg, hidden10])
+                if r32:
+                    te_neg_32 = torch.cat([text_embeds_32, self._zeros(1, H, dtype=torch.float32)]).index_select(0, neg_rows)
+                    qtext_32 = torch.cat([text_embeds_32, text_embeds_32, te_neg_32, hidden10_32])
+                gt = [Group(r0, 2 * B, Lt, None, 2 * B, q_row0=torch.cat([pk["row0"], pk["row0"] + M]), q_len=torch.cat([pk["len"], pk["len"]]),
+                            nrows=2 * M).attend(src_pv, torch.cat([ar, neg[:B]])),
+                      Group(r0 + 2 * M, 2 * B, Lt, torch.cat([mask_neg, mask32]), B).attend(src_pv, torch.cat([ar, ar]))]
+                cls_text = torch.cat([pk["row0_64"], pk["row0_64"] + M, 2 * M + ar * Lt])
+                kvmask_qpv = None                                   # key padding is implied by the source lengths
+            else:
+                src_text = KVSource(text_embeds, B, Lt)
+                te = text_embeds.view(B, Lt * H)
+                te_neg = ops.gather_rows(self._new(B, Lt * H), te, neg[B:])
+                qtext = torch.cat([te, te, te_neg, hidden10.view(B, Lt * H)]).view(4 * B * Lt, H)
+                if r32:
+                    te32 = text_embeds_32.view(B, Lt * H)
+                    qtext_32 = torch.cat([te32, te32, te32.index_select(0, neg[B:]), hidden10_32.view(B, Lt * H)]).view(4 * B * Lt, H)
+                kvmask_qpv = torch.cat([mask32, mask32, mask_neg, mask32])
+                gt = [Group(4 * B * Lp, 4 * B, Lt, kvmask_qpv, 3 * B).attend(src_pv, torch.cat([ar, neg[:B], ar, ar]))]
+                neg_rows, cls_text, Mn = None, torch.arange(3 * B, dtype=torch.int64, device=self.dev) * Lt, B * Lt
+            X6 = torch.cat([qpv, qtext])
+            g6 = [Group(0, 4 * B, Lp, None, 3 * B, kv_mask=kvmask_qpv).attend(src_text, torch.cat([ar, ar, neg[B:], ar]))] + gt
+            src_text.finalize()
+            src_pv.finalize()
+            y6, tape6 = self.stack_fwd("text_encoder.bert.", ct, range(f, n), True, X6, g6, save, X32=torch.cat([qpv_32, qtext_32]) if r32 else None)
+            ypv, ytext = y6[:4 * B * Lp], y6[4 * B * Lp:]
+            # the loss heads read the fp32 twins in that mode (forward and backward: the tape keeps what the forward read)
+            ypv_h, ytext_h = (self.last32[:4 * B * Lp], self.last32[4 * B * Lp:]) if r32 else (ypv, ytext)
 
-        # ---- ITM head (:199-206) on the position-0 rows of the first 3B sequences of both halves
-        vl_logits = self._new(3 * B, 2, dtype=torch.float32) if aux is not None else None
-        itm_text = ytext_h.index_select(0, cls_text)
-        ops.itm_head(ypv_h, Lp * H, itm_text, H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
-                     slot=LOSS_ITM, logits=vl_logits)
+            # ---- ITM head (:199-206) on the position-0 rows of the first 3B sequences of both halves
+            vl_logits = self._new(3 * B, 2, dtype=torch.float32) if aux is not None else None
+            itm_text = ytext_h.index_select(0, cls_text)
+            ops.itm_head(ypv_h, Lp * H, itm_text, H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=self.losses,
+                         slot=LOSS_ITM, logits=vl_logits)
 
         # ---- queue (:208, :272-286)
         feat_pm, feat_tm = feats["property_proj_m"][0], feats["text_proj_m"][0]
@@ -261,13 +329,13 @@ class PretrainStep(Engine):
 
         # ---- LM loss (:211-238)
         self._join(side5)
-        hid10 = ytext[ytext.shape[0] - B * Lt:]
+        hid10 = hid10_cls if cls_top else ytext[ytext.shape[0] - B * Lt:]
         logits, lmsv = self.lm_head_fwd("text_encoder.", ct, hid10, save)
         ops.lm_loss(logits, logits_m, ids32, nseq=B, L=Lt, V=ct.vocab_size, alpha=self.alpha, ws=self.icount[0:1], losses=self.losses,
                     slot=LOSS_MLM)
 
         # ---- MPM (:241-256)
-        hp12 = ypv[3 * B * Lp:]
+        hp12 = hp12_cls if cls_top else ypv[3 * B * Lp:]
         mt, mpre = self._new(B * Lp, H), self._new(B * Lp, H)
         ops.gemm_nt(hp12, P.wb("property_mtr_head.0.weight"), mt, bias=P.w("property_mtr_head.0.bias"), epi=ops.EPI_GELU, C2=mpre)
         mln = self._new(B * Lp, H)
@@ -296,7 +364,7 @@ class PretrainStep(Engine):
                              prop=prop, mpm_mask=mpm_mask, ids32=ids32, ids2=ids2, esv1=esv1, g1=g1, tape1=tape1,
                              esv2=esv2, g2=g2, tape2=tape2, feats=feats, dfeat=dfeat, neg=neg, g6=g6, tape6=tape6, ypv=ypv_h,
                              ytext=ytext, logits=logits, logits_m=logits_m, lmsv=lmsv, hp12=hp12, mpre=mpre, mt=mt, mln=mln_h,
-                             mmean=mmean, mrstd=mrstd)
+                             mmean=mmean, mrstd=mrstd, S6=S6 if cls_top else None)
         return self.losses[:4]
 
     # ----------------------------------------------------------------------------------------------- backward
@@ -312,9 +380,16 @@ class PretrainStep(Engine):
         gs = self.gscale
         scratch = self.loss_scratch
         pk, M = T["pk"], T["M"]
-        nt6 = T["ytext"].shape[0]                                  # text-query rows of S6: 2M + 2B*Lt packed, 4B*Lt dense
-        dY6 = self._zeros(4 * B * Lp + nt6, H)
-        dYpv, dYtext = dY6[:4 * B * Lp], dY6[4 * B * Lp:]
+        S6 = T["S6"]                                               # packed path with the CLS-only top layer (_s6_forward_cls), else None
+        if S6 is not None:
+            # gradient w.r.t. the top layer's output on its [6B position-0 rows | LM pass | causal PV pass] rows: every row is written below
+            dYtop = self._new(S6["ntop"], H)
+            dY_mpm, dY_lm = dYtop[6 * B + B * Lt:], dYtop[6 * B:6 * B + B * Lt]
+        else:
+            nt6 = T["ytext"].shape[0]                              # text-query rows of S6: 2M + 2B*Lt packed, 4B*Lt dense
+            dY6 = self._zeros(4 * B * Lp + nt6, H)
+            dYpv, dYtext = dY6[:4 * B * Lp], dY6[4 * B * Lp:]
+            dY_mpm, dY_lm = dYpv[3 * B * Lp:], dYtext[nt6 - B * Lt:]
 
         # ---- MPM head
         dmln = self._new(B * Lp, H)
@@ -326,42 +401,56 @@ class PretrainStep(Engine):
                    dgamma=P.g("property_mtr_head.2.weight"), dbeta=P.g("property_mtr_head.2.bias"))
         dmpre = self._gelu_bwd(dmz, T["mpre"])
         self._wgrad(dmpre, T["hp12"], P.g("property_mtr_head.0.weight"), P.g("property_mtr_head.0.bias"))
-        ops.gemm_nt(dmpre, self._wT("property_mtr_head.0", P.w("property_mtr_head.0.weight")), dYpv[3 * B * Lp:])
+        ops.gemm_nt(dmpre, self._wT("property_mtr_head.0", P.w("property_mtr_head.0.weight")), dY_mpm)
 
         # ---- LM head
         V = ct.vocab_size
         dlogits = self._new(B * Lt, _ceil(V, 64))
         ops.lm_loss(T["logits"], T["logits_m"], T["ids32"], nseq=B, L=Lt, V=V, alpha=self.alpha, ws=self.icount[0:1], losses=scratch,
                     slot=LOSS_MLM, dlogits=dlogits, gscale=gs[0:1])
-        dYtext[nt6 - B * Lt:].copy_(self.lm_head_bwd("text_encoder.", ct, T["lmsv"], dlogits))
+        self.lm_head_bwd("text_encoder.", ct, T["lmsv"], dlogits, out=dY_lm)
 
         # ---- ITM head: gradients of the position-0 rows of the first 3B sequences of both halves
-        ditm = self._new(3 * B, H)
-        ops.itm_head(T["ypv"], Lp * H, T["itm_text"], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
-                     slot=LOSS_ITM, dxa=dYpv, dxb=ditm, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
-        dYtext.index_copy_(0, T["cls_text"], ditm)
-
-        # ---- S6 backward
+        neg_p, neg_t = T["neg"][:B], T["neg"][B:]
         d_pe = self._zeros(B, Lp * H, dtype=torch.float32)          # hub gradients of prop_embeds / text_embeds (fp32);
         d_te = self._zeros(M + 1, H, dtype=torch.float32)           # text rows packed like text_embeds, + one dump row
-        # the cross-attention K/V data gradients land directly on the unique sources (KVSource)
-        dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"],
-                             dkv_acc={id(T["src_text"]): d_te[:M], id(T["src_pv"]): d_pe.view(B * Lp, H)})
-        dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:]
-        neg_p, neg_t = T["neg"][:B], T["neg"][B:]
-        ops.acc_rows(d_pe, dXpv[0:B])
-        ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
-        ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
-        if pk:
+        if S6 is not None:
+            ytop = S6["ytop"]
+            ops.itm_head(ytop[:3 * B], H, ytop[3 * B:6 * B], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
+                         slot=LOSS_ITM, dxa=dYtop[:3 * B], dxb=dYtop[3 * B:6 * B], dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
+            # ---- S6 backward; the cross-attention K/V data gradients land directly on the unique sources (KVSource)
+            dX6 = self._s6_backward_cls(T, dYtop, d_pe, d_te)
+            dXpv = dX6[:3 * B * Lp].view(3 * B, Lp * H)
+            dXt = dX6[S6["o_tp"]:]
+            ops.acc_rows(d_pe, dXpv[0:B])
+            ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
+            ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
             ops.acc_rows(d_te[:M], dXt[:M])
             ops.acc_rows(d_te[:M], dXt[M:2 * M])
-            d_te.index_add_(0, T["neg_rows"], dXt[2 * M:2 * M + T["Mn"]].float())    # dense variant: rows past a negative's length -> dump row
+            ops.acc_rows(d_te, dXt[2 * M:2 * M + B * Lt], idx=S6["fp"]["neg_rows"], atomic=True)   # rows past a negative's length -> dump row
+            dXt_lm, dX12 = dX6[S6["o_lm"]:S6["o_12"]], dX6[S6["o_12"]:]
         else:
-            dte, dxt = d_te[:M].view(B, Lt * H), dXt.view(4 * B, Lt * H)
-            ops.acc_rows(dte, dxt[0:B])
-            ops.acc_rows(dte, dxt[B:2 * B])
-            ops.acc_rows(dte, dxt[2 * B:3 * B], idx=neg_t, atomic=True)
-        dXt_lm = dXt[nt6 - B * Lt:]
+            ditm = self._new(3 * B, H)
+            ops.itm_head(T["ypv"], Lp * H, T["itm_text"], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,
+                         slot=LOSS_ITM, dxa=dYpv, dxb=ditm, dW=P.g("itm_head.weight"), db=P.g("itm_head.bias"), gscale=gs[3:4])
+            dYtext.index_copy_(0, T["cls_text"], ditm)
+            # ---- S6 backward; the cross-attention K/V data gradients land directly on the unique sources (KVSource)
+            dX6 = self.stack_bwd("text_encoder.bert.", ct, range(f, n), T["tape6"], dY6, T["g6"],
+                                 dkv_acc={id(T["src_text"]): d_te[:M], id(T["src_pv"]): d_pe.view(B * Lp, H)})
+            dXpv, dXt = dX6[:4 * B * Lp].view(4 * B, Lp * H), dX6[4 * B * Lp:]
+            ops.acc_rows(d_pe, dXpv[0:B])
+            ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
+            ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
+            if pk:
+                ops.acc_rows(d_te[:M], dXt[:M])
+                ops.acc_rows(d_te[:M], dXt[M:2 * M])
+                ops.acc_rows(d_te, dXt[2 * M:2 * M + T["Mn"]], idx=T["neg_rows"], atomic=True)    # dense variant: rows past a negative's length -> dump row
+            else:
+                dte, dxt = d_te[:M].view(B, Lt * H), dXt.view(4 * B, Lt * H)
+                ops.acc_rows(dte, dxt[0:B])
+                ops.acc_rows(dte, dxt[B:2 * B])
+                ops.acc_rows(dte, dxt[2 * B:3 * B], idx=neg_t, atomic=True)
+            dXt_lm, dX12 = dXt[nt6 - B * Lt:], dXpv[3 * B:].reshape(B * Lp, H)
 
         # ---- ITA: stored d loss / d features -> projections -> CLS rows
         for k, proj in enumerate(("property_proj", "text_proj")):
@@ -374,7 +463,7 @@ class PretrainStep(Engine):
             if k == 0:
                 ops.acc_rows(d_pe[:, :H], dcls)
             elif pk:
-                d_te.index_add_(0, pk["row0_64"], dcls.float())
+                ops.acc_rows(d_te, dcls, idx=pk["row0_64"])
             else:
                 ops.acc_rows(d_te[:M].view(B, Lt * H)[:, :H], dcls)
         ops.axpy_scalar(P.g("temp").view(1), self.dtemp_ita, scale_ptr=gs[2:3])
@@ -386,11 +475,8 @@ class PretrainStep(Engine):
             ops.cast_f32_bf16(d_te[:M].view(-1), dY2[:M].view(-1))
             dY2[M:].copy_(dXt_lm)
             dX2 = self.stack_bwd("text_encoder.bert.", ct, range(0, f), T["tape2"], dY2, T["g2"])
-            if pk:                                              # back to the dense layout of the embedding kernels
-                dense = self._zeros(2 * B * Lt, H)
-                dense[:B * Lt].index_copy_(0, pk["rows"], dX2[:M])
-                dense[B * Lt:].copy_(dX2[M:])
-                dX2 = dense
+            if pk:                                              # back to the dense layout of the embedding kernels (padding rows: zero)
+                dX2 = ops.gather_rows2(self._new(2 * B * Lt, H), dX2, pk["inv"])
             dz2 = self._embed_ln_bwd("text_encoder.bert.", ct, T["esv2"], dX2)
             tp = "text_encoder.bert.embeddings."
             ops.embed_bwd(0, dz2, nseq=2 * B, L=Lt, H=H, dpos=P.g(tp + "position_embeddings.weight"),
@@ -399,7 +485,7 @@ class PretrainStep(Engine):
         # ---- ... S1 backward (PV encoder on P1 | P11) and the PV embedding
         dY1 = self._new(2 * B * Lp, H)
         ops.cast_f32_bf16(d_pe.view(-1), dY1[:B * Lp].view(-1))
-        dY1[B * Lp:].copy_(dXpv[3 * B:].reshape(B * Lp, H))
+        dY1[B * Lp:].copy_(dX12)
         dX1 = self.stack_bwd("property_encoder.", cp, range(cp.num_hidden_layers), T["tape1"], dY1, T["g1"])
         dz1 = self._embed_ln_bwd("property_encoder.", cp, T["esv1"], dX1)
         pp = "property_encoder.embeddings."

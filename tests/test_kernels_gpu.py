@@ -1338,3 +1338,138 @@ def test_beam_step_kernel_matches_tensor_bookkeeping(N, k, V):
     assert n_fin >= min(N, 8) and bool(ref.done.any())
     got, want = fus.results(), ref.results()
     assert [[h[1] for h in m] for m in got] == [[h[1] for h in m] for m in want]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# row bookkeeping kernels (csrc/plan.hip) against the tensor-library forms they replace
+@pytest.mark.parametrize("B,Lt", [(8, 37), (128, 128), (12, 200)])
+def test_pack_plan_matches_tensor_bookkeeping(ops, B, Lt):
+    g = torch.Generator().manual_seed(B + Lt)
+    lens = torch.randint(1, Lt + 1, (B,), generator=g); lens[0] = Lt
+    mask = (torch.arange(Lt)[None, :] < lens[:, None]).int().cuda()
+    M = int(lens.sum())
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pk = ops.pack_plan(mask, M, bad)
+    rows = torch.argsort((mask.view(-1) == 0), stable=True)[:M]
+    row0 = (torch.cumsum(lens, 0) - lens).cuda()
+    assert int(bad) == 0 and torch.equal(pk["rows"], rows) and torch.equal(pk["row0_64"], row0) and torch.equal(pk["row0"].long(), row0)
+    assert torch.equal(pk["len"].long().cpu(), lens)
+    BL = B * Lt
+    assert torch.equal(pk["gidx2"], torch.cat([rows, BL + torch.arange(BL, device="cuda")]))
+    assert torch.equal(pk["gidx4"], torch.cat([rows, BL + rows]))
+    inv = torch.full((2 * BL,), -1, dtype=torch.int64, device="cuda")
+    inv[rows] = torch.arange(M, device="cuda"); inv[BL:] = M + torch.arange(BL, device="cuda")
+    assert torch.equal(pk["inv"], inv)
+    # a hint that contradicts the mask, a hole in a row, an empty row: the flag goes up and no index leaves the sized ranges
+    for kind in ("short", "hole", "empty"):
+        m2, M2 = mask.clone(), M
+        if kind == "short":
+            M2 = M - 3
+        elif kind == "hole":
+            m2[0, 0] = 0
+        else:
+            m2[1, :] = 0
+        bad.zero_()
+        p2 = ops.pack_plan(m2, M2, bad)
+        assert int(bad) == 1, kind
+        assert int(p2["rows"].min()) >= 0 and int(p2["rows"].max()) < BL and int(p2["gidx4"].max()) < 2 * BL and int(p2["inv"][:BL].max()) < M2
+        assert int(p2["row0"].max()) < M2 and int((p2["row0"] + p2["len"]).max()) <= M2 and int(p2["len"].min()) >= 1
+
+
+@pytest.mark.parametrize("B,Lt,Lp", [(4, 16, 6), (128, 128, 54), (8, 37, 54)])
+def test_fusion_plan_matches_tensor_bookkeeping(ops, B, Lt, Lp):
+    """Every index array of the fusion batch against the torch.cat / index_select construction it replaces; the two shared key / value
+    sources' inverse maps against KVSource.finalize()."""
+    from spmm_amd.engine import KVSource
+    g = torch.Generator().manual_seed(5 * B + Lt)
+    lens = torch.randint(2, Lt + 1, (B,), generator=g); lens[0] = Lt
+    mask = (torch.arange(Lt)[None, :] < lens[:, None]).int().cuda()
+    M, H = int(lens.sum()), 64
+    pk = ops.pack_plan(mask, M, torch.zeros(1, dtype=torch.int32, device="cuda"))
+    neg = torch.randint(0, B, (2 * B,), generator=g).cuda()
+    neg_p, neg_t = neg[:B], neg[B:]
+    fp = ops.fusion_plan(neg, pk, mask, Lp)
+    y1, y2 = rnd(2 * B * Lp, H, seed=1), rnd(M + B * Lt, H, seed=2)
+    X6 = ops.gather_rows2(torch.empty(fp["R6"], H, dtype=BF, device="cuda"), y1, fp["idx6"], y2)
+    pe, pc, te, h10 = y1[:B * Lp].view(B, Lp * H), y1[B * Lp:], y2[:M], y2[M:]
+    ar = torch.arange(B, device="cuda")
+    mask_neg = mask[neg_t]
+    neg_rows = pk["row0_64"][neg_t][:, None] + torch.arange(Lt, device="cuda")[None, :]
+    neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)
+    te_neg = torch.cat([te, torch.zeros(1, H, dtype=BF, device="cuda")])[neg_rows]
+    ref = torch.cat([pe, pe[neg_p], pe], 0).view(-1, H)
+    ref = torch.cat([ref, te, te, te_neg, h10, pc])
+    assert torch.equal(X6, ref)
+    assert torch.equal(fp["neg_rows"], neg_rows) and torch.equal(fp["maskcat"], torch.cat([mask_neg, mask]))
+    i32 = lambda t: t.to(torch.int32)
+    assert torch.equal(fp["ar"], i32(ar)) and torch.equal(fp["kvidx_pv"], i32(torch.cat([ar, ar, neg_t])))
+    assert torch.equal(fp["kvidx_tp"], i32(torch.cat([ar, neg_p]))) and torch.equal(fp["kvidx_td"], i32(torch.cat([ar, ar])))
+    assert torch.equal(fp["kvidx_ctx"], i32(torch.cat([ar, neg_p, ar])))
+    assert torch.equal(fp["qrow0_tp"], torch.cat([pk["row0"], pk["row0"] + M])) and torch.equal(fp["qlen_tp"], torch.cat([pk["len"], pk["len"]]))
+    o_tp = 3 * B * Lp; o_tn = o_tp + 2 * M; o_lm = o_tn + B * Lt
+    assert torch.equal(fp["skv_row0_pv"], i32(torch.arange(3 * B, device="cuda") * Lp)) and bool((fp["skv_len_pv"] == Lp).all())
+    assert torch.equal(fp["skv_row0_tx"], torch.cat([o_tp + pk["row0"], o_tp + M + pk["row0"], i32(o_tn + ar * Lt)]))
+    assert torch.equal(fp["skv_len_tx"], torch.cat([pk["len"], pk["len"], pk["len"][neg_t]]))
+    top = torch.cat([torch.arange(3 * B, device="cuda") * Lp, o_tp + pk["row0_64"], o_tp + M + pk["row0_64"], o_tn + ar * Lt,
+                     o_lm + torch.arange(B * Lt + B * Lp, device="cuda")])
+    assert torch.equal(fp["idx_top"], top)
+    for nm, idx in (("t", torch.cat([ar, ar, neg_t, ar])), ("p", torch.cat([ar, neg_p, ar, ar]))):
+        src = KVSource(None, B, 1)
+        src.add(idx)
+        src.finalize()
+        assert torch.equal(fp["start_" + nm], src.start) and torch.equal(fp["list_" + nm], src.list), nm
+
+
+def test_row_helpers_gather2_add_zero_gelu(ops):
+    H = 128
+    a, b = rnd(50, H, seed=3), rnd(70, H, seed=4)
+    g = torch.Generator().manual_seed(9)
+    ia, ib = torch.randint(0, 50, (40,), generator=g), torch.randint(0, 70, (40,), generator=g)
+    idx = torch.cat([ia, ib + ops.SRC_B, torch.full((7,), -1, dtype=torch.int64)]).cuda()
+    out = ops.gather_rows2(torch.empty(87, H, dtype=BF, device="cuda"), a, idx, b)
+    assert torch.equal(out, torch.cat([a[ia.cuda()], b[ib.cuda()], torch.zeros(7, H, dtype=BF, device="cuda")]))
+    dst, src = rnd(60, H, seed=5), rnd(20, H, seed=6)
+    perm = torch.randperm(60, generator=g)[:20].cuda()
+    ref = dst.clone(); ref[perm] = (ref[perm].float() + src.float()).to(BF)
+    assert torch.equal(ops.add_rows_bf16(dst, perm, src), ref)
+    t = rnd(33, 3 * H, seed=7)
+    keep = t.clone()
+    ops.zero_(t[5:20, H:])
+    keep[5:20, H:] = 0
+    assert torch.equal(t, keep) and float(ops.zero_(rnd(1000, 8, seed=8)).abs().max()) == 0.0
+    dz, pre = rnd(300, H, seed=10), rnd(300, H, seed=11, scale=2.0)
+    x = pre.float()
+    want = dz.float() * (0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327)
+    close(ops.gelu_bwd(dz, pre).float(), want, 2e-2, 1e-2, "gelu_bwd")
+
+
+@pytest.mark.parametrize("nseq,nH,Lmax", [(6, 2, 54), (5, 12, 128), (4, 2, 200)])
+def test_attention_of_position0_queries_over_full_sequences(ops, nseq, nH, Lmax):
+    """The CLS-only top fusion layer's self-attention (engine.SelfKV): one query row per sequence (Lq = 1, dense) against the keys / values
+    of the whole sequence, addressed by kv_row0 / kv_len in another tensor -- equal, bit for bit, to row 0 of the full-sequence launch."""
+    H = nH * 64
+    g = torch.Generator().manual_seed(nseq * Lmax)
+    lens = torch.randint(3, Lmax + 1, (nseq,), generator=g); lens[0] = Lmax
+    row0 = torch.cumsum(lens, 0) - lens
+    M = int(lens.sum())
+    qkv = rnd(M, 3 * H, seed=31)
+    i32 = lambda t: t.to(torch.int32).cuda()
+    lay = dict(q_row0=i32(row0), q_len=i32(lens), kv_row0=i32(row0), kv_len=i32(lens))
+    O = torch.zeros(M, H, dtype=BF, device="cuda"); lse = torch.zeros(nseq, nH, Lmax, device="cuda")
+    kw = dict(nseq=nseq, nH=nH, Lkv=Lmax, causal_from=nseq)
+    ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], O, lse, Lq=Lmax, **kw, **lay)
+    q0 = qkv[row0.cuda(), :H].contiguous()
+    O1 = torch.zeros(nseq, H, dtype=BF, device="cuda"); lse1 = torch.zeros(nseq, nH, 1, device="cuda")
+    ops.attn_fwd(q0, qkv[:, H:2 * H], qkv[:, 2 * H:], O1, lse1, Lq=1, kv_row0=lay["kv_row0"], kv_len=lay["kv_len"], **kw)
+    assert torch.equal(O1, O[row0.cuda()]) and torch.equal(lse1[:, :, 0], lse[:, :, 0])
+    # backward: upstream gradient on position 0 only
+    dO = torch.zeros(M, H, dtype=BF, device="cuda")
+    dO1 = rnd(nseq, H, seed=32)
+    dO[row0.cuda()] = dO1
+    dQKV = torch.zeros(M, 3 * H, dtype=BF, device="cuda")
+    ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], O, lse, dO, dQKV[:, :H], dQKV[:, H:2 * H], dQKV[:, 2 * H:], Lq=Lmax, **kw, **lay)
+    dQ1 = torch.zeros(nseq, H, dtype=BF, device="cuda"); dKV1 = torch.zeros(M, 2 * H, dtype=BF, device="cuda")
+    ops.attn_bwd(q0, qkv[:, H:2 * H], qkv[:, 2 * H:], O1, lse1, dO1, dQ1, dKV1[:, :H], dKV1[:, H:], Lq=1, kv_row0=lay["kv_row0"], kv_len=lay["kv_len"], **kw)
+    assert torch.equal(dQ1, dQKV[row0.cuda(), :H]) and torch.equal(dKV1, dQKV[:, H:])
+    rest = torch.ones(M, dtype=torch.bool, device="cuda"); rest[row0.cuda()] = False
+    assert float(dQKV[rest][:, :H].float().abs().max()) == 0.0        # rows without an upstream gradient get exactly zero
