@@ -74,6 +74,16 @@ const char* spmm_last_error(void);
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
                  void* C2, long ldc2, int epi, float* colsum, int kernel, spmm_stream_t stream);
+/* The output projection in front of a residual LayerNorm with the hidden dropout and the residual in its epilogue:
+ *   C(bf16) = dropout(bf16(A W^T + bias)) + R        BertSelfOutput / BertOutput xbert.py:370-372, 448-450 (up to the LayerNorm)
+ * on the 8-phase kernel, so that spmm_ln_fwd(C, res = NULL, dropout_p = 0) reads one tensor instead of two.  The mask is the one
+ * spmm_ln_fwd / spmm_ln_bwd draw for the same (seed, salt, row, column): spmm_ln_bwd(..., dropout_p, seed, salt) serves it unchanged.
+ * K % 128 == 0, N % 8 == 0; kernel 0 / SPMM_GEMM_AUTO_TILES / 8 / 9.  spmm_gemm_nt_drop_ok: 1 where the automatic choice of spmm_gemm_nt
+ * would take the 8-phase kernel for this shape anyway (callers keep the two-launch form elsewhere). */
+int spmm_gemm_nt_drop_ok(int M, int N, int K);
+int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, const void* R,
+                      long ldr, void* C, long ldc, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int kernel,
+                      spmm_stream_t stream);
 /* Weight-gradient GEMM C[N,K] += alpha * A[M,N]^T . B[M,K] straight from the token-major activations (LDS transpose reads,
  * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
  * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
@@ -235,7 +245,7 @@ int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int
  *   every dense row (-1: padding) for the way back; *bad |= 1 when the mask is not B non-empty prefixes with M tokens in all.
  *  spmm_fusion_plan: index arrays of the fusion batch (layout in csrc/plan.hip) from the sampled negatives neg[2B] (prop | text):
  *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]), maskcat [2B, Lt] key masks of
- *   the dense text group, neg_rows [B Lt] (packed row of every token of a text negative, M = none), idx_top (rows the top fusion layer
+ *   the dense text group, neg_rows [B Lt] (packed row of every token of a text negative, -1 = none), idx_top (rows the top fusion layer
  *   keeps: position 0 of the 6B ITM sequences, every row of the LM and causal-PV passes), small32 [39 B] (sequence -> key/value
  *   source maps, packed row tables, CSR inverse maps of the two shared key/value sources). */
 int spmm_gather_rows2(void* dst, const void* srcA, const void* srcB, const long* idx, long rows, int H, spmm_stream_t stream);

@@ -285,22 +285,49 @@ def _finish_aliases(sd: SD, cfg: SPMMCfg) -> None:
 # accumulation, biases, LayerNorm statistics and affine parameters, softmax sums, the loss heads' arithmetic.  It is the yard-stick
 # that separates "deviation caused by bf16 storage" (shared by this model and the product) from "kernel error" (what is left
 # between them): tests/test_step_gpu.py::test_losses_match_the_bf16_storage_model_of_the_oracle.  Forward only, dropout off.
+# Round 5: `bf16_storage(backward=True)` extends the model to the BACKWARD: the gradient that autograd sends back through one of those
+# storage points is rounded to bf16 too -- the product materialises d(loss)/d(that tensor) as a bf16 tensor between two of its kernels
+# (data-gradient GEMM / LayerNorm-backward / attention-backward outputs), while weight and bias gradients, the hub gradients of the
+# shared key / value sources and all accumulation stay fp32 (engine.py, step.py).  `bf16_storage(fused_sum=True)` models the
+# EngineOptions.fuse_drop_res form: the projection in front of a residual LayerNorm writes the pre-norm sum itself (spmm_gemm_nt_drop), so
+# that sum is a storage point the LayerNorm reads back (`_ln(..., stored_sum=True)`); in the default form the LayerNorm kernel forms the
+# sum in fp32 registers and only its backward copy is rounded.
 _BF16_STORAGE = False
+_BF16_STORAGE_BWD = False
+_BF16_FUSED_SUM = False
 
 
 class bf16_storage:
+    def __init__(self, backward: bool = False, fused_sum: bool = False):
+        self.backward, self.fused_sum = backward, fused_sum
+
     def __enter__(self):
-        global _BF16_STORAGE
-        self._old, _BF16_STORAGE = _BF16_STORAGE, True
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM
+        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM), True
+        _BF16_STORAGE_BWD, _BF16_FUSED_SUM = self.backward, self.fused_sum
 
     def __exit__(self, *exc):
-        global _BF16_STORAGE
-        _BF16_STORAGE = self._old
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM
+        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM = self._old
+
+
+class _RoundBothWays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
 
 
 def _st(x: Tensor) -> Tensor:
     """A tensor as the product holds it in HBM."""
-    return x.to(torch.bfloat16).to(torch.float32) if _BF16_STORAGE else x
+    if not _BF16_STORAGE:
+        return x
+    if _BF16_STORAGE_BWD and x.requires_grad:
+        return _RoundBothWays.apply(x)
+    return x.to(torch.bfloat16).to(torch.float32)
 
 
 # ------------------------------------------------------------------------ xbert.py
@@ -314,7 +341,10 @@ def _lin(sd: SD, p: str, x: Tensor, act=None, f32_out: bool = False, f32_w: bool
     return y if f32_out else _st(y)
 
 
-def _ln(sd: SD, p: str, x: Tensor, eps: float) -> Tensor:
+def _ln(sd: SD, p: str, x: Tensor, eps: float, stored_sum: bool = False) -> Tensor:
+    """stored_sum: x is the pre-norm sum dropout(dense(.)) + residual, which the product writes to HBM (bf16) before the LayerNorm reads it."""
+    if stored_sum and _BF16_FUSED_SUM:
+        x = _st(x)
     return _st(F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps))
 
 
@@ -373,7 +403,7 @@ def attention(sd: SD, p: str, c: BertCfg, hidden: Tensor, add_mask: Tensor,
         pr = _drop(torch.softmax(s, dim=-1), c.attention_probs_dropout_prob, train)
         ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
     out = _drop(_lin(sd, p + ".output.dense", ctx), c.hidden_dropout_prob, train)
-    return _ln(sd, p + ".output.LayerNorm", out + hidden, c.layer_norm_eps)
+    return _ln(sd, p + ".output.LayerNorm", out + hidden, c.layer_norm_eps, stored_sum=True)
 
 
 def bert_layer(sd: SD, p: str, c: BertCfg, i: int, has_cross: bool, hidden, self_mask,
@@ -386,7 +416,7 @@ def bert_layer(sd: SD, p: str, c: BertCfg, i: int, has_cross: bool, hidden, self
         a = attention(sd, lp + "crossattention", c, a, enc_mask, enc, train)
     h = _lin(sd, lp + "intermediate.dense", a, act=F.gelu)                   # :434-437 erf GELU
     o = _drop(_lin(sd, lp + "output.dense", h), c.hidden_dropout_prob, train)  # :447-451
-    return _ln(sd, lp + "output.LayerNorm", o + a, c.layer_norm_eps)
+    return _ln(sd, lp + "output.LayerNorm", o + a, c.layer_norm_eps, stored_sum=True)
 
 
 def bert_model(sd: SD, p: str, c: BertCfg, has_cross: bool, *, input_ids=None, inputs_embeds=None,

@@ -55,6 +55,19 @@ class _Lib:
 
 
 _lib = None
+_device = None
+
+
+def bind_device(index: int) -> None:
+    """One GPU per process (the launch model of the package: one process per GPU under torch.distributed).  The kernels' dynamic-LDS
+    opt-ins (hipFuncSetAttribute) are made once per process, on the device current at that moment; a second device in the same process
+    would launch the 128-KiB GEMM and the large attention kernels without them.  Called by every Engine; raises on a second device."""
+    global _device
+    if _device is None:
+        _device = int(index)
+    elif _device != int(index):
+        raise RuntimeError(f"spmm_amd: this process already runs on cuda:{_device}; a second device (cuda:{index}) needs its own process "
+                           "(kernel attributes are set once per process, spmm_amd/_lib.py::bind_device)")
 
 
 def lib() -> _Lib:

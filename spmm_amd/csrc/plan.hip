@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void fusion_plan_kernel(const long* __restrict
   }
   for (long w = g0; w < BLt; w += gsz) {
     const long s = w / Lt, l = w - s * Lt, n = neg_t[s];
-    neg_rows[w] = l < lens[n] ? row0[n] + l : M;
+    neg_rows[w] = l < lens[n] ? row0[n] + l : -1;
   }
   // top layer: rows of the layer input it keeps -- position 0 of the 6B ITM sequences, then every row of the LM and causal-PV passes
   for (long w = g0; w < 6l * B + BLt + BLp; w += gsz) {

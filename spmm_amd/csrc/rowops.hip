@@ -615,7 +615,7 @@ __global__ void cast_bf16_f32_kernel(const bf16* __restrict__ in, float* __restr
   }
 }
 
-// dst_f32[row_idx[r] or r] (+)= src_bf16[r]   (row length H, 4-element vectors)
+// dst_f32[row_idx[r] or r] (+)= src_bf16[r]   (row length H, 4-element vectors; rows with a negative index are skipped)
 __global__ void acc_rows_kernel(float* __restrict__ dst, long ldd, const bf16* __restrict__ src, long lds,
                                 const long* __restrict__ idx, long rows, int H, int atomic) {
   const int h4 = H / 4;
@@ -623,6 +623,7 @@ __global__ void acc_rows_kernel(float* __restrict__ dst, long ldd, const bf16* _
     const long r = i / h4;
     const int c = (int)(i - r * h4) * 4;
     const long dr = idx ? idx[r] : r;
+    if (dr < 0) continue;                      // a source row nobody owns (rows past a text negative's length)
     const bf16x4 v = *(const bf16x4*)(src + r * lds + c);
     float* d = dst + dr * ldd + c;
     if (atomic) {

@@ -319,13 +319,18 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
     if cached is None:
         cached = hasattr(model, "engine")
     if graph is None:
-        graph = bool(cached and not stochastic and props.shape[0] * k < GRAPH_BELOW_ROWS)
+        # Replay is OPT-IN (graph=True) since round 5: every call re-captures its ~130 kernels (a graph is tied to this call's buffers), capture
+        # is process-global on the capture stream's device -- another thread touching the GPU meanwhile aborts it -- and a replayed graph
+        # cannot drop finished molecules (`compact`).  It gains 7 % at 100 beam rows and nothing from 500 on (GRAPH_BELOW_ROWS).
+        graph = False
     prop_embeds = encode_properties(model, props, prop_mask)
     N, dev = prop_embeds.shape[0], prop_embeds.device
     if cached:
         model.engine.train_mode = False
     dec = (CachedDecoder if cached else RecomputeDecoder)(model, prop_embeds, k, max_steps + 3)
-    fused = bool(cached and not stochastic and k <= 8 and FUSED_BEAM_STEP)      # one launch per position for the beam bookkeeping (csrc/decode.hip)
+    # one launch per position for the beam bookkeeping (csrc/decode.hip::beam_step_kernel: k <= 8 beams, vocabulary <= 512, histories <= 256
+    # tokens -- the tensor-op bookkeeping serves everything else)
+    fused = bool(cached and not stochastic and k <= 8 and FUSED_BEAM_STEP and model.cfg.text.vocab_size <= 512 and max_steps + 3 <= 256)
     book = BeamBook(N, k, max_steps, dev, fused=fused)
     ids = torch.full((N * k,), CLS_ID, dtype=torch.long, device=dev)
     logits = dec.step(ids, 0).view(N, k, -1)[:, 0]                       # all k rows hold the same [CLS] prefix
@@ -348,10 +353,12 @@ def beam_search_batched(model, props: torch.Tensor, k: int = 5, max_steps: int =
         if s % sync_every == sync_every - 1:
             if not fused:
                 if book.all_done():
+                    last_run["positions"] = s + 1
                     break
                 continue
             n_live = N - int(book.n_done.item())         # the one host read of the loop
             if n_live == 0:
+                last_run["positions"] = s + 1
                 break
             if compact:
                 # molecules that hold their k finals stop costing anything: once a quarter of the batch is done the rest is gathered into
@@ -423,7 +430,7 @@ def _decode_graphed(dec: "CachedDecoder", book: BeamBook, ids: torch.Tensor, N: 
     if steps_left > 0 and not book.all_done():
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads' GPU work does not abort this capture
             one_position()
         g.replay()                                               # capture records, it does not execute: this is position `eager`
         for s in range(1, steps_left):

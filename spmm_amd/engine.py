@@ -129,6 +129,9 @@ class Engine:
     def __init__(self, cfg: SPMMConfig, params: ParamStore, device, options: Optional[EngineOptions] = None):
         self.cfg, self.P, self.dev = cfg, params, device
         self.opt = options if options is not None else EngineOptions.from_env()
+        if torch.device(device).type == "cuda":
+            from ._lib import bind_device
+            bind_device(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
         f32 = dict(dtype=torch.float32, device=device)
         self.alpha = torch.zeros(1, **f32)
         self.lr = torch.zeros(1, **f32)
@@ -284,6 +287,24 @@ class Engine:
         ops.ln_fwd_r32(x, X32, gamma, beta, y, y32=y32, **kw)
         return y32
 
+    def _proj_ln(self, A, Wb, bias, resid, X32, gamma, beta, *, save, eps, ph):
+        """y = LayerNorm(dropout(A W^T + b) + resid): BertSelfOutput / BertOutput (xbert.py:369-373, 447-451).
+        Where the projection runs on the 8-phase kernel, dropout and residual sit in ITS epilogue (spmm_gemm_nt_drop) and the LayerNorm
+        reads one tensor -- the pre-norm sum z it would otherwise have written itself; elsewhere (small M, fp32 residual stream) the
+        two-launch form.  Same dropout mask either way: spmm_ln_bwd regenerates it from (seed, salt).  -> (y, z, mean, rstd, salt, y32)"""
+        M, H = A.shape[0], Wb.shape[0]
+        x, y = self._new(M, H), self._new(M, H)
+        mean = self._new(M, dtype=torch.float32) if save else None
+        rstd = self._new(M, dtype=torch.float32) if save else None
+        salt = self._next_salt()
+        if X32 is None and self.opt.fuse_drop_res and ops.gemm_nt_drop_ok(M, H, A.shape[1]):
+            ops.gemm_nt_drop(A, Wb, x, bias=bias, R=resid, dropout_p=ph, seed=self.seed, salt=salt)
+            ops.ln_fwd(x, None, gamma, beta, y, mean=mean, rstd=rstd, eps=eps)
+            return y, x, mean, rstd, salt, None
+        ops.gemm_nt(A, Wb, x, bias=bias)
+        y32 = self._ln_res(x, resid, X32, gamma, beta, y, zout=x if save else None, mean=mean, rstd=rstd, eps=eps, dropout_p=ph, seed=self.seed, salt=salt)
+        return y, x, mean, rstd, salt, y32
+
     def _attn_block_fwd(self, pfx, c, X, groups, save, cross, X32=None):
         """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source.
         -> (y, tape entry, fp32 twin of y or None)."""
@@ -383,14 +404,9 @@ class Engine:
             if fused:
                 sv.update(ctx=ctx, z=z, mean=mean, rstd=rstd, salt_h=salt_h)
                 return y, (sv if save else None), None
-        x = self._new(M, H)
-        ops.gemm_nt(ctx, P.wb(pfx + ".output.dense.weight"), x, bias=P.w(pfx + ".output.dense.bias"))
-        y = self._new(M, H)
-        mean = self._new(M, dtype=torch.float32) if save else None
-        rstd = self._new(M, dtype=torch.float32) if save else None
-        salt = self._next_salt()
-        y32 = self._ln_res(x, X, X32, P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y, zout=x if save else None,
-                           mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt)
+        y, x, mean, rstd, salt, y32 = self._proj_ln(ctx, P.wb(pfx + ".output.dense.weight"), P.w(pfx + ".output.dense.bias"), X, X32,
+                                                    P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), save=save,
+                                                    eps=c.layer_norm_eps, ph=ph)
         sv.update(ctx=ctx, z=x, mean=mean, rstd=rstd, salt_h=salt)
         return y, (sv if save else None), y32
 
@@ -484,8 +500,9 @@ class Engine:
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
         u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN and H % 128 == 0 and I % 128 == 0     # (the 8-phase kernel's shapes)
         dact = (self._new(M, I, dtype=torch.uint8) if u8 else self._new(M, I)) if save else None
-        x = self._new(M, H)
-        if self.fp8 and H % 256 == 0 and I % 256 == 0:
+        fp8 = self.fp8 and H % 256 == 0 and I % 256 == 0
+        x = self._new(M, H) if fp8 else None
+        if fp8:
             # fp8 tier (BASELINE configs[4]): both FFN GEMMs of the forward read E4M3 operands with per-row scales (activations
             # quantised per token, weights per output channel) and accumulate in fp32; the backward stays bf16 on the saved bf16
             # activations (straight-through).  K = I for the second GEMM is where the 2x MFMA rate shows (tools/gemm_bench f8time).
@@ -498,13 +515,17 @@ class Engine:
         else:
             ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"),
                         epi=(ops.EPI_GELU_DERIV8 if u8 else ops.EPI_GELU_DERIV) if save else ops.EPI_GELU, C2=dact)
-            ops.gemm_nt(h, P.wb(lp + "output.dense.weight"), x, bias=P.w(lp + "output.dense.bias"))
-        y = self._new(M, H)
-        mean = self._new(M, dtype=torch.float32) if save else None
-        rstd = self._new(M, dtype=torch.float32) if save else None
-        salt = self._next_salt()
-        y32 = self._ln_res(x, a, a32, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
-                           mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
+        if fp8:
+            y = self._new(M, H)
+            mean = self._new(M, dtype=torch.float32) if save else None
+            rstd = self._new(M, dtype=torch.float32) if save else None
+            salt = self._next_salt()
+            y32 = self._ln_res(x, a, a32, P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), y, zout=x if save else None,
+                               mean=mean, rstd=rstd, eps=c.layer_norm_eps, dropout_p=self._p_hidden(c), seed=self.seed, salt=salt)
+        else:
+            y, x, mean, rstd, salt, y32 = self._proj_ln(h, P.wb(lp + "output.dense.weight"), P.w(lp + "output.dense.bias"), a, a32,
+                                                        P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), save=save,
+                                                        eps=c.layer_norm_eps, ph=self._p_hidden(c))
         sv = dict(att=sv1, cross=sv2, a=a, h=h, dact=dact, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
         return y, sv, y32
 

@@ -58,7 +58,7 @@ class _FusedAdamW:
         self.scalars = torch.zeros(ops.adam_scalars_bytes() // 4, device=dev)
 
     def zero_grad(self, set_to_none: bool = False):
-        self.store.grad.zero_()
+        ops.zero_(self.store.grad)
 
     def step(self, fill_lr: bool = True):
         g = self.param_groups[0]
@@ -333,7 +333,7 @@ class SPMM(_Base):
         check = self._schedule_check_begin(grad_sync)
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
-        self.store.grad.zero_()
+        ops.zero_(self.store.grad)
         dev = self.device_
         losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn(),
                              n_tokens=n_tokens)
@@ -473,7 +473,7 @@ class SPMM(_Base):
     def _step_body(self, prop, ids, mask, mpm_mask, neg_idx):
         """zero_grad -> forward -> backward -> clip -> AdamW on device-resident scalars only (what a hipGraph can hold)."""
         eng, opt = self.engine, self.optimizers()
-        self.store.grad.zero_()
+        ops.zero_(self.store.grad)
         losses = eng.forward(prop, ids, mask, mpm_mask=mpm_mask, neg_idx=neg_idx, gather=None)
         eng.backward()
         opt.step(fill_lr=False)

@@ -14,6 +14,7 @@ from dataclasses import dataclass
 _ENV = {
     "pack_text": ("SPMM_PACK_TEXT", lambda s: s != "0"),
     "cls_only_top": ("SPMM_CLS_ONLY_TOP", lambda s: s != "0"),
+    "fuse_drop_res": ("SPMM_FUSE_DROP_RES", lambda s: s == "1"),
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
     "fp8": ("SPMM_FP8", lambda s: s == "1"),
@@ -35,6 +36,11 @@ class EngineOptions:
     pack_text: bool = True        # drop padding-token rows from the text passes whose losses read only position 0
     cls_only_top: bool = True     # last fusion layer of the ITM passes on position 0 only (what the ITM head reads, SPMM_models.py:199-201); their other
     #                               rows stay keys / values of its self-attention.  Packed path only; exact
+    fuse_drop_res: bool = False   # hidden dropout + residual of BertSelfOutput / BertOutput inside the projection GEMM's epilogue (spmm_gemm_nt_drop):
+    #                               the LayerNorm behind it reads one tensor instead of two (LayerNorm forward 2.4 -> 1.4 ms per step, the
+    #                               step 54.6 -> 54.3 ms).  OFF: the LayerNorm then starts from the bf16-ROUNDED pre-norm sum, one more rounding
+    #                               per sublayer on the residual stream -- loss_itm deviates 2.6e-3 from the fp32 oracle at the benchmark shape
+    #                               instead of 1.3e-3, loss_ita 4.8e-3 instead of 3.6e-3 (EXPERIMENTS.md 3.4)
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
     gelu_deriv_u8: bool = False   # gelu'(x) kept for the FFN backward as 8-bit codes instead of bf16 (half the bytes written and re-read;

@@ -427,7 +427,7 @@ class PretrainStep(Engine):
             ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
             ops.acc_rows(d_te[:M], dXt[:M])
             ops.acc_rows(d_te[:M], dXt[M:2 * M])
-            ops.acc_rows(d_te, dXt[2 * M:2 * M + B * Lt], idx=S6["fp"]["neg_rows"], atomic=True)   # rows past a negative's length -> dump row
+            ops.acc_rows(d_te, dXt[2 * M:2 * M + B * Lt], idx=S6["fp"]["neg_rows"], atomic=True)   # (rows past a negative's length: skipped)
             dXt_lm, dX12 = dX6[S6["o_lm"]:S6["o_12"]], dX6[S6["o_12"]:]
         else:
             ditm = self._new(3 * B, H)
@@ -444,7 +444,8 @@ class PretrainStep(Engine):
             if pk:
                 ops.acc_rows(d_te[:M], dXt[:M])
                 ops.acc_rows(d_te[:M], dXt[M:2 * M])
-                ops.acc_rows(d_te, dXt[2 * M:2 * M + T["Mn"]], idx=T["neg_rows"], atomic=True)    # dense variant: rows past a negative's length -> dump row
+                nr = T["neg_rows"]                                 # (rows past a negative's length: skipped)
+                ops.acc_rows(d_te, dXt[2 * M:2 * M + T["Mn"]], idx=torch.where(nr < M, nr, torch.full_like(nr, -1)), atomic=True)
             else:
                 dte, dxt = d_te[:M].view(B, Lt * H), dXt.view(4 * B, Lt * H)
                 ops.acc_rows(dte, dxt[0:B])

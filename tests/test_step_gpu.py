@@ -33,6 +33,15 @@ LOSS_ATOL = {
     "grad_tiny":     [1e-3, 2.9e-3, 1.3e-3, 1e-3],      # measured 2.5e-4 / 1.9e-3 / 8.2e-4 / 4.0e-4
 }
 
+# product vs `oracle.bf16_storage(backward=True)`: (whole-gradient relative L2, worst family relative L2, worst ranked tensor) -- 1.5 x the measured
+# 2.1e-3 / 2.9e-3 / 6.3e-3 (h768_2layer) and 2.2e-3 / 2.6e-3 / 9.5e-3 (bench shape; profiles/r05_gradient_parity.txt); against the fp32 oracle the
+# same gradients sit at 5.3e-3 / 6.1e-3.  See test_gradients_match_the_bf16_storage_model_of_the_oracle.
+GRAD_VS_STORAGE_MODEL = {"h768_2layer": (3.5e-3, 4.5e-3, 1e-2), "bench_shape": (3.5e-3, 4.5e-3, 1.5e-2)}
+# test_training_trace_vs_reference: per step (absolute loss tolerance, relative gradient-norm tolerance) for the bf16 / fp32 residual stream.
+# Measured worst loss deviation per step 9.2e-4 / 3.5e-3 / 1.3e-2 (bf16) and 5.4e-4 / 5.8e-3 / 1.25e-2 (fp32 stream), gradient norm
+# 2e-4 / 8e-4 / 2.2e-2 and 1e-4 / 9e-4 / 2.0e-2: the third step of this toy run (closed-form weights, lr 1e-3) amplifies whatever the first two left.
+TRACE_TOL = {False: ([1.5e-3, 6e-3, 2e-2], [1e-3, 2e-3, 3.3e-2]), True: ([1.5e-3, 9e-3, 2e-2], [1e-3, 2e-3, 3.3e-2])}
+
 
 def assert_losses(got, ref, key, what=""):
     got, ref, tol = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64), np.asarray(LOSS_ATOL[key])
@@ -290,6 +299,34 @@ def test_fused_cross_attention_inside_the_step(env):
     assert_losses(got, ref, "h768_2layer")
 
 
+def test_dropout_and_residual_in_the_projection_epilogue_inside_the_step(env):
+    """EngineOptions.fuse_drop_res (off by default): hidden dropout + residual of BertSelfOutput / BertOutput inside the projection GEMM's
+    epilogue wherever that GEMM runs on the 8-phase kernel (spmm_gemm_nt_drop), the LayerNorm reading the stored pre-norm sum.  H = 768, 2+2
+    layers, B = 64, Lt = 128, train mode with dropout, same seed -> the same masks in both forms.  The only difference is that the LayerNorm
+    starts from the bf16-rounded sum: losses within 5e-3, whole gradient within 1.5e-2 relative L2 of the two-launch form."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd.options import EngineOptions
+    cfg, ocfg = _mid_cfg(env)
+    sd = O.init_state_dict(ocfg, seed=3)
+    B, Lt = 64, 128                      # (the fusion batch and the text batch then have > 8 192 rows: their projections run on the 8-phase kernel)
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=23)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(1))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
+    res = {}
+    for fused in (False, True):
+        m = SPMM(config=None, spmm_config=cfg, options=EngineOptions.from_env(fuse_drop_res=fused))
+        m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+        m.train()
+        m.engine.seed.fill_(4242)
+        losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+        sum(losses).backward()
+        res[fused] = (np.array([float(x) for x in losses]), m.store.grad.detach().clone())
+    rel = ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item()
+    print(f"dropout + residual in the GEMM epilogue: losses {res[True][0]} vs {res[False][0]}, whole-gradient relative L2 difference {rel:.3g}")
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=5e-3)
+    assert rel > 1e-5 and rel < 1.5e-2                       # (the fused form really ran)
+
+
 def test_gelu_derivative_as_8bit_codes_inside_the_step(env):
     """EngineOptions.gelu_deriv_u8 inside the real step (H = 768, 2+2 layers, train mode with dropout, same seed).  The forward computes the
     same function (the option pins the FFN-up GEMM to the 8-phase kernel, so at this small M the accumulation order -- and with it a few
@@ -400,6 +437,100 @@ def test_losses_match_the_bf16_storage_model_of_the_oracle(env, shape):
     assert (np.abs(got - ref16) <= np.array([1e-3, 1e-3, 1.6e-3, 1e-3])).all(), (got, ref16)
 
 
+GRAD_FAMILIES = (("embeddings", "embeddings."), ("self-attention q/k/v", ".attention.self."), ("self-attention output", ".attention.output."),
+                 ("cross-attention q/k/v", ".crossattention.self."), ("cross-attention output", ".crossattention.output."),
+                 ("FFN up", ".intermediate."), ("FFN down + LayerNorm", ".output."), ("heads and projections", ""))
+
+
+@pytest.mark.parametrize("shape", ["h768_2layer", "bench_shape"])
+def test_gradients_match_the_bf16_storage_model_of_the_oracle(env, shape):
+    """The backward against the storage model (round 5: `oracle.bf16_storage(backward=True)` also rounds the gradient flowing back through
+    every bf16 storage point, as the product's bf16 dX tensors do; weight / bias gradients and their accumulation stay fp32 on both sides).
+    Asserted: relative L2 error of the WHOLE gradient, and per parameter family (embeddings, q/k/v, attention outputs, FFN, heads) the
+    family's own relative L2 error and its worst tensor.  Dropout off, recorded draws, the published widths at 2+2 layers and the
+    benchmark shape (12+6 layers, B = 32, Lt = 128, queue 36 864).  The same numbers against the fp32 oracle are printed beside them."""
+    O, SPMM, *_ = env
+    if shape == "bench_shape":
+        cfg, ocfg = _mid_cfg(env, layers=(12, 6, 6), Q=36864)
+        seed, (B, Lt), neg_roll = 13, (32, 128), (1, 7)
+    else:
+        cfg, ocfg = _mid_cfg(env)
+        seed, (B, Lt), neg_roll = 3, (8, 40), (3, 5)
+    for c in (ocfg.text, ocfg.prop, cfg.text, cfg.prop):
+        c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=42)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(6))
+    neg = (torch.arange(B).roll(neg_roll[0]), torch.arange(B).roll(neg_roll[1]))
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    sd0 = O.init_state_dict(ocfg, seed=seed)
+    m = _mk(SPMM, cfg, sd0).train()
+    sum(m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))).backward()
+    names = O.trainable_names(ocfg)
+    hip = {n: m.store.g(n).detach().float().cpu() for n in names}
+    del m
+    torch.cuda.empty_cache()
+    res = {}
+    for model in ("bf16 storage model", "fp32 oracle"):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for n in names:
+            sd[n].requires_grad_(True)
+        O._finish_tied(sd)
+        if model == "fp32 oracle":
+            sum(O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, train=True)).backward()
+        else:
+            with O.bf16_storage(backward=True):
+                sum(O.spmm_forward(sd, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, train=True)).backward()
+        tot = sum(float((sd[n].grad.double() ** 2).sum()) for n in names if sd[n].grad is not None) ** 0.5
+        fam = {f: [0.0, 0.0, 0.0, ""] for f, _ in GRAD_FAMILIES}           # err^2, ref^2, worst per-tensor relative error, its name
+        err2 = 0.0
+        for n in names:
+            rg = sd[n].grad
+            if rg is None:
+                assert float(hip[n].abs().max()) == 0, n
+                continue
+            e, r = float((hip[n].reshape(rg.shape) - rg).norm()), float(rg.norm())
+            err2 += e * e
+            f = next(f for f, key in GRAD_FAMILIES if key in n)
+            fam[f][0] += e * e; fam[f][1] += r * r
+            if r > 5e-4 * tot and e / r > fam[f][2]:                       # (tensors below the summation-noise floor are not ranked)
+                fam[f][2], fam[f][3] = e / r, n
+        res[model] = (err2 ** 0.5 / tot, {f: ((v[0] / max(v[1], 1e-30)) ** 0.5, v[2], v[3]) for f, v in fam.items()})
+        print(f"{shape}: product vs {model}: whole gradient |g| = {tot:.4f}, relative L2 error {res[model][0]:.5f}")
+        for f, (rel, worst, wn) in res[model][1].items():
+            print(f"    {f:26s} family rel L2 {rel:.5f}   worst tensor {worst:.4f}  {wn}")
+        del sd
+    glob, fams = res["bf16 storage model"]
+    # stated bounds against the storage model (1.5 x the measured values, profiles/r05_gradient_parity.txt): the product's remaining
+    # distance is fp32 accumulation order and the roundings that flip with it
+    assert glob < GRAD_VS_STORAGE_MODEL[shape][0], glob
+    for f, (rel, worst, wn) in fams.items():
+        assert rel < GRAD_VS_STORAGE_MODEL[shape][1] and worst < GRAD_VS_STORAGE_MODEL[shape][2], (f, rel, worst, wn)
+    assert glob <= 1.05 * res["fp32 oracle"][0] + 1e-4          # and it is the better predictor of the product than the fp32 oracle
+
+
+def test_full_benchmark_batch_against_the_oracle_and_its_storage_model(env):
+    """The FULL benchmark batch (B = 128, Lt = 128, 12+6 layers, queue 36 864; round 4's one-off tools/parity_b128.py as a test): the four
+    losses against the fp32 oracle (the bf16 pipeline's stated deviation, LOSS_ATOL['bench_shape']) and against the oracle's bf16 storage
+    model (1e-3 on three losses, 2.1e-3 on the property loss; measured 2.4e-5 / 1.39e-3 / 2.2e-4 / 1.4e-4, profiles/r05_gradient_parity.txt).  ~2 minutes of host time."""
+    O, SPMM, *_ = env
+    cfg, ocfg = _mid_cfg(env, layers=(12, 6, 6), Q=36864)
+    sd = O.init_state_dict(ocfg, seed=13)
+    B, Lt = 128, 128
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=42)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(6))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(7))
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    m = _mk(SPMM, cfg, sd).eval()
+    with torch.no_grad():
+        got = np.array([float(x) for x in m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))])
+        ref32 = np.array([float(x) for x in O.spmm_forward({k: v.clone() for k, v in sd.items()}, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)])
+        with O.bf16_storage():
+            ref16 = np.array([float(x) for x in O.spmm_forward({k: v.clone() for k, v in sd.items()}, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)])
+    print(f"B = 128: hip {got}\n  |hip - fp32 oracle| {np.abs(got - ref32)}\n  |hip - bf16 storage model| {np.abs(got - ref16)}\n  |storage model - fp32| {np.abs(ref16 - ref32)}")
+    assert_losses(got, ref32, "bench_shape")
+    assert (np.abs(got - ref16) <= np.array([1e-3, 2.1e-3, 1e-3, 1e-3])).all(), (got, ref16)
+
+
 def test_fp32_residual_stream_at_the_benchmark_shape(env):
     """EngineOptions.resid_fp32: the residual stream in fp32 through every LayerNorm (fp32 twin of each hidden state),
     fp32 inputs to the ITM / MPM heads and the feature projections -- measured at the benchmark shape (12+6 layers, H=768, B=32,
@@ -481,9 +612,13 @@ def test_gradients_match_oracle(env):
         assert err <= max(6e-2 * nrm, 5e-4 * total_r), (n, rel, err, nrm)
 
 
-def test_training_trace_vs_reference(env, golden_dir):
-    """First three steps of the reference's recorded AdamW/clip/scheduler trace (later steps of that toy run are chaotic)."""
+@pytest.mark.parametrize("resid_fp32", [False, True])
+def test_training_trace_vs_reference(env, golden_dir, resid_fp32):
+    """First three steps of the reference's recorded AdamW/clip/scheduler trace (later steps of that toy run are chaotic: closed-form
+    weights, lr 1e-3, Adam's sign-like first updates).  Run in the default bf16 residual stream and with EngineOptions.resid_fp32 (fp32
+    residual stream through the LayerNorms; the backward is the same bf16 one); TRACE_TOL holds the bounds of both."""
     O, SPMM, tiny_config, *_ = env
+    from spmm_amd.options import EngineOptions
     g = np.load(os.path.join(golden_dir, "train_tiny_b4_l16.npz"))
     cfg = tiny_config()
     for c in (cfg.text, cfg.prop):
@@ -492,10 +627,11 @@ def test_training_trace_vs_reference(env, golden_dir):
              'warmup_epochs': 2, 'cooldown_epochs': 0}
     tc = {'embed_dim': 64, 'temp': 0.07, 'queue_size': 16, 'momentum': 0.995, 'alpha': 0.4, 'schedular': sched,
           'optimizer': {'opt': 'adamW', 'lr': 1e-3, 'weight_decay': 0.02}}
-    m = SPMM(config=tc, spmm_config=cfg, loader_len=int(g["loader_len"]))
+    m = SPMM(config=tc, spmm_config=cfg, loader_len=int(g["loader_len"]), options=EngineOptions.from_env(resid_fp32=resid_fp32))
     m.load_state_dict(O.closed_form_state_dict(O.tiny_cfg()))
     m.train()
     opt = m.optimizers()
+    loss_tol, gn_tol = TRACE_TOL[resid_fp32]
     B, Lt, seed = int(g["B"]), int(g["Lt"]), int(g["seed"])
     for s, (epoch, bidx) in enumerate(g["plan"][:3]):
         prop, ids, mask = O.synthetic_batch(B, Lt, seed=seed + s)
@@ -513,10 +649,11 @@ def test_training_trace_vs_reference(env, golden_dir):
             opt.param_groups[0]["lr"] = m.lr_schedulers().lr_at(int(bidx) // step_size)
         got = losses.cpu().numpy()
         gn = float(opt.grad_norm)
-        print(f"step {s}: hip {got} ref {g['losses'][s]}  grad-norm hip {gn:.3f} ref {g['grad_norm'][s]:.3f}")
+        print(f"resid_fp32={resid_fp32} step {s}: hip {got} ref {g['losses'][s]} |diff| {np.abs(got - g['losses'][s])}  grad-norm hip {gn:.3f} ref {g['grad_norm'][s]:.3f} "
+              f"({abs(gn / g['grad_norm'][s] - 1):.4f})")
         assert abs(lr_used - g["lr_used"][s]) < 1e-12 and abs(opt.param_groups[0]["lr"] - g["lr_next"][s]) < 1e-12
-        np.testing.assert_allclose(got, g["losses"][s], rtol=0, atol=[2e-2, 6e-2, 0.15][s])
-        np.testing.assert_allclose(gn, g["grad_norm"][s], rtol=[3e-2, 8e-2, 0.2][s])
+        np.testing.assert_allclose(got, g["losses"][s], rtol=0, atol=loss_tol[s])
+        np.testing.assert_allclose(gn, g["grad_norm"][s], rtol=gn_tol[s])
         assert int(m.queue_ptr) == int(g["ptr"][s])
         np.testing.assert_allclose(float(m.temp), g["temp"][s], atol=2e-4 * (s + 1))
 
@@ -936,6 +1073,40 @@ def test_decode_at_published_widths(env):
             assert abs(got[n][0][0] - ref[n][0][0]) < 0.15, (n, got[n][0], ref[n][0])
             for p, seq in got[n]:
                 assert seq[0] == decode.CLS_ID and seq[-1] == decode.SEP_ID and p <= 0.0
+
+
+def test_batched_decode_against_the_reference_search_at_the_published_size(env, golden_dir):
+    """BASELINE configs[3] at its published size -- H = 768, 12 text layers (fusion at 6), 6 PV layers -- against the REAL reference's search
+    (tests/golden/decode_wide768_k5.npz by oracle/make_golden_decode_wide.py: d_pv2smiles_batched.py:18-59 / d_pv2smiles_single.py:26-44 run in
+    the dev container on `init_state_dict(full_cfg(), seed=0)`, one LM-head bias per molecule, k = 5, the reference's 100 steps; hypotheses of
+    2 ... 35 tokens and one search that finishes nothing).  The model is built once; only the LM-head bias changes between molecules.  The best
+    hypothesis must be the reference's token for token (bf16 activations may flip a near-tie: at most one of the eight may differ), and a
+    search the reference leaves empty must stay empty."""
+    O, SPMM, tiny_config, SPMMConfig, BertConfig = env
+    from spmm_amd import decode
+    g = np.load(os.path.join(golden_dir, "decode_wide768_k5.npz"), allow_pickle=False)
+    props, k = torch.from_numpy(g["props"]), int(g["k"])
+    ocfg = O.full_cfg()
+    cfg = SPMMConfig(text=BertConfig(num_hidden_layers=12, fusion_layer=6, add_cross_attention=True),
+                     prop=BertConfig(num_hidden_layers=6, fusion_layer=6, vocab_size=1), embed_dim=256, queue_size=ocfg.queue_size)
+    m = SPMM(config=None, spmm_config=cfg, no_train=True)
+    m.load_state_dict({kk: v.detach().clone() for kk, v in O.init_state_dict(ocfg, seed=int(g["init_seed"])).items()})
+    m.eval()
+    same, diff = 0, []
+    for n in range(props.shape[0]):
+        gen = torch.Generator().manual_seed(int(g["bias_seed"][n]))
+        b = torch.randn(300, generator=gen) * 1.5
+        b[3] = b.max() - float(g["sep_gap"][n])
+        m.store.w("text_encoder.cls.predictions.bias").copy_(b.to(m.device))
+        m.store.refresh_shadows()
+        got = decode.beam_search_batched(m, props[n:n + 1], k=k, max_steps=100)[0]
+        want = g["best_ids"][n, :int(g["best_len"][n])].tolist()
+        ok = (got == []) if not want else (bool(got) and got[0][1][:-1] == want and got[0][1][-1] == decode.SEP_ID)
+        same += int(ok)
+        if not ok:
+            diff.append((n, want, got[0][1] if got else None))
+    print(f"batched HIP decode vs the reference's search at H=768 / 12+6 layers: {same} / {props.shape[0]} best hypotheses identical; differing: {diff}")
+    assert same >= props.shape[0] - 1, diff
 
 
 def test_smiles_to_pv_matches_oracle(env):
