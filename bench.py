@@ -119,6 +119,16 @@ def cls_top_saving(B, Lt, n_valid, Lp=54, H=768, I=3072):
     return 3 * (gemm + core)
 
 
+def neg_pack_saving(B, Lt, n_valid, Lp=54, H=768, I=3072, n_text=12, fusion=6):
+    """FLOPs not executed because the text hard negatives re-enter the fusion layers as PACKED query rows (their total length is device
+    data: the launches over the batch take their row count from device memory, spmm_amd/step.py::_s6_forward_cls) instead of a dense
+    [B, Lt] block with zero rows: per fusion layer below the top one, expected padding = B*Lt - n_valid rows (a negative is as long as an
+    average sequence)."""
+    pad = B * Lt - n_valid
+    fus_tok = 12 * H * H + 4 * Lt * H + 4 * Lp * H + 4 * H * I
+    return 3 * pad * (n_text - fusion - 1) * fus_tok
+
+
 def cross_attn_unit_flops(nseq, Lq, Lkv, H=768):
     """Fused cross-attention unit (Q/K/V projections + core + out-proj), BASELINE.md section 3."""
     return nseq * (4 * H * H * Lq + 4 * H * H * Lkv + 4 * Lq * Lkv * H)
@@ -741,8 +751,8 @@ def main():
            "step_tflop": round(flops / 1e12, 2),
            "executed_step_tflop": round((flops - shared_kv_saving(B, Lt, n_text=nt, fusion=f)
                                          - (padding_saving(B, Lt, n_valid, n_text=nt, fusion=f) if Lt <= ops.ATTN_MAXL else 0.0)
-                                         - (cls_top_saving(B, Lt, n_valid) if (Lt <= ops.ATTN_MAXL and opts.cls_only_top and opts.pack_text
-                                                                               and not opts.resid_fp32) else 0.0)) / 1e12, 2),
+                                         - ((cls_top_saving(B, Lt, n_valid) + neg_pack_saving(B, Lt, n_valid, n_text=nt, fusion=f))
+                                            if (Lt <= ops.ATTN_MAXL and opts.cls_only_top and opts.pack_text and not opts.resid_fp32) else 0.0)) / 1e12, 2),
            "valid_text_tokens_frac": round(n_valid / (B * Lt), 4),
            "model_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1),
            "mfma_frac_of_peak_step": round(flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "losses": final_losses, "hbm": hbm}

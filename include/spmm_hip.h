@@ -73,7 +73,7 @@ const char* spmm_last_error(void);
 #define SPMM_GEMM_AUTO_TILES 16
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
-                 void* C2, long ldc2, int epi, float* colsum, int kernel, spmm_stream_t stream);
+                 void* C2, long ldc2, int epi, float* colsum, int kernel, const int* M_dev, spmm_stream_t stream);
 /* The output projection in front of a residual LayerNorm with the hidden dropout and the residual in its epilogue:
  *   C(bf16) = dropout(bf16(A W^T + bias)) + R        BertSelfOutput / BertOutput xbert.py:370-372, 448-450 (up to the LayerNorm)
  * on the 8-phase kernel, so that spmm_ln_fwd(C, res = NULL, dropout_p = 0) reads one tensor instead of two.  The mask is the one
@@ -83,7 +83,12 @@ int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N,
 int spmm_gemm_nt_drop_ok(int M, int N, int K);
 int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, const void* R,
                       long ldr, void* C, long ldc, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int kernel,
-                      spmm_stream_t stream);
+                      const int* M_dev, spmm_stream_t stream);
+/* Device-side row counts (`M_dev` / `R_dev` / `rows_dev`, optional, null = none): spmm_gemm_nt (8-phase kernel), spmm_gemm_nt_drop,
+ * spmm_gemm_tn (8-phase kernel, split launch), spmm_colsum_bf16, spmm_ln_fwd and spmm_ln_bwd take a pointer to an int in device memory
+ * holding the number of rows to process, <= the host-side row count the launch and the buffers are sized for.  Rows past it are neither
+ * read nor written.  For batches whose tail length only the device knows -- here the text hard negatives drawn on the device
+ * (SPMM_models.py:166-178) that re-enter the fusion layers as packed query rows: no host read sizes the step. */
 /* Weight-gradient GEMM C[N,K] += alpha * A[M,N]^T . B[M,K] straight from the token-major activations (LDS transpose reads,
  * no transposed copies); `splits` > 1 reduces partial slabs from `workspace` (spmm_gemm_tn_workspace_bytes) without atomics.
  * Replaces autograd's weight-gradient matmuls of every nn.Linear on the path.  spmm_colsum_bf16: bias gradients. */
@@ -92,10 +97,10 @@ long spmm_gemm_tn_workspace_bytes(int M, int N, int K, int splits);
  * spmm_gemm_tn_splits returns the split count that fills the chip for that choice (pass the same `kernel` to both). */
 int spmm_gemm_tn_splits(int M, int N, int K, int kernel);
 int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C,
-                 long ldc, float* workspace, int kernel, spmm_stream_t stream);
+                 long ldc, float* workspace, int kernel, const int* M_dev, spmm_stream_t stream);
 /* C[n*ldc + k] += sum over ns slabs of N*K floats in `ws`: the split reduction spmm_gemm_tn runs itself, as an entry of its own. */
 int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream);
-int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream);
+int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, const int* R_dev, spmm_stream_t stream);
 
 /* Attention core softmax(QK^T/8 + mask) -> dropout -> .V for head_dim 64, Lq,Lkv <= 256 (one workgroup holds the K/V
  * panel of a head in LDS; the forward runs one workgroup per 128-query chunk, the backward one launch per 128-query chunk).
@@ -150,7 +155,7 @@ int spmm_segment_sum_bf16(const void* src, const int* start, const int* list, vo
  * property_mtr_head LN SPMM_models.py:41.  zout (may alias x) keeps the pre-norm sum for backward. */
 int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* zout, float* mean,
                 float* rstd, long rows, int H, float eps, float dropout_p, const uint64_t* seed_ptr, uint64_t salt,
-                spmm_stream_t stream);
+                const int* rows_dev, spmm_stream_t stream);
 /* The same with the fp32 residual stream (EngineOptions.resid_fp32): res32 is read in fp32, the normalised row is
  * written as bf16 (y: the MFMA operand of the next GEMM) AND fp32 (y32: the next residual / the loss heads' input; may be null). */
 int spmm_ln_fwd_r32(const void* x, const float* res32, const float* gamma, const float* beta, void* y, float* y32, void* zout,
@@ -161,7 +166,7 @@ int spmm_ln_fwd_r32(const void* x, const float* res32, const float* gamma, const
  * i.e. the bias gradient of the dense layer whose output was normalised. */
 int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H, float dropout_p,
-                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, spmm_stream_t stream);
+                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, const int* rows_dev, spmm_stream_t stream);
 
 /* One decode step of BertEmbeddings.forward (xbert.py:193-220) at inference: y[r] = LN(word[ids[r]] + pos[pos_index] +
  * type[0]) for `rows` single-token rows (every beam is at the same position).  pos_ptr (optional) overrides pos_index
@@ -244,10 +249,11 @@ int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int
  *   [packed | dense] and [packed | packed] batches of the text encoders from their dense [2B Lt] embeddings, inv[2 B Lt] = packed row of
  *   every dense row (-1: padding) for the way back; *bad |= 1 when the mask is not B non-empty prefixes with M tokens in all.
  *  spmm_fusion_plan: index arrays of the fusion batch (layout in csrc/plan.hip) from the sampled negatives neg[2B] (prop | text):
- *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]), maskcat [2B, Lt] key masks of
- *   the dense text group, neg_rows [B Lt] (packed row of every token of a text negative, -1 = none), idx_top (rows the top fusion layer
- *   keeps: position 0 of the 6B ITM sequences, every row of the LM and causal-PV passes), small32 [39 B] (sequence -> key/value
- *   source maps, packed row tables, CSR inverse maps of the two shared key/value sources). */
+ *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]; the text negatives re-enter as PACKED
+ *   query rows at the end of the batch, Mn = sum of their lengths known only on the device), neg_rows [B Lt] (row of text_embeds behind
+ *   every packed negative row, -1 past Mn), idx_top (rows the top fusion layer keeps: position 0 of the 6B ITM sequences, every row of the
+ *   LM and causal-PV passes), small32 [35 B] (sequence -> key/value source maps, packed row tables, CSR inverse maps of the two shared
+ *   key/value sources, and rows_dev = {rows of the batch, Mn}: the device-side row counts of the launches over it). */
 int spmm_gather_rows2(void* dst, const void* srcA, const void* srcB, const long* idx, long rows, int H, spmm_stream_t stream);
 int spmm_add_rows_bf16(void* dst, const long* idx, const void* src, long rows, int H, spmm_stream_t stream);
 int spmm_zero_bytes(void* p, long nbytes, spmm_stream_t stream);
@@ -255,8 +261,8 @@ int spmm_zero_rows(void* p, long rows, long row_bytes, long stride_bytes, spmm_s
 int spmm_gelu_bwd(const void* dz, const void* pre, void* out, long n, spmm_stream_t stream);
 int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32, int* row0_32, long* row0_64, long* rows, long* gidx2,
                    long* gidx4, long* inv, int* bad, spmm_stream_t stream);
-int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, const int* mask, int B, int Lt, int Lp, int M,
-                     long* idx6, int* maskcat, long* neg_rows, long* idx_top, int* small32, spmm_stream_t stream);
+int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, int B, int Lt, int Lp, int M,
+                     long* idx6, long* neg_rows, long* idx_top, int* small32, spmm_stream_t stream);
 
 /* F.normalize(proj(cls), dim=-1) SPMM_models.py:92,95,101,105; also emits split-bf16 GEMM operands. */
 int spmm_l2norm_fwd(const float* x, long ldx, float* y, float* nrm, void* a3, void* w3, void* yT, long ldt, int rows, int E,

@@ -51,7 +51,19 @@ struct GemmP {
   // EPI_DROPRES (spmm_gemm_nt_drop): the hidden dropout of BertSelfOutput / BertOutput (xbert.py:371,449) inside the epilogue -- the mask
   // spmm_ln_fwd / spmm_ln_bwd draw for (seed, salt, row, column): element (m, n) uses half (n & 1) of drop_pair(drop_rowkey(seed', m), n >> 1)
   const uint64_t* seed_ptr; uint64_t salt; uint32_t drop_thresh16; float drop_scale;
+  // optional device-side row count (8-phase kernel only): the launch is SIZED for M rows, the kernel computes *M_ptr <= M of them -- the
+  // rows of a batch whose tail length only the device knows (step.py: the hard negatives drawn as text queries)
+  const int* M_ptr;
 };
+
+// device-side row count (GemmP::M_ptr): the kernel argument copy of M is lowered once, before anything derives from it
+#define GEMM_DYN_M(P)                                          \
+  do {                                                         \
+    if ((P).M_ptr) {                                           \
+      const int m_ = *(P).M_ptr;                               \
+      (P).M = m_ < (P).M ? (m_ > 0 ? m_ : 1) : (P).M;          \
+    }                                                          \
+  } while (0)
 
 // LDS-DMA staging: 128 rows x 8 slots(16 B) = 1024 chunks, 4 per thread; chunk id -> (row = id>>3,
 // physical slot = id&7).  The wave's 64 chunks are contiguous in LDS (wave-uniform base + lane*16).
@@ -281,10 +293,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware tile id: workgroup b runs on XCD b%8; give each XCD a contiguous range of tiles.
+  GEMM_DYN_M(p);
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
   int t;
   {
     const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    if (i >= (xcd < r ? q + 1 : q)) return;          // (a device-side row count left this workgroup without a tile)
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
   const int tile_m = t / ntn, tile_n = t % ntn;
@@ -370,10 +384,12 @@ __global__ __launch_bounds__(PC_THREADS) void gemm_nt_pc_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_pc[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GEMM_DYN_M(p);
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
   int t;
   {
     const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    if (i >= (xcd < r ? q + 1 : q)) return;          // (a device-side row count left this workgroup without a tile)
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
   const int tile_m = t / ntn, tile_n = t % ntn;
@@ -518,10 +534,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  GEMM_DYN_M(p);
   const int ntm = (p.M + BM2 - 1) / BM2, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
   int t;
   {
     const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    if (i >= (xcd < r ? q + 1 : q)) return;          // (a device-side row count left this workgroup without a tile)
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
   const int tile_m = t / ntn, tile_n = t % ntn;
@@ -674,10 +692,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves, wave tile 128 (m) x 64 (n)
+  GEMM_DYN_M(p);
   const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
   int t;
   {
     const int b = blockIdx.x, q = nt >> 3, r = nt & 7, xcd = b & 7, i = b >> 3;
+    if (i >= (xcd < r ? q + 1 : q)) return;          // (a device-side row count left this workgroup without a tile)
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
   int tile_m, tile_n;
@@ -1099,7 +1119,9 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves, wave tile 128 (m) x 64 (n)
+  GEMM_DYN_M(p);                                     // device-side row count: fewer row panels than the grid was sized for
   const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
+  if ((int)blockIdx.x >= nt) return;                 // (whole workgroups: no barrier has been executed yet)
   const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (launcher)
 
   f32x4 acc[2][4][4];                                // [m half][mi][ni], 128 accumulators
@@ -1507,7 +1529,7 @@ int pick_tile(int M, int N, int epi) {
 extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits,
                             const float* bias, const float* div_ptr, float alpha, const void* R, long ldr,
                             const void* G, long ldg, void* C, long ldc, void* C2, long ldc2, int epi, float* colsum,
-                            int kernel, hipStream_t stream) {
+                            int kernel, const int* M_dev, hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(K % 64 == 0, "spmm_gemm_nt: K=%d must be a multiple of 64", K);
   SPMM_CHECK_SHAPE(N % 4 == 0, "spmm_gemm_nt: N=%d must be a multiple of 4", N);
@@ -1528,7 +1550,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum; p.sa = nullptr; p.sw = nullptr;
-  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f;
+  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f; p.M_ptr = nullptr;
   // tile order (tile_of): K <= 1024 -> 2 (blocks of 8 row panels x up to 4 column tiles per XCD), longer K -> 0 (row-major).  Measured in
   // the cache state the step presents (a 256-MiB memset between launches, tools/gemm_bench sustain GEMM_BENCH_BETWEEN=1): 84256x2304x768
   // 1 072 TF/s with order 2 against 960 with the column-group order 3 used before (which had the lowest counter traffic with warm
@@ -1558,6 +1580,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   SPMM_CHECK_SHAPE(k != 3 || is_bf16_epi(epi), "spmm_gemm_nt: the 256x256 kernel has bf16-output epilogues only");
   SPMM_CHECK_SHAPE(k != 2 || epi != EPI_F32_ATOMIC, "spmm_gemm_nt: the 256x128 kernel has no atomic epilogue");
   SPMM_CHECK_SHAPE(k == 1 || k == 5 || splits == 1, "spmm_gemm_nt: split-K runs on the 128x128 kernels only");
+  p.M_ptr = M_dev;
   int rc;
   if (k == 8 || k == 9) rc = launch_p8(epi, p, stream, k == 8);     // 9: one workgroup per tile (A/B of the persistent walk)
   else if (k == 3) rc = launch_v3(epi, p, stream);
@@ -1578,7 +1601,7 @@ extern "C" int spmm_gemm_nt_drop_ok(int M, int N, int K) {
 }
 extern "C" int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, const void* R,
                                  long ldr, void* C, long ldc, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int kernel,
-                                 hipStream_t stream) {
+                                 const int* M_dev, hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0, "spmm_gemm_nt_drop: M=%d N=%d K=%d (K %% 128 == 0, N %% 8 == 0)", M, N, K);
   SPMM_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0 && R != nullptr, "spmm_gemm_nt_drop: rows must be multiples of 8 elements and R is required");
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)R % 16 == 0), "spmm_gemm_nt_drop: operands must be 16-B aligned");
@@ -1591,6 +1614,7 @@ extern "C" int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ld
   p.C2 = nullptr; p.ldc2 = 0; p.colsum = nullptr; p.sa = nullptr; p.sw = nullptr;
   p.order = K > 1024 ? 0 : 2;
   p.seed_ptr = seed_ptr; p.salt = salt; p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f); p.drop_scale = 1.f / (1.f - dropout_p);
+  p.M_ptr = M_dev;
   SPMM_CHECK_SHAPE(p8_ok(p, EPI_DROPRES), "spmm_gemm_nt_drop: operands must be < 4 GiB");
   int rc = (p.drop_thresh16 == 0) ? launch_p8(EPI_BF16, p, stream, !(kernel == SPMM_GEMM_AUTO_TILES || kernel == 9))
                                   : launch_p8(EPI_DROPRES, p, stream, !(kernel == SPMM_GEMM_AUTO_TILES || kernel == 9));
@@ -1617,7 +1641,7 @@ extern "C" int spmm_gemm_nt_f8(const void* A8, long lda, const float* sa, const 
   p.M = M; p.N = N; p.K = K; p.ksplit = K; p.bias = bias; p.div_ptr = nullptr; p.alpha = 1.f;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = nullptr; p.ldg = 0; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = nullptr; p.sa = sa; p.sw = sw;
-  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f;
+  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f; p.M_ptr = nullptr;
   p.order = K > 2048 ? 0 : 2;
   int rc;
   if (epi == EPI_BF16) rc = launch_p8_one<EPI_BF16, true>(p, stream, true);

@@ -36,6 +36,7 @@ struct TnP {
   float alpha;
   int nsplit;                 // 8-phase kernel: > 0 = 1-D grid of tiles x nsplit workgroups in XCD-contiguous order (else grid.z = slice)
   int rlast, ndup;            // 8-phase kernel: the LAST slice is rows [M - rlast, M); its first ndup rows belong to the slice before (masked)
+  const int* M_ptr;           // optional device-side row count <= M (8-phase kernel, nsplit > 1): the slices are re-cut on the device
 };
 
 // physical byte offset of logical 16-B chunk `c16` (8 columns) of row `row`
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
   }
   const int n0 = (t / ntk) * BT, k0 = (t % ntk) * BT;
+  if (p.M_ptr) { const int m_ = *p.M_ptr; p.M = m_ < p.M ? m_ : p.M; }      // device-side row count: slices past it reduce nothing
   const int mbeg = blockIdx.z * p.rsplit;
   const int mend = min(p.M, mbeg + p.rsplit);
   const int nsteps = (mend - mbeg + BR - 1) / BR;
@@ -258,13 +260,26 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
     tile = bidx; zsplit = bz;
   }
   const int n0 = (tile / ntk) * 256, k0 = (tile % ntk) * 256;
+  // Device-side row count (rows of a batch whose tail only the device knows): the launcher's slicing rule applied here to *M_ptr, with
+  // the nsplit slices the grid was sized for; slices left without rows write a zero tile into their slab.
+  int Mrows = p.M, rsplit = p.rsplit, rlast_ = p.rlast, ndup_ = p.ndup, nslices = p.nsplit;
+  if (p.M_ptr != nullptr && p.nsplit > 1) {
+    int m_ = *p.M_ptr;
+    m_ = m_ < p.M ? (m_ > 256 ? m_ : 256) : p.M;
+    const int rs = ((((m_ + 127) >> 7) + p.nsplit - 1) / p.nsplit) << 7;
+    const int ns = (m_ + rs - 1) / rs;               // >= 2 for m_ > rs; rows [0, m_) cut like the launcher cuts [0, M)
+    const int over = ns * rs - m_;
+    Mrows = m_; rsplit = rs; nslices = ns; rlast_ = rs - ((over >> 7) << 7); ndup_ = over & 127;
+    if (ns == 1) { rlast_ = (m_ >> 7) << 7; ndup_ = 0; }      // (cannot happen for m_ > 256 with nsplit >= 2; kept total)
+  }
+  const bool empty = p.nsplit > 0 && zsplit >= nslices;
   // Row slices are multiples of 128 rows (pairs of 64-row steps).  M is not: the last slice is moved back to END at row M, and the
   // ndup rows it then shares with the slice before are zeroed in LDS (A side) after they land -- LDS-DMA cannot zero-fill, and
   // reading past row M is not an option.
-  const bool lastz = p.nsplit > 0 && zsplit == p.nsplit - 1;
-  const int mbeg = lastz ? p.M - p.rlast : zsplit * p.rsplit;
-  const int nk = (lastz ? p.rlast : min(p.M, mbeg + p.rsplit) - mbeg) / 64;     // steps of 64 rows: even and >= 2
-  const int ndup = lastz ? p.ndup : 0;
+  const bool lastz = p.nsplit > 0 && zsplit == nslices - 1;
+  const int mbeg = empty ? 0 : (lastz ? Mrows - rlast_ : zsplit * rsplit);
+  const int nk = empty ? 0 : (lastz ? rlast_ : min(Mrows, mbeg + rsplit) - mbeg) / 64;     // steps of 64 rows: even and >= 2 (0: a slice without rows)
+  const int ndup = lastz ? ndup_ : 0;
   (void)ntn;
 
   f32x4 acc[2][4][4];                                  // [n half][n block mi][k half * 2 + k block]
@@ -374,6 +389,7 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
     TP_SB();                                               \
   } while (0)
 
+  if (nk > 0) {                                         // (wave- and workgroup-uniform)
   // ---- prologue: step 0 complete, the first three half-tiles of step 1 in flight
   TP_STG_A(0, 0, 0); TP_STG_B(0, 0, 0); TP_STG_B(1, 0, 0); TP_STG_A(1, 0, 0);
   TP_STG_B(0, 1, 1); TP_STG_A(0, 1, 1); TP_STG_B(1, 1, 1);
@@ -434,6 +450,7 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
     TP_COMPUTE(1, 0, tb0);
   }
   if (wr == 0) TP_BAR();
+  }
 #undef TP_MASK
 #undef TP_STG
 #undef TP_STG_A
@@ -512,8 +529,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // out[c] += sum_r x[r][c]   (bias gradients).  A workgroup reduces a CS_ROWS-row x 128-column strip: 16 column groups of
 // 8 bf16 (16-byte loads) x 16 row lanes, eight loads in flight per thread, LDS tree over the row lanes, one atomicAdd per column.
 constexpr int CS_ROWS = 256;    // (1024-row strips were measured SLOWER: 37 vs 26 us per launch -- fewer workgroups, less memory-level parallelism)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, int R, int C, float* __restrict__ out,
+                                                     const int* __restrict__ R_ptr) {
   __shared__ float red[16][129];
+  if (R_ptr) { const int r_ = *R_ptr; R = r_ < R ? r_ : R; }
+  if ((int)blockIdx.y * CS_ROWS >= R) return;
   const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 128 + cg * 8;
   const int r0 = blockIdx.y * CS_ROWS;
@@ -604,7 +624,7 @@ static void tn_reduce_launch(const float* ws, int ns, int N, int K, float* C, lo
 }
 
 static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha, float* C, long ldc,
-                  float* workspace, int kernel, hipStream_t stream) {
+                  float* workspace, int kernel, const int* M_dev, hipStream_t stream) {
   SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "spmm_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   SPMM_CHECK_SHAPE(N % 4 == 0 && K % 4 == 0 && ldc % 4 == 0, "spmm_gemm_tn: N=%d K=%d ldc=%ld must be multiples of 4", N, K, ldc);
 #ifndef P8_PROFILE   // (the profiling build of tools/ aliases all rows onto row 0 with lda = ldb = 0: cache-resident operands)
@@ -621,7 +641,7 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
                    "spmm_gemm_tn: the 8-phase kernel addresses its operands with 32-bit byte offsets (< 4 GiB)");
   TnP p;
   p.A = (const bf16*)A; p.lda = lda; p.B = (const bf16*)B; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
-  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha; p.nsplit = 0;
+  p.C = C; p.ldc = ldc; p.slab = workspace; p.alpha = alpha; p.nsplit = 0; p.M_ptr = nullptr;
   auto reduce = [&](int nsplit) { tn_reduce_launch(workspace, nsplit, N, K, C, ldc, stream); };
   if (k8) {
     static const hipError_t attr_rc = [] {
@@ -643,6 +663,14 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
     if (ns == 1) { p.rlast = ((M + 127) / 128) * 128 > M ? (M / 128) * 128 : M; p.ndup = 0; }   // a single slice cannot overlap anything
     const int single_left = ns == 1 ? M - p.rlast : 0;
     dim3 grid(((N + 255) / 256) * ((K + 255) / 256) * ns, 1, 1);
+    if (M_dev != nullptr && ns == 1) {                 // one slice + remainder pass: the 128x128 kernel serves a device-side row count at any M
+      p.nsplit = 0; p.M_ptr = M_dev;
+      p.rsplit = ((M + BR - 1) / BR) * BR;
+      hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(((N + BT - 1) / BT) * ((K + BT - 1) / BT), 1, 1), dim3(256), 0, stream, p);
+      SPMM_LAUNCH_CHECK("spmm_gemm_tn(device rows, 128x128)");
+      return SPMM_OK;
+    }
+    p.M_ptr = M_dev;
     if (ns > 1) {
       hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, grid, dim3(512), TP_LDS, stream, p);
       reduce(ns);
@@ -658,6 +686,7 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
     SPMM_LAUNCH_CHECK("spmm_gemm_tn(8-phase)");
     return SPMM_OK;
   }
+  p.M_ptr = M_dev;
   int rsplit = (((M + BR - 1) / BR + splits - 1) / splits) * BR;
   splits = (M + rsplit - 1) / rsplit;
   p.rsplit = rsplit;
@@ -674,8 +703,8 @@ static int tn_run(const void* A, long lda, const void* B, long ldb, int M, int N
 }
 
 extern "C" int spmm_gemm_tn(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int splits, float alpha,
-                            float* C, long ldc, float* workspace, int kernel, spmm_stream_t stream) {
-  return tn_run(A, lda, B, ldb, M, N, K, splits, alpha, C, ldc, workspace, kernel, stream);
+                            float* C, long ldc, float* workspace, int kernel, const int* M_dev, spmm_stream_t stream) {
+  return tn_run(A, lda, B, ldb, M, N, K, splits, alpha, C, ldc, workspace, kernel, M_dev, stream);
 }
 
 extern "C" int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float* C, long ldc, spmm_stream_t stream) {
@@ -686,9 +715,9 @@ extern "C" int spmm_gemm_tn_reduce(const float* ws, int ns, int N, int K, float*
   return SPMM_OK;
 }
 
-extern "C" int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, spmm_stream_t stream) {
+extern "C" int spmm_colsum_bf16(const void* x, long ld, int R, int C, float* out, const int* R_dev, spmm_stream_t stream) {
   SPMM_CHECK_SHAPE(R > 0 && C > 0 && ld % 8 == 0 && ((uintptr_t)x % 16 == 0), "spmm_colsum_bf16: R=%d C=%d ld=%ld (ld %% 8, 16-B aligned)", R, C, ld);
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128, (R + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, stream, (const bf16*)x, ld, R, C, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128, (R + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, stream, (const bf16*)x, ld, R, C, out, R_dev);
   SPMM_LAUNCH_CHECK("spmm_colsum_bf16");
   return SPMM_OK;
 }

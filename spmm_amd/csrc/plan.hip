@@ -141,35 +141,41 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(const int* __restrict__
 
 // ---- index arrays of the fusion batch (PretrainStep.forward, packed text layout).  Row layout of the batch X6:
 //   [ PV queries of the three ITM passes: pe | pe[neg_p] | pe   (3B x Lp)          rows [0, o_tp)
-//   | text queries, packed: te | te                          (2M)                 rows [o_tp, o_tn)
-//   | text negatives as queries, dense, zero rows past the negative's length (B x Lt)  rows [o_tn, o_lm)
+//   | text queries, packed: te | te                          (2M)                 rows [o_tp, o_lm)
 //   | the LM pass (hidden10, dense B x Lt)                                          rows [o_lm, o_12)
-//   | the causal PV pass (B x Lp)                                                   rows [o_12, R6) ]
+//   | the causal PV pass (B x Lp)                                                   rows [o_12, o_8)
+//   | text negatives as queries, PACKED: sequence s = te[neg_t[s]]                  rows [o_8, o_8 + Mn),  Mn = sum_s len[neg_t[s]] <= B Lt ]
+// Mn is known only here, on the device: the batch is allocated for B Lt such rows and every row-wise / GEMM launch over it takes its row
+// count R = o_8 + Mn from rows_dev (include/spmm_hip.h, "device-side row counts") -- no host read, no padding rows computed.
 // Sources of the assembly gather: A = y1 = [prop_embeds (B Lp) ; prop_embeds_causal (B Lp)], B = y2 = [text_embeds (M) ; hidden10 (B Lt)].
-// small32: 39 x B int32, layout in units of B (spmm_amd/step.py::_FUSION_SMALL mirrors it):
-//   0 ar | 1 kvidx_pv[3B] = ar,ar,neg_t | 4 kvidx_tp[2B] = ar,neg_p | 6 kvidx_td[2B] = ar,ar | 8 kvidx_ctx[3B] = ar,neg_p,ar
-//   11 qrow0_tp[2B] | 13 qlen_tp[2B] | 15 skv_row0_pv[3B] | 18 skv_len_pv[3B] | 21 skv_row0_tx[3B] | 24 skv_len_tx[3B]
-//   27 start_t[B+1] | 29 list_t[4B] | 33 start_p[B+1] | 35 list_p[4B]
+// small32: 35 x B int32, layout in units of B (spmm_amd/ops.py::FUSION_SMALL mirrors it):
+//   0 ar | 1 kvidx_pv[3B] = ar,ar,neg_t | 4 kvidx_tp[2B] = ar,neg_p | 6 qrow0_tp[2B] | 8 qlen_tp[2B] | 10 row0_8[B] | 11 len_8[B]
+//   12 skv_row0_pv[3B] | 15 skv_len_pv[3B] | 18 skv_row0_tx[2B] | 20 skv_len_tx[2B] | 22 start_t[B+1] | 24 list_t[4B] | 28 start_p[B+1]
+//   30 list_p[4B] | 34 rows_dev[2] = {o_8 + Mn, Mn}
 __global__ __launch_bounds__(256) void fusion_plan_kernel(const long* __restrict__ neg, const int* __restrict__ lens, const int* __restrict__ row0,
-                                                           const int* __restrict__ mask, int B, int Lt, int Lp, int M, long* __restrict__ idx6,
-                                                           int* __restrict__ maskcat, long* __restrict__ neg_rows, long* __restrict__ idx_top,
-                                                           int* __restrict__ small32) {
+                                                           int B, int Lt, int Lp, int M, long* __restrict__ idx6, long* __restrict__ neg_rows,
+                                                           long* __restrict__ idx_top, int* __restrict__ small32) {
+  extern __shared__ int r8[];                          // [B + 1] first packed row of every text negative (every workgroup computes it)
   const long BLp = (long)B * Lp, BLt = (long)B * Lt;
-  const long o_tp = 3 * BLp, o_tn = o_tp + 2l * M, o_lm = o_tn + BLt, o_12 = o_lm + BLt, R6 = o_12 + BLp;
+  const long o_tp = 3 * BLp, o_lm = o_tp + 2l * M, o_12 = o_lm + BLt, o_8 = o_12 + BLp, Rcap = o_8 + BLt;
   const long* neg_p = neg;
   const long* neg_t = neg + B;
+  for (int s = threadIdx.x; s <= B; s += blockDim.x) {
+    int a = 0;
+    for (int j = 0; j < s; ++j) a += lens[neg_t[j]];
+    r8[s] = a;
+  }
+  __syncthreads();
+  const int Mn = r8[B];
   const long gsz = (long)gridDim.x * blockDim.x, g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (long r = g0; r < R6; r += gsz) {
+  for (long r = g0; r < o_8; r += gsz) {
     long j;
     if (r < o_tp) {
       const long g = r / BLp, w = r - g * BLp, s = w / Lp, l = w - s * Lp;
       j = (g == 1 ? neg_p[s] : s) * Lp + l;
-    } else if (r < o_tn) {
+    } else if (r < o_lm) {
       const long w = r - o_tp;
       j = SRC_B | (w >= M ? w - M : w);
-    } else if (r < o_lm) {
-      const long w = r - o_tn, s = w / Lt, l = w - s * Lt, n = neg_t[s];
-      j = l < lens[n] ? (SRC_B | (row0[n] + l)) : -1;
     } else if (r < o_12) {
       j = SRC_B | (M + (r - o_lm));
     } else {
@@ -177,13 +183,14 @@ __global__ __launch_bounds__(256) void fusion_plan_kernel(const long* __restrict
     }
     idx6[r] = j;
   }
-  for (long w = g0; w < 2 * BLt; w += gsz) {
-    const long s = w / Lt, l = w - s * Lt;
-    maskcat[w] = s < B ? mask[neg_t[s] * Lt + l] : mask[(s - B) * Lt + l];
-  }
-  for (long w = g0; w < BLt; w += gsz) {
+  for (long w = g0; w < BLt; w += gsz) {               // the packed negatives: token l of sequence s <- token l of te[neg_t[s]]
     const long s = w / Lt, l = w - s * Lt, n = neg_t[s];
-    neg_rows[w] = l < lens[n] ? row0[n] + l : -1;
+    if (l < lens[n]) {
+      const long j = r8[s] + l;
+      idx6[o_8 + j] = SRC_B | (row0[n] + l);
+      neg_rows[j] = row0[n] + l;
+    }
+    if (w >= Mn) { idx6[o_8 + w] = -1; neg_rows[w] = -1; }
   }
   // top layer: rows of the layer input it keeps -- position 0 of the 6B ITM sequences, then every row of the LM and causal-PV passes
   for (long w = g0; w < 6l * B + BLt + BLp; w += gsz) {
@@ -191,25 +198,26 @@ __global__ __launch_bounds__(256) void fusion_plan_kernel(const long* __restrict
     if (w < 3l * B) j = w * Lp;
     else if (w < 4l * B) j = o_tp + row0[w - 3l * B];
     else if (w < 5l * B) j = o_tp + M + row0[w - 4l * B];
-    else if (w < 6l * B) j = o_tn + (w - 5l * B) * Lt;
+    else if (w < 6l * B) j = o_8 + r8[w - 5l * B];
     else j = o_lm + (w - 6l * B);
     idx_top[w] = j;
   }
+  (void)Rcap;
   if (blockIdx.x != 0) return;
   int* S = small32;
+  if (threadIdx.x == 0) { S[34 * B] = (int)o_8 + Mn; S[34 * B + 1] = Mn; }
   for (int s = threadIdx.x; s < B; s += blockDim.x) {
     const int np = (int)neg_p[s], nt = (int)neg_t[s];
     S[s] = s;
     S[1 * B + s] = s; S[2 * B + s] = s; S[3 * B + s] = nt;
     S[4 * B + s] = s; S[5 * B + s] = np;
-    S[6 * B + s] = s; S[7 * B + s] = s;
-    S[8 * B + s] = s; S[9 * B + s] = np; S[10 * B + s] = s;
-    S[11 * B + s] = row0[s]; S[12 * B + s] = row0[s] + M;
-    S[13 * B + s] = lens[s]; S[14 * B + s] = lens[s];
-    S[15 * B + s] = s * Lp; S[16 * B + s] = (B + s) * Lp; S[17 * B + s] = (2 * B + s) * Lp;
-    S[18 * B + s] = Lp; S[19 * B + s] = Lp; S[20 * B + s] = Lp;
-    S[21 * B + s] = (int)o_tp + row0[s]; S[22 * B + s] = (int)o_tp + M + row0[s]; S[23 * B + s] = (int)o_tn + s * Lt;
-    S[24 * B + s] = lens[s]; S[25 * B + s] = lens[s]; S[26 * B + s] = lens[nt];
+    S[6 * B + s] = row0[s]; S[7 * B + s] = row0[s] + M;
+    S[8 * B + s] = lens[s]; S[9 * B + s] = lens[s];
+    S[10 * B + s] = r8[s]; S[11 * B + s] = lens[nt];
+    S[12 * B + s] = s * Lp; S[13 * B + s] = (B + s) * Lp; S[14 * B + s] = (2 * B + s) * Lp;
+    S[15 * B + s] = Lp; S[16 * B + s] = Lp; S[17 * B + s] = Lp;
+    S[18 * B + s] = (int)o_tp + row0[s]; S[19 * B + s] = (int)o_tp + M + row0[s];
+    S[20 * B + s] = lens[s]; S[21 * B + s] = lens[s];
     // inverse (CSR) maps of the shared key/value sources: the consumers of source u in consumer order
     //   text source u: PV sequences u, B+u, {2B+s : neg_t[s] == u}, 3B+u      PV source u: text sequences u, {B+s : neg_p[s] == u}, 2B+u, 3B+u
     int ct = 0, cp = 0, bt = 0, bp = 0;               // consumers drawn as negatives: of u, and of all sources before u
@@ -219,10 +227,10 @@ __global__ __launch_bounds__(256) void fusion_plan_kernel(const long* __restrict
       cp += b == s; bp += b < s;
     }
     const int st = 3 * s + bt, sp = 3 * s + bp;
-    S[27 * B + s] = st; S[33 * B + s] = sp;
-    if (s == B - 1) { S[27 * B + B] = st + 3 + ct; S[33 * B + B] = sp + 3 + cp; }
-    int* Lt_ = S + 29 * B + st;
-    int* Lp_ = S + 35 * B + sp;
+    S[22 * B + s] = st; S[28 * B + s] = sp;
+    if (s == B - 1) { S[22 * B + B] = st + 3 + ct; S[28 * B + B] = sp + 3 + cp; }
+    int* Lt_ = S + 24 * B + st;
+    int* Lp_ = S + 30 * B + sp;
     Lt_[0] = s; Lt_[1] = B + s;
     Lp_[0] = s;
     int kt = 2, kp = 1;
@@ -288,13 +296,13 @@ extern "C" int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32
   return SPMM_OK;
 }
 
-extern "C" int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, const int* mask, int B, int Lt, int Lp, int M,
-                                long* idx6, int* maskcat, long* neg_rows, long* idx_top, int* small32, hipStream_t stream) {
-  SPMM_CHECK_SHAPE(B >= 1 && Lt >= 1 && Lp >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_fusion_plan: B=%d Lt=%d Lp=%d M=%d", B, Lt, Lp, M);
-  const long R6 = 4l * B * Lp + 2l * M + 2l * B * Lt;
-  SPMM_CHECK_SHAPE(R6 < (1l << 31), "spmm_fusion_plan: %ld rows do not fit the int32 row tables", R6);
-  hipLaunchKernelGGL(fusion_plan_kernel, dim3(blocks_for(R6, 256)), dim3(256), 0, stream, neg, lens32, row0_32, mask, B, Lt, Lp, M, idx6, maskcat,
-                     neg_rows, idx_top, small32);
+extern "C" int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, int B, int Lt, int Lp, int M,
+                                long* idx6, long* neg_rows, long* idx_top, int* small32, hipStream_t stream) {
+  SPMM_CHECK_SHAPE(B >= 1 && B <= 8192 && Lt >= 1 && Lp >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_fusion_plan: B=%d Lt=%d Lp=%d M=%d", B, Lt, Lp, M);
+  const long Rcap = 4l * B * Lp + 2l * M + 2l * B * Lt;
+  SPMM_CHECK_SHAPE(Rcap < (1l << 31), "spmm_fusion_plan: %ld rows do not fit the int32 row tables", Rcap);
+  hipLaunchKernelGGL(fusion_plan_kernel, dim3(blocks_for(Rcap, 256) > 64 ? 64 : blocks_for(Rcap, 256)), dim3(256), (B + 1) * sizeof(int), stream, neg, lens32,
+                     row0_32, B, Lt, Lp, M, idx6, neg_rows, idx_top, small32);
   SPMM_LAUNCH_CHECK("spmm_fusion_plan");
   return SPMM_OK;
 }

@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16* __restrict__ y, bf16* __restrict__ zout, float* __restrict__ mean_o,
                                                      float* __restrict__ rstd_o, long rows, int H, float eps,
-                                                     uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt) {
+                                                     uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt,
+                                                     const int* __restrict__ rows_ptr) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_ptr) { const long r_ = *rows_ptr; rows = r_ < rows ? r_ : rows; }
   if (row >= rows) return;
   RowVec z, r, o;
   load_row_bf16(x + row * H, H, lane, z);
@@ -174,9 +176,14 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16* __restrict__ 
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        bf16* __restrict__ y, bf16* __restrict__ zout, float* __restrict__ mean_o,
                                                        float* __restrict__ rstd_o, long rows, float eps, uint32_t thresh16,
-                                                       float dscale, const uint64_t* seed_ptr, uint64_t salt) {
+                                                       float dscale, const uint64_t* seed_ptr, uint64_t salt, const int* __restrict__ rows_ptr) {
   constexpr int H = 256 * NC;
   const int l32 = threadIdx.x & 31;
+  if (rows_ptr) {                                  // device-side row count (<= rows): workgroups wholly past it leave at once
+    const long r_ = *rows_ptr;
+    rows = r_ < rows ? (r_ > 0 ? r_ : 1) : rows;
+    if ((long)blockIdx.x * 8 >= rows) return;
+  }
   long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
   const bool live = row < rows;
   if (!live) row = rows - 1;                       // the partner half-wave still needs every lane for the reductions
@@ -277,8 +284,9 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
                                                      bf16* __restrict__ dz_o, bf16* __restrict__ dx_o,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H,
                                                      uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt,
-                                                     int drop_on_dy, float* __restrict__ dxsum) {
+                                                     int drop_on_dy, float* __restrict__ dxsum, const int* __restrict__ rows_ptr) {
   __shared__ float red[4][NC * 256];
+  if (rows_ptr) { const long r_ = *rows_ptr; rows = r_ < rows ? r_ : rows; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float gsum[NC][4], bsum[NC][4], xsum[NC][4];   // xsum: column sums of dx = bias gradient of the dense layer that produced x
 #pragma unroll
@@ -704,21 +712,21 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
 
 extern "C" int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* zout,
                            float* mean, float* rstd, long rows, int H, float eps, float dropout_p,
-                           const uint64_t* seed_ptr, uint64_t salt, hipStream_t stream) {
+                           const uint64_t* seed_ptr, uint64_t salt, const int* rows_dev, hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_fwd: rows=%ld H=%d (need H%%4==0, H<=1024)", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_fwd: dropout needs a device seed");
   const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
   const float ds = 1.f / (1.f - dropout_p);
 #define LN_FWD16(NC)                                                                                                          \
   hipLaunchKernelGGL(ln_fwd16_kernel<NC>, dim3((rows + 7) / 8), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, gamma, \
-                     beta, (bf16*)y, (bf16*)zout, mean, rstd, rows, eps, th, ds, seed_ptr, salt)
+                     beta, (bf16*)y, (bf16*)zout, mean, rstd, rows, eps, th, ds, seed_ptr, salt, rows_dev)
   if (H == 768) LN_FWD16(3);
   else if (H == 1024) LN_FWD16(4);
   else if (H == 512) LN_FWD16(2);
   else if (H == 256) LN_FWD16(1);
   else
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, gamma, beta,
-                       (bf16*)y, (bf16*)zout, mean, rstd, rows, H, eps, th, ds, seed_ptr, salt);
+                       (bf16*)y, (bf16*)zout, mean, rstd, rows, H, eps, th, ds, seed_ptr, salt, rows_dev);
 #undef LN_FWD16
   SPMM_LAUNCH_CHECK("spmm_ln_fwd");
   return SPMM_OK;
@@ -747,7 +755,8 @@ extern "C" int spmm_quant_rows_fp8(const void* x, int x_is_f32, long ldx, long r
 
 extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H,
-                           float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, hipStream_t stream) {
+                           float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, const int* rows_dev,
+                           hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_bwd: rows=%ld H=%d", rows, H);
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
@@ -758,7 +767,7 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   const bool hot = !dy2 && dx && dgamma && dbeta && dxsum && th && !drop_on_dy;
 #define LN_BWD_LAUNCH(NC, EX, HOT)                                                                                                \
   hipLaunchKernelGGL((ln_bwd_kernel<NC, EX, HOT>), dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, \
-                     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum)
+                     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum, rows_dev)
   if (H == 768 && hot) LN_BWD_LAUNCH(3, true, true);
   else if (H <= 768) LN_BWD_LAUNCH(3, false, false);
   else LN_BWD_LAUNCH(4, false, false);

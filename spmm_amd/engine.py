@@ -80,6 +80,7 @@ class SelfKV:
     key / value weights; a group's sequence s owns skv_len[s] rows from row skv_row0[s] of x.  Backward writes d(loss)/dx into `dx`."""
     x: torch.Tensor
     dx: Optional[torch.Tensor] = None
+    rows_dev: Optional[torch.Tensor] = None      # device-side row count of x (int32 [1]) when only the device knows it
 
 
 @dataclass
@@ -171,6 +172,7 @@ class Engine:
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
+        self._dyn = None                  # (rows a batch is allocated for, int32 [1] device tensor with the rows it really has): step.py, fusion batch
         self.tape = None
         self.last32 = None
         E, Q = cfg.embed_dim, cfg.queue_size
@@ -197,6 +199,13 @@ class Engine:
     def _on(side):
         return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
+    def _md(self, t):
+        """Device-side row count for launches over the batch `t` belongs to (None: its host-side row count is exact).  The fusion batch of
+        the packed path ends with the text hard negatives drawn on the device: their total length -- and so the batch's row count -- is
+        device data; the batch is allocated for the most it can be and every launch over it takes the real count from device memory."""
+        d = self._dyn
+        return d[1] if (d is not None and t.shape[0] == d[0]) else None
+
     def _new(self, *shape, dtype=BF):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
@@ -216,7 +225,7 @@ class Engine:
     def _wT(self, key, src_fp32):
         return self.P.wT(key, src_fp32)
 
-    def _wgrad(self, dY, X, gW, gb=None, inline=False):
+    def _wgrad(self, dY, X, gW, gb=None, inline=False, md=None):
         """gW[N,K] += dY[M,N]^T X[M,K] ; gb[N] += column sums of dY (TN GEMM: no transposed copies).
         Nothing on the backward's critical path reads a weight gradient, so (unless `inline`) the two launches go to a side stream
         behind an event on the current one: they fill the CUs the data-gradient chain leaves idle (attention / LayerNorm backward,
@@ -224,18 +233,19 @@ class Engine:
         `wgrad_join()` makes the current stream wait for it (before a layer's gradient exchange, before the optimiser)."""
         ws = None if inline else self._wgrad_side()
         C = gW.view(dY.shape[1], X.shape[1])
+        md = self._md(dY) if md is None else md
         if ws is None:
             if gb is not None:
-                ops.colsum_bf16(dY, gb)
-            ops.gemm_tn(dY, X, C)
+                ops.colsum_bf16(dY, gb, R_dev=md)
+            ops.gemm_tn(dY, X, C, M_dev=md)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         ws.wait_event(ev)
         with torch.cuda.stream(ws):
             if gb is not None:
-                ops.colsum_bf16(dY, gb)
-            ops.gemm_tn(dY, X, C)
+                ops.colsum_bf16(dY, gb, R_dev=md)
+            ops.gemm_tn(dY, X, C, M_dev=md)
         # The operands must outlive the side stream's use of them.  They are simply kept referenced until the next join
         # (`record_stream` on ~100 tensors per step makes the caching allocator poll events on every allocation).
         self._wg_keep.append((dY, X))
@@ -281,7 +291,7 @@ class Engine:
         """y = LN(dropout(x) + residual): the residual is X (bf16) or, with the fp32 residual stream (EngineOptions.resid_fp32), X32;
         returns the fp32 twin of y in that mode (None otherwise)."""
         if X32 is None:
-            ops.ln_fwd(x, X, gamma, beta, y, **kw)
+            ops.ln_fwd(x, X, gamma, beta, y, rows_dev=self._md(x), **kw)
             return None
         y32 = self._new(*y.shape, dtype=torch.float32)
         ops.ln_fwd_r32(x, X32, gamma, beta, y, y32=y32, **kw)
@@ -298,10 +308,10 @@ class Engine:
         rstd = self._new(M, dtype=torch.float32) if save else None
         salt = self._next_salt()
         if X32 is None and self.opt.fuse_drop_res and ops.gemm_nt_drop_ok(M, H, A.shape[1]):
-            ops.gemm_nt_drop(A, Wb, x, bias=bias, R=resid, dropout_p=ph, seed=self.seed, salt=salt)
-            ops.ln_fwd(x, None, gamma, beta, y, mean=mean, rstd=rstd, eps=eps)
+            ops.gemm_nt_drop(A, Wb, x, bias=bias, R=resid, dropout_p=ph, seed=self.seed, salt=salt, M_dev=self._md(A))
+            ops.ln_fwd(x, None, gamma, beta, y, mean=mean, rstd=rstd, eps=eps, rows_dev=self._md(A))
             return y, x, mean, rstd, salt, None
-        ops.gemm_nt(A, Wb, x, bias=bias)
+        ops.gemm_nt(A, Wb, x, bias=bias, M_dev=self._md(A))
         y32 = self._ln_res(x, resid, X32, gamma, beta, y, zout=x if save else None, mean=mean, rstd=rstd, eps=eps, dropout_p=ph, seed=self.seed, salt=salt)
         return y, x, mean, rstd, salt, y32
 
@@ -316,7 +326,7 @@ class Engine:
             Wqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "weight")
             bqkv = P.fused(pfx + ".self.", ("query", "key", "value"), "bias", what="w")
             QKV = self._new(M, 3 * H)
-            ops.gemm_nt(X, Wqkv, QKV, bias=bqkv)
+            ops.gemm_nt(X, Wqkv, QKV, bias=bqkv, M_dev=self._md(X))
             sv["QKV"] = QKV
             skv = sv["SKV"] = {}                                 # K/V of the groups' private self-attention sources (SelfKV), one GEMM each
             for g in groups:
@@ -327,7 +337,8 @@ class Engine:
                     # query rows = a subset of their sequences' rows (here: position 0 only); keys / values = every token of the
                     # sequence, projected from the layer input with the key / value rows of the fused weight
                     if id(g.self_src) not in skv:
-                        skv[id(g.self_src)] = ops.gemm_nt(g.self_src.x, Wqkv[H:], self._new(g.self_src.x.shape[0], 2 * H), bias=bqkv[H:])
+                        skv[id(g.self_src)] = ops.gemm_nt(g.self_src.x, Wqkv[H:], self._new(g.self_src.x.shape[0], 2 * H), bias=bqkv[H:],
+                                                          M_dev=g.self_src.rows_dev)
                     KVs = skv[id(g.self_src)]
                     self._attn_fwd(QKV[r, :H], KVs[:, :H], KVs[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.skv_L,
                                    kmask=None, causal_from=g.nseq, dropout_p=pa, seed=self.seed, salt=salt,
@@ -340,12 +351,12 @@ class Engine:
                 sv["salt_a"].append(salt)
         else:
             Qc = self._new(M, H)
-            ops.gemm_nt(X, P.wb(pfx + ".self.query.weight"), Qc, bias=P.w(pfx + ".self.query.bias"))
+            ops.gemm_nt(X, P.wb(pfx + ".self.query.weight"), Qc, bias=P.w(pfx + ".self.query.bias"), M_dev=self._md(X))
             Wkv = P.fused(pfx + ".self.", ("key", "value"), "weight")
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
             shared = {}                                          # K/V of a shared source: projected once per layer
-            fused = self.opt.fused_xattn and X32 is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
+            fused = self.opt.fused_xattn and X32 is None and self._md(X) is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
             if fused:
                 # ONE launch per group for core + output projection + dropout + residual + LayerNorm (csrc/xattn.hip); the salts are
                 # drawn in the composite's order (every group's attention salt, then the hidden one): both forms draw the same masks
@@ -420,10 +431,10 @@ class Engine:
         dx = self._new(M, H) if ph > 0 else dz
         ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + ".output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(pfx + ".output.LayerNorm.weight"), dbeta=P.g(pfx + ".output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt_h"], dxsum=P.g(pfx + ".output.dense.bias"))
+                   seed=self.seed, salt=sv["salt_h"], dxsum=P.g(pfx + ".output.dense.bias"), rows_dev=self._md(dY))
         self._wgrad(dx, sv["ctx"], P.g(pfx + ".output.dense.weight"))
         dctx = self._new(M, H)
-        ops.gemm_nt(dx, self._wT(pfx + ".output.dense", P.w(pfx + ".output.dense.weight")), dctx)
+        ops.gemm_nt(dx, self._wT(pfx + ".output.dense", P.w(pfx + ".output.dense.weight")), dctx, M_dev=self._md(dx))
         dX = self._new(M, H)
         if not sv["cross"]:
             QKV = sv["QKV"]
@@ -449,9 +460,9 @@ class Engine:
             self._wgrad(dQKV, X, gWqkv, gbqkv)
             WT = self._wT(pfx + ".self.qkv", P.fused(pfx + ".self.", ("query", "key", "value"), "weight", what="w"))
             for src, dKVs in dskv.values():                      # key / value projections of the private sources: weight and data gradient
-                self._wgrad(dKVs, src.x, gWqkv[H:], gbqkv[H:])
-                ops.gemm_nt(dKVs, WT[:, H:], src.dx)
-            ops.gemm_nt(dQKV, WT, dX, R=dz)
+                self._wgrad(dKVs, src.x, gWqkv[H:], gbqkv[H:], md=src.rows_dev)
+                ops.gemm_nt(dKVs, WT[:, H:], src.dx, M_dev=src.rows_dev)
+            ops.gemm_nt(dQKV, WT, dX, R=dz, M_dev=self._md(dQKV))
         else:
             Qc = sv["Qc"]
             dQc = self._new(M, H)
@@ -484,7 +495,7 @@ class Engine:
                 self._wgrad(dKVu, src.kv, gWkv, gbkv)
                 ops.gemm_nt(dKVu, WkvT, dkv_acc[id(src)], epi=ops.EPI_F32_ACC)
             self._wgrad(dQc, X, P.g(pfx + ".self.query.weight"), P.g(pfx + ".self.query.bias"))
-            ops.gemm_nt(dQc, self._wT(pfx + ".self.query", P.w(pfx + ".self.query.weight")), dX, R=dz)
+            ops.gemm_nt(dQc, self._wT(pfx + ".self.query", P.w(pfx + ".self.query.weight")), dX, R=dz, M_dev=self._md(dQc))
         return dX
 
     # ------------------------------------------------------------------------------------------------- layers
@@ -500,7 +511,7 @@ class Engine:
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
         u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN and H % 128 == 0 and I % 128 == 0     # (the 8-phase kernel's shapes)
         dact = (self._new(M, I, dtype=torch.uint8) if u8 else self._new(M, I)) if save else None
-        fp8 = self.fp8 and H % 256 == 0 and I % 256 == 0
+        fp8 = self.fp8 and H % 256 == 0 and I % 256 == 0 and self._md(a) is None
         x = self._new(M, H) if fp8 else None
         if fp8:
             # fp8 tier (BASELINE configs[4]): both FFN GEMMs of the forward read E4M3 operands with per-row scales (activations
@@ -514,7 +525,7 @@ class Engine:
             ops.gemm_nt_f8(h8, sh, w8, sw, x, bias=P.w(lp + "output.dense.bias"))
         else:
             ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"),
-                        epi=(ops.EPI_GELU_DERIV8 if u8 else ops.EPI_GELU_DERIV) if save else ops.EPI_GELU, C2=dact)
+                        epi=(ops.EPI_GELU_DERIV8 if u8 else ops.EPI_GELU_DERIV) if save else ops.EPI_GELU, C2=dact, M_dev=self._md(a))
         if fp8:
             y = self._new(M, H)
             mean = self._new(M, dtype=torch.float32) if save else None
@@ -536,14 +547,15 @@ class Engine:
         dx = self._new(M, H) if ph > 0 else dz
         ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(lp + "output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(lp + "output.LayerNorm.weight"), dbeta=P.g(lp + "output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"))
+                   seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"), rows_dev=self._md(dY))
         self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
         ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre,
-                    epi=ops.EPI_MUL8 if sv["dact"].dtype == torch.uint8 else ops.EPI_MUL, G=sv["dact"], colsum=P.g(lp + "intermediate.dense.bias"))
+                    epi=ops.EPI_MUL8 if sv["dact"].dtype == torch.uint8 else ops.EPI_MUL, G=sv["dact"], colsum=P.g(lp + "intermediate.dense.bias"),
+                    M_dev=self._md(dx))
         self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"))
         da = self._new(M, H)
-        ops.gemm_nt(dpre, self._wT(lp + "intermediate.dense", P.w(lp + "intermediate.dense.weight")), da, R=dz)
+        ops.gemm_nt(dpre, self._wT(lp + "intermediate.dense", P.w(lp + "intermediate.dense.weight")), da, R=dz, M_dev=self._md(dpre))
         if sv["cross"] is not None:
             da = self._attn_block_bwd(lp + "crossattention", c, sv["cross"], da, groups, dkv_acc)
         return self._attn_block_bwd(lp + "attention", c, sv["att"], da, groups, None)

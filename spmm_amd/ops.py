@@ -80,7 +80,24 @@ class nt_tiles_per_workgroup:
         return False
 
 
-def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None, kernel=0):
+# Timing experiment (tools/fp8_bound.sh, EXPERIMENTS.md 3.5; NOT a product path, results are garbage): every NT GEMM whose epilogue the E4M3
+# kernel has (plain / +R / GELU + derivative) runs on it with the BYTES of its bf16 operands reinterpreted as fp8 -- no quantisation pass,
+# no extra memory -- which prices "all forward and data-gradient GEMMs in fp8 with free quantisation": an upper bound for the fp8 tier.
+_FP8_TIMING = os.environ.get("SPMM_FP8_TIMING_EXPERIMENT") == "1"
+_f8_ones = {}
+
+
+def _gemm_nt_f8_timing(A, W, C, bias, epi, R, C2, K):
+    M, N = A.shape[0], W.shape[0]
+    one = _f8_ones.get(A.device)
+    if one is None or one.numel() < max(M, N):
+        one = _f8_ones[A.device] = torch.full((max(M, N, 1 << 18),), 1e-3, dtype=torch.float32, device=A.device)
+    gemm_nt_f8(A.view(torch.uint8)[:, :K], one[:M], W.view(torch.uint8)[:, :K], one[:N], C, bias=bias, epi=epi, R=R, C2=C2)
+    return C
+
+
+def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None, kernel=0,
+            M_dev=None):
     """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride).  kernel: 0 = chosen from the shape,
     1 / 2 / 3 / 8 / 9 force a tile kernel (SPMM_GEMM_* in include/spmm_hip.h)."""
     if kernel == 0:
@@ -95,9 +112,12 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
         assert epi != EPI_MUL8 or G.dtype == torch.uint8
     else:
         assert C.dtype == torch.float32
+    if (_FP8_TIMING and M_dev is None and epi in (EPI_BF16, EPI_GELU_DERIV) and K % 256 == 0 and N % 8 == 0 and M >= 4096 and div is None and colsum is None
+            and alpha == 1.0 and splits == 1 and C.stride(1) == 1):
+        return _gemm_nt_f8_timing(A, W, C, bias, epi, R, C2, K)
     _call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
                float(alpha), _p(R), 0 if R is None else _row_stride(R), _p(G), 0 if G is None else _row_stride(G),
-               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), int(kernel), _st())
+               _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), int(kernel), _p(M_dev), _st())
     return C
 
 
@@ -106,18 +126,18 @@ def gemm_nt_drop_ok(M, N, K):
     return bool(M >= 6000 and K % 128 == 0 and N % 8 == 0) if _DRY_RUN else bool(lib().cdll.spmm_gemm_nt_drop_ok(int(M), int(N), int(K)))
 
 
-def gemm_nt_drop(A, W, C, *, bias, R, dropout_p=0.0, seed=None, salt=0):
+def gemm_nt_drop(A, W, C, *, bias, R, dropout_p=0.0, seed=None, salt=0, M_dev=None):
     """C = dropout(bf16(A @ W^T + bias)) + R in the GEMM's epilogue (the projection in front of a residual LayerNorm: ln_fwd then reads C
     alone); the mask is the one ln_fwd / ln_bwd draw for the same (seed, salt)."""
     M, K = A.shape
     N = W.shape[0]
     assert A.dtype == BF16 and W.dtype == BF16 and C.dtype == BF16 and R.dtype == BF16 and W.shape[1] >= K and tuple(C.shape) == (M, N) and tuple(R.shape) == (M, N)
     _call("spmm_gemm_nt_drop", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, _p(bias), _p(R), _row_stride(R), _p(C), _row_stride(C),
-          float(dropout_p), _p(seed), salt, int(_nt_auto), _st())
+          float(dropout_p), _p(seed), salt, int(_nt_auto), _p(M_dev), _st())
     return C
 
 
-def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0):
+def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0, M_dev=None):
     """C[N,K] (fp32) += alpha * A[M,N]^T @ B[M,K]  -- weight gradients straight from token-major activations.
     kernel: 0 = chosen from the shape, 1 = 128x128 tiles, 8 = 256x256 8-phase (N, K multiples of 8)."""
     M, N = A.shape
@@ -127,13 +147,13 @@ def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0):
         splits = 1 if _DRY_RUN else lib().cdll.spmm_gemm_tn_splits(M, N, K, int(kernel))
     ws = torch.empty(splits * N * K, dtype=torch.float32, device=C.device) if splits > 1 else None
     _call("spmm_gemm_tn", _p(A), _row_stride(A), _p(B), _row_stride(B), M, N, K, splits, float(alpha), _p(C), _row_stride(C), _p(ws),
-          int(kernel), _st())
+          int(kernel), _p(M_dev), _st())
     return C
 
 
-def colsum_bf16(x, out):
+def colsum_bf16(x, out, *, R_dev=None):
     R, C = x.shape
-    _call("spmm_colsum_bf16", _p(x), _row_stride(x), R, C, _p(out), _st())
+    _call("spmm_colsum_bf16", _p(x), _row_stride(x), R, C, _p(out), _p(R_dev), _st())
     return out
 
 
@@ -183,10 +203,10 @@ def xattn_fwd(Q, K, V, WoF, bo, R, gamma, beta, Y, *, nseq, nH, Lq, Lkv, eps=1e-
     return Y
 
 
-def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0):
+def ln_fwd(x, res, gamma, beta, y, *, zout=None, mean=None, rstd=None, eps=1e-12, dropout_p=0.0, seed=None, salt=0, rows_dev=None):
     rows, H = x.shape
     _call("spmm_ln_fwd", _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(zout), _p(mean), _p(rstd), rows, H, float(eps),
-               float(dropout_p), _p(seed), salt, _st())
+               float(dropout_p), _p(seed), salt, _p(rows_dev), _st())
     return y
 
 
@@ -201,10 +221,10 @@ def ln_fwd_r32(x, res32, gamma, beta, y, *, y32=None, zout=None, mean=None, rstd
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbeta=None, dropout_p=0.0, seed=None, salt=0,
-           drop_on_dy=False, dxsum=None):
+           drop_on_dy=False, dxsum=None, rows_dev=None):
     rows, H = dy.shape
     _call("spmm_ln_bwd", _p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
-               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _p(dxsum), _st())
+               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _p(dxsum), _p(rows_dev), _st())
     return dz
 
 
@@ -322,25 +342,25 @@ def pack_plan(mask32, M, bad):
     return dict(M=M, rows=rows, row0=i32[B:], row0_64=row0_64, len=i32[:B], gidx2=gidx2, gidx4=gidx4, inv=inv)
 
 
-FUSION_SMALL = dict(ar=(0, 1), kvidx_pv=(1, 3), kvidx_tp=(4, 2), kvidx_td=(6, 2), kvidx_ctx=(8, 3), qrow0_tp=(11, 2), qlen_tp=(13, 2),
-                    skv_row0_pv=(15, 3), skv_len_pv=(18, 3), skv_row0_tx=(21, 3), skv_len_tx=(24, 3), start_t=(27, 2), list_t=(29, 4),
-                    start_p=(33, 2), list_p=(35, 4))          # (offset, length) in units of B: the layout csrc/plan.hip writes
+FUSION_SMALL = dict(ar=(0, 1), kvidx_pv=(1, 3), kvidx_tp=(4, 2), qrow0_tp=(6, 2), qlen_tp=(8, 2), row0_8=(10, 1), len_8=(11, 1),
+                    skv_row0_pv=(12, 3), skv_len_pv=(15, 3), skv_row0_tx=(18, 2), skv_len_tx=(20, 2), start_t=(22, 2), list_t=(24, 4),
+                    start_p=(28, 2), list_p=(30, 4))          # (offset, length) in units of B: the layout csrc/plan.hip writes; then rows_dev[2]
 
 
-def fusion_plan(neg, pk, mask32, Lp):
-    """Index arrays of the fusion batch from the sampled negatives (csrc/plan.hip::fusion_plan_kernel) -> dict of views."""
-    B, Lt = mask32.shape
-    M, dev = pk["M"], mask32.device
-    R6 = 4 * B * Lp + 2 * M + 2 * B * Lt
+def fusion_plan(neg, pk, Lp):
+    """Index arrays of the fusion batch from the sampled negatives (csrc/plan.hip::fusion_plan_kernel) -> dict of views.  `Rcap` = rows the
+    batch is allocated for; `rows_dev` / `mn_dev` (int32 [1] device views) = rows it really has / rows of the packed text negatives."""
+    B = pk["len"].numel()
+    Lt = (pk["inv"].numel() // 2) // B
+    M, dev = pk["M"], neg.device
+    Rcap = 4 * B * Lp + 2 * M + 2 * B * Lt
     ntop = 6 * B + B * Lt + B * Lp
     alloc = torch.zeros if _DRY_RUN else torch.empty
-    i64 = alloc(R6 + B * Lt + ntop, dtype=torch.int64, device=dev)
-    idx6, neg_rows, idx_top = i64[:R6], i64[R6:R6 + B * Lt], i64[R6 + B * Lt:]
-    maskcat = alloc(2 * B, Lt, dtype=torch.int32, device=dev)
-    small = alloc(39 * B, dtype=torch.int32, device=dev)
-    _call("spmm_fusion_plan", _p(neg), _p(pk["len"]), _p(pk["row0"]), _p(mask32), B, Lt, Lp, M, _p(idx6), _p(maskcat), _p(neg_rows), _p(idx_top),
-          _p(small), _st())
-    out = dict(idx6=idx6, neg_rows=neg_rows, idx_top=idx_top, maskcat=maskcat, R6=R6)
+    i64 = alloc(Rcap + B * Lt + ntop, dtype=torch.int64, device=dev)
+    idx6, neg_rows, idx_top = i64[:Rcap], i64[Rcap:Rcap + B * Lt], i64[Rcap + B * Lt:]
+    small = alloc(35 * B, dtype=torch.int32, device=dev)
+    _call("spmm_fusion_plan", _p(neg), _p(pk["len"]), _p(pk["row0"]), B, Lt, Lp, M, _p(idx6), _p(neg_rows), _p(idx_top), _p(small), _st())
+    out = dict(idx6=idx6, neg_rows=neg_rows, idx_top=idx_top, Rcap=Rcap, rows_dev=small[34 * B:34 * B + 1], mn_dev=small[34 * B + 1:34 * B + 2])
     for k, (o, n) in FUSION_SMALL.items():
         out[k] = small[o * B:(o + n) * B]
     out["start_t"], out["start_p"] = out["start_t"][:B + 1], out["start_p"][:B + 1]

@@ -44,34 +44,46 @@ class PretrainStep(Engine):
         layer their other rows matter only as self-attention keys / values: that layer runs on [6B position-0 rows | every row of the LM
         pass | every row of the causal PV pass], the position-0 queries attending keys / values projected from the full sequences
         (engine.SelfKV).  Exact: the rows left out reach no loss, and their gradients are exactly zero in the reference too.
-        Every index array comes from ONE launch (spmm_fusion_plan); the batch and the top layer's input are two row gathers.
-        Batch layout (csrc/plan.hip): [PV queries pe | pe[neg] | pe] [text packed te | te] [text negatives, dense] [LM pass] [causal PV]."""
+        Batch layout (csrc/plan.hip): [PV queries pe | pe[neg] | pe] [text packed te | te] [LM pass] [causal PV] [text negatives, PACKED].
+        Which sequences were drawn as text negatives is device data, so the LENGTH of that last part -- and with it the batch's row count --
+        is known only on the device: the batch is allocated for B x Lt such rows and every launch over it reads the real row count from
+        device memory (`Engine._dyn`, "device-side row counts" in include/spmm_hip.h): no padding row is computed, no host read sizes
+        anything.  Every index array comes from ONE launch (spmm_fusion_plan); the batch and the top layer's input are two row gathers."""
         cfg = self.cfg
         ct = cfg.text
         H, Lp, f, n = ct.hidden_size, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
-        fp = ops.fusion_plan(neg, pk, mask32, Lp)
+        fp = ops.fusion_plan(neg, pk, Lp)
         o_tp = 3 * B * Lp
-        o_tn = o_tp + 2 * M
-        o_lm = o_tn + B * Lt
+        o_lm = o_tp + 2 * M
         o_12 = o_lm + B * Lt
-        X6 = ops.gather_rows2(self._new(fp["R6"], H), y1, fp["idx6"], y2)
+        o_8 = o_12 + B * Lp
+        Rcap = fp["Rcap"]
+        X6 = ops.gather_rows2(self._new(Rcap, H), y1, fp["idx6"], y2)
         src_pv = KVSource(prop_embeds.view(B * Lp, H), B, Lp).preset(4 * B, fp["start_p"], fp["list_p"])
         src_text = KVSource(text_embeds, B, Lt, row0=pk["row0"], length=pk["len"], pack_idx=pk["rows"]).preset(4 * B, fp["start_t"], fp["list_t"])
+        ar = fp["ar"]
         g_lo = [Group(0, 3 * B, Lp, None, 3 * B).bind(src_text, fp["kvidx_pv"], 0),
                 Group(o_tp, 2 * B, Lt, None, 2 * B, q_row0=fp["qrow0_tp"], q_len=fp["qlen_tp"], nrows=2 * M).bind(src_pv, fp["kvidx_tp"], 0),
-                Group(o_tn, 2 * B, Lt, fp["maskcat"], B).bind(src_pv, fp["kvidx_td"], 2 * B),
-                Group(o_12, B, Lp, None, 0).bind(src_text, fp["ar"], 3 * B)]
-        y, tape_lo = self.stack_fwd("text_encoder.bert.", ct, range(f, n - 1), True, X6, g_lo, save)
+                Group(o_lm, B, Lt, mask32, 0).bind(src_pv, ar, 2 * B),
+                Group(o_12, B, Lp, None, 0).bind(src_text, ar, 3 * B),
+                Group(o_8, B, Lt, None, B, q_row0=fp["row0_8"], q_len=fp["len_8"], nrows=B * Lt).bind(src_pv, ar, 3 * B)]
+        self._dyn = (Rcap, fp["rows_dev"])
+        try:
+            y, tape_lo = self.stack_fwd("text_encoder.bert.", ct, range(f, n - 1), True, X6, g_lo, save)
+        finally:
+            self._dyn = None
         ntop = 6 * B + B * Lt + B * Lp
         Xtop = ops.gather_rows2(self._new(ntop, H), y, fp["idx_top"])
-        skv = SelfKV(y[:o_lm])
-        g_top = [Group(0, 3 * B, 1, None, 3 * B, self_src=skv, skv_row0=fp["skv_row0_pv"], skv_len=fp["skv_len_pv"], skv_L=Lp).bind(src_text, fp["kvidx_pv"], 0),
-                 Group(3 * B, 3 * B, 1, None, 3 * B, self_src=skv, skv_row0=fp["skv_row0_tx"], skv_len=fp["skv_len_tx"], skv_L=Lt).bind(src_pv, fp["kvidx_ctx"], 0),
-                 Group(6 * B, B, Lt, mask32, 0).bind(src_pv, fp["ar"], 3 * B),
-                 Group(6 * B + B * Lt, B, Lp, None, 0).bind(src_text, fp["ar"], 3 * B)]
+        skv_a = SelfKV(y[:o_lm])                                # rows of the PV and packed-text ITM sequences
+        skv_b = SelfKV(y[o_8:], rows_dev=fp["mn_dev"])          # rows of the packed text negatives (device-side count)
+        g_top = [Group(0, 3 * B, 1, None, 3 * B, self_src=skv_a, skv_row0=fp["skv_row0_pv"], skv_len=fp["skv_len_pv"], skv_L=Lp).bind(src_text, fp["kvidx_pv"], 0),
+                 Group(3 * B, 2 * B, 1, None, 2 * B, self_src=skv_a, skv_row0=fp["skv_row0_tx"], skv_len=fp["skv_len_tx"], skv_L=Lt).bind(src_pv, fp["kvidx_tp"], 0),
+                 Group(5 * B, B, 1, None, B, self_src=skv_b, skv_row0=fp["row0_8"], skv_len=fp["len_8"], skv_L=Lt).bind(src_pv, ar, 3 * B),
+                 Group(6 * B, B, Lt, mask32, 0).bind(src_pv, ar, 2 * B),
+                 Group(6 * B + B * Lt, B, Lp, None, 0).bind(src_text, ar, 3 * B)]
         ytop, sv_top, _ = self._layer_fwd(f"text_encoder.bert.encoder.layer.{n - 1}.", ct, True, Xtop, g_top, save)
-        return dict(fp=fp, ytop=ytop, sv_top=sv_top, g_top=g_top, skv=skv, g_lo=g_lo, tape_lo=tape_lo, src_text=src_text, src_pv=src_pv,
-                    o_tp=o_tp, o_tn=o_tn, o_lm=o_lm, o_12=o_12, ntop=ntop)
+        return dict(fp=fp, ytop=ytop, sv_top=sv_top, g_top=g_top, skv=(skv_a, skv_b), g_lo=g_lo, tape_lo=tape_lo, src_text=src_text, src_pv=src_pv,
+                    o_tp=o_tp, o_lm=o_lm, o_12=o_12, o_8=o_8, ntop=ntop, Rcap=Rcap)
 
     def _s6_backward_cls(self, T, dYtop, d_pe, d_te):
         """Backward of `_s6_forward_cls`: dYtop = d(loss)/d(top layer output) on its [6B | B Lt | B Lp] rows -> d(loss)/d(batch rows)."""
@@ -79,16 +91,21 @@ class PretrainStep(Engine):
         cfg = self.cfg
         ct = cfg.text
         H, Lp, f, n = ct.hidden_size, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
-        fp, o_lm = S6["fp"], S6["o_lm"]
+        fp, o_lm, o_8 = S6["fp"], S6["o_lm"], S6["o_8"]
         dkv_acc = {id(S6["src_text"]): d_te[:M], id(S6["src_pv"]): d_pe.view(B * Lp, H)}
-        dX6 = self._new(fp["R6"], H)
-        S6["skv"].dx = dX6[:o_lm]                                # the ITM sequences' rows: gradient through the top layer's keys / values ...
+        dX6 = self._new(S6["Rcap"], H)
+        S6["skv"][0].dx = dX6[:o_lm]                             # the ITM sequences' rows: gradient through the top layer's keys / values ...
+        S6["skv"][1].dx = dX6[o_8:]
         dXtop = self._layer_bwd(f"text_encoder.bert.encoder.layer.{n - 1}.", ct, S6["sv_top"], dYtop, S6["g_top"], dkv_acc)
         if self.layer_done_cb is not None:
             self._layer_done(f"text_encoder.bert.encoder.layer.{n - 1}.")
         ops.add_rows_bf16(dX6, fp["idx_top"][:6 * B], dXtop[:6 * B])     # ... plus, at position 0, what came through the queries
-        dX6[o_lm:].copy_(dXtop[6 * B:])
-        return self.stack_bwd("text_encoder.bert.", ct, range(f, n - 1), S6["tape_lo"], dX6, S6["g_lo"], dkv_acc=dkv_acc)
+        dX6[o_lm:o_8].copy_(dXtop[6 * B:])
+        self._dyn = (S6["Rcap"], fp["rows_dev"])
+        try:
+            return self.stack_bwd("text_encoder.bert.", ct, range(f, n - 1), S6["tape_lo"], dX6, S6["g_lo"], dkv_acc=dkv_acc)
+        finally:
+            self._dyn = None
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, prop: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, *, mpm_mask: Optional[torch.Tensor] = None,
@@ -421,14 +438,14 @@ class PretrainStep(Engine):
             # ---- S6 backward; the cross-attention K/V data gradients land directly on the unique sources (KVSource)
             dX6 = self._s6_backward_cls(T, dYtop, d_pe, d_te)
             dXpv = dX6[:3 * B * Lp].view(3 * B, Lp * H)
-            dXt = dX6[S6["o_tp"]:]
+            dXt = dX6[S6["o_tp"]:S6["o_lm"]]
             ops.acc_rows(d_pe, dXpv[0:B])
             ops.acc_rows(d_pe, dXpv[B:2 * B], idx=neg_p, atomic=True)
             ops.acc_rows(d_pe, dXpv[2 * B:3 * B])
             ops.acc_rows(d_te[:M], dXt[:M])
             ops.acc_rows(d_te[:M], dXt[M:2 * M])
-            ops.acc_rows(d_te, dXt[2 * M:2 * M + B * Lt], idx=S6["fp"]["neg_rows"], atomic=True)   # (rows past a negative's length: skipped)
-            dXt_lm, dX12 = dX6[S6["o_lm"]:S6["o_12"]], dX6[S6["o_12"]:]
+            ops.acc_rows(d_te, dX6[S6["o_8"]:], idx=S6["fp"]["neg_rows"], atomic=True)       # packed negatives; rows past their count: skipped
+            dXt_lm, dX12 = dX6[S6["o_lm"]:S6["o_12"]], dX6[S6["o_12"]:S6["o_8"]]
         else:
             ditm = self._new(3 * B, H)
             ops.itm_head(T["ypv"], Lp * H, T["itm_text"], H, H, P.w("itm_head.weight"), P.w("itm_head.bias"), n=3 * B, B=B, losses=scratch,

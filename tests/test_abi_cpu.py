@@ -43,7 +43,7 @@ def test_bad_shape_is_reported_without_touching_the_gpu(built):
     from spmm_amd._lib import lib
     L = lib()
     with pytest.raises(RuntimeError, match="multiple of 64"):
-        L.call("spmm_gemm_nt", None, 8, None, 8, 16, 16, 100, 1, None, None, 1.0, None, 0, None, 0, None, 16, None, 0, 0, None, 0, None)
+        L.call("spmm_gemm_nt", None, 8, None, 8, 16, 16, 100, 1, None, None, 1.0, None, 0, None, 0, None, 16, None, 0, 0, None, 0, None, None)
     with pytest.raises(RuntimeError, match=r"must be in \[1,256\]"):
         L.call("spmm_attn_fwd", None, 64, None, 64, None, 64, None, None, None, None, None, None, None, 64, None, 1, 1, 300, 54, 1, 0, 0.0, None, 0, 0, 0, None)
     with pytest.raises(RuntimeError, match="SPMM_models.py:279"):

@@ -82,9 +82,9 @@ def test_step_schedule_dry_run(dry):
                    "spmm_ema_update", "spmm_grad_sqnorm", "spmm_adamw_step", "spmm_clamp_scalar", "spmm_l2norm_fwd", "spmm_l2norm_bwd"):
         assert needed in log, needed
     # 2 text layers (1 fusion) + 1 PV layer, packed text passes: S1 one group; S2 two (packed P2 | dense causal P10a);
-    # S6 = its top layer alone, four groups (position-0 rows of the PV / of the text ITM sequences | LM pass | causal PV pass), each
-    # with a self- and a cross-attention launch
-    assert log.count("spmm_attn_bwd") == 1 + 2 + 4 * 2
+    # S6 = its top layer alone, five groups (position-0 rows of the PV / of the packed-text / of the text-negative ITM sequences | LM pass |
+    # causal PV pass), each with a self- and a cross-attention launch
+    assert log.count("spmm_attn_bwd") == 1 + 2 + 5 * 2
     assert log.count("spmm_fusion_plan") == 1 and log.count("spmm_pack_plan") == 1
     assert log.count("spmm_segment_sum_bf16") == 2              # one fold per shared key/value source (text, PV) per fusion layer
     # autograd-boundary path

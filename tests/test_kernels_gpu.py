@@ -1378,8 +1378,9 @@ def test_pack_plan_matches_tensor_bookkeeping(ops, B, Lt):
 
 @pytest.mark.parametrize("B,Lt,Lp", [(4, 16, 6), (128, 128, 54), (8, 37, 54)])
 def test_fusion_plan_matches_tensor_bookkeeping(ops, B, Lt, Lp):
-    """Every index array of the fusion batch against the torch.cat / index_select construction it replaces; the two shared key / value
-    sources' inverse maps against KVSource.finalize()."""
+    """Every index array of the fusion batch against the torch.cat / index_select construction it replaces (the text negatives re-enter
+    PACKED at the end of the batch: their row count lives on the device); the two shared key / value sources' inverse maps against
+    KVSource.finalize()."""
     from spmm_amd.engine import KVSource
     g = torch.Generator().manual_seed(5 * B + Lt)
     lens = torch.randint(2, Lt + 1, (B,), generator=g); lens[0] = Lt
@@ -1388,30 +1389,27 @@ def test_fusion_plan_matches_tensor_bookkeeping(ops, B, Lt, Lp):
     pk = ops.pack_plan(mask, M, torch.zeros(1, dtype=torch.int32, device="cuda"))
     neg = torch.randint(0, B, (2 * B,), generator=g).cuda()
     neg_p, neg_t = neg[:B], neg[B:]
-    fp = ops.fusion_plan(neg, pk, mask, Lp)
+    fp = ops.fusion_plan(neg, pk, Lp)
     y1, y2 = rnd(2 * B * Lp, H, seed=1), rnd(M + B * Lt, H, seed=2)
-    X6 = ops.gather_rows2(torch.empty(fp["R6"], H, dtype=BF, device="cuda"), y1, fp["idx6"], y2)
+    X6 = ops.gather_rows2(torch.empty(fp["Rcap"], H, dtype=BF, device="cuda"), y1, fp["idx6"], y2)
     pe, pc, te, h10 = y1[:B * Lp].view(B, Lp * H), y1[B * Lp:], y2[:M], y2[M:]
     ar = torch.arange(B, device="cuda")
-    mask_neg = mask[neg_t]
-    neg_rows = pk["row0_64"][neg_t][:, None] + torch.arange(Lt, device="cuda")[None, :]
-    neg_rows = torch.where(mask_neg.bool(), neg_rows, torch.full_like(neg_rows, M)).view(-1)
-    te_neg = torch.cat([te, torch.zeros(1, H, dtype=BF, device="cuda")])[neg_rows]
-    ref = torch.cat([pe, pe[neg_p], pe], 0).view(-1, H)
-    ref = torch.cat([ref, te, te, te_neg, h10, pc])
-    assert torch.equal(X6, ref)
-    assert torch.equal(fp["neg_rows"], torch.where(neg_rows < M, neg_rows, torch.full_like(neg_rows, -1)))
-    assert torch.equal(fp["maskcat"], torch.cat([mask_neg, mask]))
+    len8 = pk["len"][neg_t].long()
+    row8 = torch.cumsum(len8, 0) - len8
+    Mn = int(len8.sum())
+    src_rows = torch.cat([pk["row0_64"][neg_t[s]] + torch.arange(int(len8[s]), device="cuda") for s in range(B)])      # row of te behind every packed negative row
+    ref = torch.cat([torch.cat([pe, pe[neg_p], pe], 0).view(-1, H), te, te, h10, pc, te[src_rows]])
+    o_tp = 3 * B * Lp; o_lm = o_tp + 2 * M; o_12 = o_lm + B * Lt; o_8 = o_12 + B * Lp
+    assert fp["Rcap"] == o_8 + B * Lt and int(fp["rows_dev"]) == o_8 + Mn and int(fp["mn_dev"]) == Mn
+    assert torch.equal(X6[:o_8 + Mn], ref) and float(X6[o_8 + Mn:].float().abs().max() if Mn < B * Lt else 0.0) == 0.0
+    assert torch.equal(fp["neg_rows"][:Mn], src_rows) and bool((fp["neg_rows"][Mn:] == -1).all())
     i32 = lambda t: t.to(torch.int32)
-    assert torch.equal(fp["ar"], i32(ar)) and torch.equal(fp["kvidx_pv"], i32(torch.cat([ar, ar, neg_t])))
-    assert torch.equal(fp["kvidx_tp"], i32(torch.cat([ar, neg_p]))) and torch.equal(fp["kvidx_td"], i32(torch.cat([ar, ar])))
-    assert torch.equal(fp["kvidx_ctx"], i32(torch.cat([ar, neg_p, ar])))
+    assert torch.equal(fp["ar"], i32(ar)) and torch.equal(fp["kvidx_pv"], i32(torch.cat([ar, ar, neg_t]))) and torch.equal(fp["kvidx_tp"], i32(torch.cat([ar, neg_p])))
     assert torch.equal(fp["qrow0_tp"], torch.cat([pk["row0"], pk["row0"] + M])) and torch.equal(fp["qlen_tp"], torch.cat([pk["len"], pk["len"]]))
-    o_tp = 3 * B * Lp; o_tn = o_tp + 2 * M; o_lm = o_tn + B * Lt
+    assert torch.equal(fp["row0_8"], i32(row8)) and torch.equal(fp["len_8"], i32(len8))
     assert torch.equal(fp["skv_row0_pv"], i32(torch.arange(3 * B, device="cuda") * Lp)) and bool((fp["skv_len_pv"] == Lp).all())
-    assert torch.equal(fp["skv_row0_tx"], torch.cat([o_tp + pk["row0"], o_tp + M + pk["row0"], i32(o_tn + ar * Lt)]))
-    assert torch.equal(fp["skv_len_tx"], torch.cat([pk["len"], pk["len"], pk["len"][neg_t]]))
-    top = torch.cat([torch.arange(3 * B, device="cuda") * Lp, o_tp + pk["row0_64"], o_tp + M + pk["row0_64"], o_tn + ar * Lt,
+    assert torch.equal(fp["skv_row0_tx"], torch.cat([o_tp + pk["row0"], o_tp + M + pk["row0"]])) and torch.equal(fp["skv_len_tx"], torch.cat([pk["len"], pk["len"]]))
+    top = torch.cat([torch.arange(3 * B, device="cuda") * Lp, o_tp + pk["row0_64"], o_tp + M + pk["row0_64"], o_8 + row8,
                      o_lm + torch.arange(B * Lt + B * Lp, device="cuda")])
     assert torch.equal(fp["idx_top"], top)
     for nm, idx in (("t", torch.cat([ar, ar, neg_t, ar])), ("p", torch.cat([ar, neg_p, ar, ar]))):
@@ -1419,6 +1417,72 @@ def test_fusion_plan_matches_tensor_bookkeeping(ops, B, Lt, Lp):
         src.add(idx)
         src.finalize()
         assert torch.equal(fp["start_" + nm], src.start) and torch.equal(fp["list_" + nm], src.list), nm
+
+
+@pytest.mark.parametrize("M,N,K,Md", [(9000, 768, 768, 8200), (9000, 768, 768, 9000), (700, 128, 128, 300), (20000, 2304, 768, 17123), (5000, 768, 3072, 4097)])
+def test_device_side_row_counts(ops, M, N, K, Md):
+    """The launches over a batch whose row count only the device knows (include/spmm_hip.h, "device-side row counts"): the NT GEMM, the
+    weight-gradient GEMM + column sums and both LayerNorm kernels, sized for M rows and told Md <= M through device memory, give on rows
+    [0, Md) exactly what the same launch on the first Md rows gives, touch no row past Md, and reduce nothing past it -- with NaN in the
+    tail rows of every input."""
+    md = torch.tensor([Md], dtype=torch.int32, device="cuda")
+    A, W, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, N, seed=3)
+    A[Md:] = float("nan"); R[Md:] = float("nan")
+    bias = torch.randn(N, device="cuda")
+    for kw in (dict(), dict(R=R), dict(epi=ops.EPI_GELU_DERIV, C2=True), dict(epi=ops.EPI_MUL, G=R, colsum=True)):
+        kw = dict(kw)
+        two = kw.pop("C2", False)
+        cs = kw.pop("colsum", False)
+        outs = []
+        for dyn in (True, False):
+            rows = M if dyn else Md
+            C = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+            C2 = torch.full((M, N), 7.0, dtype=BF, device="cuda") if two else None
+            col = torch.zeros(N, device="cuda") if cs else None
+            k2 = {k: (v[:rows] if torch.is_tensor(v) else v) for k, v in kw.items()}
+            ops.gemm_nt(A[:rows], W, C[:rows], bias=None if "G" in kw else bias, C2=None if C2 is None else C2[:rows], colsum=col,
+                        M_dev=md if dyn else None, **k2)
+            outs.append((C, C2, col))
+        (C_d, C2_d, col_d), (C_s, C2_s, col_s) = outs
+        assert torch.equal(C_d[:Md], C_s[:Md]) and bool((C_d[Md:] == 7.0).all()), kw
+        if two:
+            assert torch.equal(C2_d[:Md], C2_s[:Md]) and bool((C2_d[Md:] == 7.0).all())
+        if cs:
+            close(col_d, col_s, 2e-2 * (Md ** 0.5) / 30, 1e-3, "fused column sums")
+    # weight gradient + column sums
+    dY, X = rnd(M, N, seed=5), rnd(M, K, seed=6)
+    dY[Md:] = float("nan"); X[Md:] = float("nan")
+    g_d, g_s = torch.zeros(N, K, device="cuda"), torch.zeros(N, K, device="cuda")
+    b_d, b_s = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    ops.gemm_tn(dY, X, g_d, M_dev=md); ops.colsum_bf16(dY, b_d, R_dev=md)
+    ops.gemm_tn(dY[:Md], X[:Md], g_s); ops.colsum_bf16(dY[:Md], b_s)
+    assert bool(torch.isfinite(g_d).all()) and bool(torch.isfinite(b_d).all())
+    close(g_d, g_s, 2e-3 * Md ** 0.5, 1e-4, "weight gradient")
+    close(b_d, b_s, 1e-3 * Md ** 0.5, 1e-4, "bias gradient")
+    # LayerNorm forward / backward
+    if N in (128, 768):
+        x, r = rnd(M, N, seed=7), rnd(M, N, seed=8)
+        x[Md:] = float("nan")
+        gamma, beta = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
+        seed = torch.full((1,), 99, dtype=torch.int64, device="cuda")
+        res = []
+        for dyn in (True, False):
+            rows = M if dyn else Md
+            y = torch.full((M, N), 7.0, dtype=BF, device="cuda"); z = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+            mean, rstd = torch.full((M,), 7.0, device="cuda"), torch.full((M,), 7.0, device="cuda")
+            ops.ln_fwd(x[:rows], r[:rows], gamma, beta, y[:rows], zout=z[:rows], mean=mean[:rows], rstd=rstd[:rows], dropout_p=0.1, seed=seed, salt=5,
+                       rows_dev=md if dyn else None)
+            dz = torch.full((M, N), 7.0, dtype=BF, device="cuda"); dx = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+            dg, db, dxs = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+            dy = rnd(M, N, seed=9); dy[Md:] = float("nan")
+            ops.ln_bwd(dy[:rows], z[:rows], mean[:rows], rstd[:rows], gamma, dz[:rows], dx=dx[:rows], dgamma=dg, dbeta=db, dropout_p=0.1, seed=seed, salt=5,
+                       dxsum=dxs, rows_dev=md if dyn else None)
+            res.append((y, z, mean, dz, dx, dg, db, dxs))
+        for a_, b_ in zip(res[0][:5], res[1][:5]):
+            assert torch.equal(a_[:Md], b_[:Md]) and bool((a_[Md:] == 7.0).all())
+        for a_, b_, nm in zip(res[0][5:], res[1][5:], ("dgamma", "dbeta", "dxsum")):
+            assert bool(torch.isfinite(a_).all())
+            close(a_, b_, 2e-3 * Md ** 0.5, 1e-3, nm)
 
 
 def test_row_helpers_gather2_add_zero_gelu(ops):

@@ -35,7 +35,7 @@ static int run(int kernel, int epi, const Buf& A, const Buf& W, int M, int N, in
   // (an upper bound for what hiding the first-touch latency of A could buy)
   static const long lda = getenv("GEMM_BENCH_LDA0") ? 0 : -1;
   return spmm_gemm_nt(A.d, lda < 0 ? K : lda, W.d, K, M, N, K, 1, bias, nullptr, 1.0f, R ? R->d : nullptr, N, G ? G->d : nullptr, N, C.d, N, C2 ? C2->d : nullptr, N,
-                      epi, colsum, kernel, st);
+                      epi, colsum, kernel, nullptr, st);
 }
 
 static double gelu(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752)); }
@@ -176,7 +176,7 @@ static int tn_run(int kernel, const Buf& A, const Buf& B, int M, int N, int K, B
   if ((size_t)spmm_gemm_tn_workspace_bytes(M, N, K, splits) > ws.bytes) { printf("workspace too small\n"); return 1; }
   // GEMM_BENCH_LDA0=1: all rows of both operands alias row 0 (cache-resident operands: what the schedule does without HBM / fabric)
   static const bool ld0 = getenv("GEMM_BENCH_LDA0") != nullptr;
-  return spmm_gemm_tn(A.d, ld0 ? 0 : N, B.d, ld0 ? 0 : K, M, N, K, splits, 1.0f, (float*)C.d, K, (float*)ws.d, kernel, 0);
+  return spmm_gemm_tn(A.d, ld0 ? 0 : N, B.d, ld0 ? 0 : K, M, N, K, splits, 1.0f, (float*)C.d, K, (float*)ws.d, kernel, nullptr, 0);
 }
 static int cmd_tncheck() {
   int fails = 0;
@@ -274,7 +274,7 @@ static int cmd_f8time(int M, int N, int K, int epi, int rounds) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t8.push_back(ms / 5);
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < 5; ++i)
-      if (spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, nullptr, N, C.d, N, epi == SPMM_EPI_GELU_DERIV ? C2.d : nullptr, N, epi, nullptr, 8, 0)) {
+      if (spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, nullptr, N, C.d, N, epi == SPMM_EPI_GELU_DERIV ? C2.d : nullptr, N, epi, nullptr, 8, nullptr, 0)) {
         printf("%s\n", spmm_last_error()); return 1; }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t16.push_back(ms / 5);
   }
@@ -311,7 +311,7 @@ static int cmd_sustain(int M, int N, int K, int epi, int launches) {
     for (int i = 0; i < launches; ++i) {
       const int r = i % nrot;
       if (between == 1) CK(hipMemsetAsync(scratch.d, i & 255, scratch.bytes, 0));
-      else if (between == 3) { if (spmm_colsum_bf16(scratch.d, 768, 174762, 768, (float*)cs.d, 0)) { printf("%s\n", spmm_last_error()); return 1; } }   // read-only sweep of 256 MiB
+      else if (between == 3) { if (spmm_colsum_bf16(scratch.d, 768, 174762, 768, (float*)cs.d, nullptr, 0)) { printf("%s\n", spmm_last_error()); return 1; } }   // read-only sweep of 256 MiB
       else { CK(hipDeviceSynchronize()); struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr); }
       CK(hipEventRecord(e0, 0));
       if (run(kern, epi, A[r], W, M, N, K, nullptr, nullptr, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? &G : nullptr, C[r],
@@ -423,7 +423,7 @@ int main(int argc, char** argv) {
       CK(hipMemset(prof.d, 0, prof.bytes));
       CK(hipEventRecord(e0, 0));
       int rc = spmm_gemm_nt(A.d, lda, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, (epi == SPMM_EPI_GELU_GRAD || epi == SPMM_EPI_MUL) ? G.d : nullptr, N, C.d, N,
-                            (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? C2.d : nullptr, N, epi, (float*)prof.d, 8, 0);
+                            (epi == SPMM_EPI_GELU || epi == SPMM_EPI_GELU_DERIV) ? C2.d : nullptr, N, epi, (float*)prof.d, 8, nullptr, 0);
       CK(hipEventRecord(e1, 0));
       if (rc) { printf("rc=%d %s\n", rc, spmm_last_error()); return 1; }
       CK(hipDeviceSynchronize());
