@@ -730,7 +730,7 @@ def main():
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pmc_path = next((os.path.join(pdir, f) for f in ("r04_pmc_nt_gemm.json", "r03_pmc_nt_gemm.json", "r02_pmc_nt_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
+        pmc_path = next((os.path.join(pdir, f) for f in ("r05_pmc_nt_gemm.json", "r04_pmc_nt_gemm.json", "r03_pmc_nt_gemm.json", "r02_pmc_nt_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
         if pmc_path:
             pmc = json.load(open(pmc_path))
             if pmc["workload"] == {"batch": B, "seq_len": Lt, "layers": nt, "queue": args.queue}:

@@ -44,9 +44,6 @@ const char* spmm_last_error(void);
 #define SPMM_EPI_GELU_DERIV 6  /* pre = acc + bias ; C(bf16) = gelu_erf(pre) ; C2(bf16) = gelu_erf'(pre): the FFN forward keeps  */
                                /* the derivative (one shared exp) so that the backward epilogue is SPMM_EPI_MUL                  */
 #define SPMM_EPI_MUL 7         /* C(bf16) = alpha*acc * G      (G bf16, e.g. the stored gelu'; colsum allowed)                   */
-#define SPMM_EPI_GELU_DERIV8 8 /* as 6 with C2 as 8-BIT codes of gelu' (1 byte per element, ldc2 in bytes): linear over [-0.1298, 1.1298],  */
-                               /* |error| <= 2.5e-3 (6e-4 of the whole gradient, profiles/r03_gelu_deriv_u8_error.txt); 8-phase kernel only  */
-#define SPMM_EPI_MUL8 9        /* as 7 with G as those 8-bit codes (ldg in bytes)                                                            */
 
 /* C[M,N] = A[M,K] . W[N,K]^T on MFMA (bf16 in, fp32 accumulate).  Replaces every nn.Linear on the path
  * (xbert.py:280-300 query/key/value, :370 attention output.dense, :435 intermediate.dense + erf GELU :436,

@@ -24,14 +24,10 @@ constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
 
 enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5, EPI_GELU_DERIV = 6, EPI_MUL = 7,
-           EPI_GELU_DERIV8 = 8, EPI_MUL8 = 9,     // 8 / 9: gelu' kept as 8-bit codes (8-phase kernel only)
            EPI_DROPRES = 10 };                    // C = dropout(bf16(acc + bias)) + R: spmm_gemm_nt_drop (8-phase kernel only)
-// gelu'(x) lies in [-0.1298, 1.1298]: the 8-bit image is the linear code over that range (step 4.94e-3, |error| <= 2.5e-3; measured effect on
-// the whole gradient of a full-depth step: 6e-4 relative, profiles/r03_gelu_deriv_u8_error.txt)
-constexpr float DQ_LO = -0.1298f, DQ_STEP = (1.1298f + 0.1298f) / 255.f, DQ_INV = 255.f / (1.1298f + 0.1298f);
 // bf16-output epilogues (LDS-transposed, row-coalesced stores): BF16, GELU (C2 = pre-activation), GELU_DERIV (C2 = gelu'(pre)),
 // GELU_GRAD (C = acc * gelu'(G), G = pre-activation), MUL (C = acc * G, G = a stored derivative)
-constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU || e == EPI_GELU_GRAD || e == EPI_GELU_DERIV || e == EPI_MUL || e == EPI_GELU_DERIV8 || e == EPI_MUL8 || e == EPI_DROPRES; }
+constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU || e == EPI_GELU_GRAD || e == EPI_GELU_DERIV || e == EPI_MUL || e == EPI_DROPRES; }
 
 struct GemmP {
   const bf16* A; long lda;
@@ -817,22 +813,6 @@ __device__ __forceinline__ void p8_dsw64(uint32_t addr, uint32_t a, uint32_t b) 
   u32x2 v = {a, b};
   asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void p8_dsw32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-template <int OFF>
-__device__ __forceinline__ void p8_dsr64u(u32x2& d, uint32_t addr) {
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ uint32_t dq_pack4(float a, float b, float c, float d) {          // four gelu' values -> four 8-bit codes
-  uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32((a - DQ_LO) * DQ_INV, 0, 0u);
-  r = __builtin_amdgcn_cvt_pk_u8_f32((b - DQ_LO) * DQ_INV, 1, r);
-  r = __builtin_amdgcn_cvt_pk_u8_f32((c - DQ_LO) * DQ_INV, 2, r);
-  return __builtin_amdgcn_cvt_pk_u8_f32((d - DQ_LO) * DQ_INV, 3, r);
-}
-template <int B>
-__device__ __forceinline__ float dq_byte(uint32_t w) {                                       // code -> gelu' value
-  const float f = (float)((w >> (8 * B)) & 0xffu);          // (v_cvt_f32_ubyteB)
-  return __builtin_fmaf(f, DQ_STEP, DQ_LO);
-}
 template <int OFF>
 __device__ __forceinline__ void p8_dsr128u(u32x4& d, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -880,28 +860,17 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
   const bool n_ok = INTERIOR || n < p.N;                        // N % 8 == 0: a chunk is all in or all out
   const long row0 = m_base + r8;
   bf16* cp = (bf16*)p.C + row0 * p.ldc + n;
-  constexpr bool GELU2 = EPI == EPI_GELU || EPI == EPI_GELU_DERIV || EPI == EPI_GELU_DERIV8;    // two outputs
-  constexpr bool DERIV = EPI == EPI_GELU_DERIV || EPI == EPI_GELU_DERIV8;
-  constexpr bool Q8 = EPI == EPI_GELU_DERIV8 || EPI == EPI_MUL8;      // the second output / the factor as 8-bit codes (1 byte per element)
-  constexpr bool MULG = EPI == EPI_MUL || EPI == EPI_MUL8;
-  bf16* c2p = GELU2 && p.C2 ? (Q8 ? (bf16*)((unsigned char*)p.C2 + row0 * p.ldc2 + n) : p.C2 + row0 * p.ldc2 + n) : nullptr;
-  // 8-bit image of a 16-row block: 72-byte rows (the 16 rows of a write land on 16 distinct even banks; 8-byte aligned for the reader),
-  // no swizzle, so the (ni) pieces are immediate offsets of ONE address register each way (the kernel has no registers to spare)
-  const uint32_t wadq = xb + (uint32_t)(m * 72 + g * 4);
-  const uint32_t radq = xb + (uint32_t)(r8 * 72 + c16 * 8);
+  constexpr bool GELU2 = EPI == EPI_GELU || EPI == EPI_GELU_DERIV;    // two outputs
+  constexpr bool DERIV = EPI == EPI_GELU_DERIV;
+  constexpr bool MULG = EPI == EPI_MUL;
+  bf16* c2p = GELU2 && p.C2 ? p.C2 + row0 * p.ldc2 + n : nullptr;
   u32x4 ex[8];                                                  // R / G pieces of one 64-row half in the store layout, all in flight at once
   const bf16* esrc = (EPI == EPI_GELU_GRAD || MULG) ? p.G : p.R;
   const long eld = (EPI == EPI_GELU_GRAD || MULG) ? p.ldg : p.ldr;
   const long nn = n_ok ? n : 0;
-  // (EPI_MUL8: the factor's rows are bytes -- 8 codes = 8 bytes per lane, kept in the first two dwords of ex[])
 #define P8_EX_LOAD1(I_, R_)                                                                                            \
   do {                                                                                                                 \
-    if constexpr (EPI == EPI_MUL8) {                                                                                   \
-      const u32x2 t_ = *(const u32x2*)((const unsigned char*)esrc + (R_) * eld + nn);                                 \
-      ex[I_][0] = t_[0]; ex[I_][1] = t_[1];                                                                            \
-    } else {                                                                                                           \
-      ex[I_] = *(const u32x4*)(esrc + (R_) * eld + nn);                                                                \
-    }                                                                                                                  \
+    ex[I_] = *(const u32x4*)(esrc + (R_) * eld + nn);                                                                  \
   } while (0)
 #define P8_LOAD_EX(H)                                                          \
   if constexpr (HAS_EX) {                                                      \
@@ -949,25 +918,6 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
             v[ni][j] = gg.x; v[ni][j + 1] = gg.y;
             w[ni][j] = dd.x; w[ni][j + 1] = dd.y;
           }
-        if constexpr (EPI == EPI_GELU_DERIV8) {
-          if (c2p) {
-            // gelu' as 8-bit codes in this block's image (1 KiB of it), the activation in the other one: one LDS round trip for both
-            u32x2 q1, q2;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) p8_dsw32(wadq + bo + ni * 16, dq_pack4(w[ni][0], w[ni][1], w[ni][2], w[ni][3]));
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + (bo ^ 2048u), p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
-            p8_dsr64u<0>(q1, radq + bo);
-            p8_dsr64u<576>(q2, radq + bo);
-            p8_dsr128u<0>(o1, rad + (bo ^ 2048u));
-            p8_dsr128u<1024>(o2, rad + (bo ^ 2048u));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned char* c2q = (unsigned char*)c2p;
-            if (ok1) *(u32x2*)(c2q + (long)blk * 16 * p.ldc2) = q1;
-            if (ok2) *(u32x2*)(c2q + (long)blk * 16 * p.ldc2 + 8 * p.ldc2) = q2;
-          }
-        } else
         if (c2p && !F8) {
           // both outputs of the block go through the wave's two LDS images at once (second output in this block's image, the
           // activation in the other one): one LDS round trip per block instead of two
@@ -996,7 +946,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
         }
       }
       // (the same wave's LDS operations execute in order: the image writes below cannot pass the reads above)
-      if (!(GELU2 && c2p && (!F8 || EPI == EPI_GELU_DERIV8))) {
+      if (!(GELU2 && c2p && !F8)) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
         p8_dsr128u<0>(o1, rad + bo);
@@ -1039,17 +989,6 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
           o1[d] = p8_pack2(p8_lo(o1[d]) * p8_lo(ex[2 * mi][d]), p8_hi(o1[d]) * p8_hi(ex[2 * mi][d]));
           o2[d] = p8_pack2(p8_lo(o2[d]) * p8_lo(ex[2 * mi + 1][d]), p8_hi(o2[d]) * p8_hi(ex[2 * mi + 1][d]));
         }
-      }
-      if constexpr (EPI == EPI_MUL8) {       // o[d] holds columns 2d, 2d+1; the 8 codes of the row piece sit in ex[.][0] (columns 0-3) and ex[.][1] (4-7)
-        const uint32_t a0 = ex[2 * mi][0], a1 = ex[2 * mi][1], b0 = ex[2 * mi + 1][0], b1 = ex[2 * mi + 1][1];
-        o1[0] = p8_pack2(p8_lo(o1[0]) * dq_byte<0>(a0), p8_hi(o1[0]) * dq_byte<1>(a0));
-        o1[1] = p8_pack2(p8_lo(o1[1]) * dq_byte<2>(a0), p8_hi(o1[1]) * dq_byte<3>(a0));
-        o1[2] = p8_pack2(p8_lo(o1[2]) * dq_byte<0>(a1), p8_hi(o1[2]) * dq_byte<1>(a1));
-        o1[3] = p8_pack2(p8_lo(o1[3]) * dq_byte<2>(a1), p8_hi(o1[3]) * dq_byte<3>(a1));
-        o2[0] = p8_pack2(p8_lo(o2[0]) * dq_byte<0>(b0), p8_hi(o2[0]) * dq_byte<1>(b0));
-        o2[1] = p8_pack2(p8_lo(o2[1]) * dq_byte<2>(b0), p8_hi(o2[1]) * dq_byte<3>(b0));
-        o2[2] = p8_pack2(p8_lo(o2[2]) * dq_byte<0>(b1), p8_hi(o2[2]) * dq_byte<1>(b1));
-        o2[3] = p8_pack2(p8_lo(o2[3]) * dq_byte<2>(b1), p8_hi(o2[3]) * dq_byte<3>(b1));
       }
       if constexpr (!GELU2 && EPI != EPI_DROPRES) {
         if (p.colsum) {
@@ -1341,7 +1280,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       const uint32_t xb = lds0 + P8_LDS + wave * 4096;
       const int mb = cm0 + wr * 128, nb = cn0 + wc * 64;
       const bool interior = cm0 + BM3 <= q.M && cn0 + BN3 <= q.N;
-      if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL || EPI == EPI_MUL8) {
+      if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
         if (interior) p8_epilogue_blocks<EPI, true, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
         else p8_epilogue_blocks<EPI, false, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
       } else if (EPI == EPI_DROPRES || (EPI == EPI_BF16 && q.R != nullptr)) {
@@ -1407,8 +1346,6 @@ int launch_p8(int epi, const GemmP& p, hipStream_t st, bool persist) {
     case EPI_GELU_GRAD: return launch_p8_one<EPI_GELU_GRAD>(p, st, persist);
     case EPI_GELU_DERIV: return launch_p8_one<EPI_GELU_DERIV>(p, st, persist);
     case EPI_MUL: return launch_p8_one<EPI_MUL>(p, st, persist);
-    case EPI_GELU_DERIV8: return launch_p8_one<EPI_GELU_DERIV8>(p, st, persist);
-    case EPI_MUL8: return launch_p8_one<EPI_MUL8>(p, st, persist);
     case EPI_DROPRES: return launch_p8_one<EPI_DROPRES>(p, st, persist);
     default: return -1;
   }
@@ -1538,11 +1475,11 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   SPMM_CHECK_SHAPE(!is_bf16_epi(epi) || (ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!G || ldg % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0),
                    "spmm_gemm_nt: bf16 outputs need 16-B aligned rows (ldc/ldr/ldg/ldc2 multiples of 8)");
   SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "spmm_gemm_nt: A/W must be 16-B aligned");
-  SPMM_CHECK_SHAPE(epi >= EPI_BF16 && epi <= EPI_MUL8, "spmm_gemm_nt: unknown epilogue %d", epi);
+  SPMM_CHECK_SHAPE(epi >= EPI_BF16 && epi <= EPI_MUL, "spmm_gemm_nt: unknown epilogue %d", epi);
   if (splits < 1) splits = 1;
   SPMM_CHECK_SHAPE(splits == 1 || epi == EPI_F32_ATOMIC, "spmm_gemm_nt: split-K needs the atomic epilogue");
-  SPMM_CHECK_SHAPE((epi != EPI_GELU_GRAD && epi != EPI_MUL && epi != EPI_MUL8) || G != nullptr, "spmm_gemm_nt: the GELU-grad / multiply epilogues need G");
-  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD || epi == EPI_MUL || epi == EPI_MUL8, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad / multiply epilogues");
+  SPMM_CHECK_SHAPE((epi != EPI_GELU_GRAD && epi != EPI_MUL) || G != nullptr, "spmm_gemm_nt: the GELU-grad / multiply epilogues need G");
+  SPMM_CHECK_SHAPE(colsum == nullptr || epi == EPI_BF16 || epi == EPI_GELU_GRAD || epi == EPI_MUL, "spmm_gemm_nt: colsum is only fused into the bf16 / GELU-grad / multiply epilogues");
   int ksplit = ((K / 64 + splits - 1) / splits) * 64;
   splits = (K + ksplit - 1) / ksplit;
   GemmP p;
@@ -1565,10 +1502,6 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
     const int tile = splits > 1 ? 1 : pick_tile(M, N, epi);
     k = tile == 3 ? (p8_ok(p, epi) ? (kernel == SPMM_GEMM_AUTO_TILES ? 9 : 8) : 3) : tile;
     if (k == 2 && (epi == EPI_F32_ATOMIC || M < 512)) k = 1;
-  }
-  if (epi == EPI_GELU_DERIV8 || epi == EPI_MUL8) {     // the 8-bit gelu' pair exists in the 8-phase kernel only (any M, N: edge tiles are predicated)
-    SPMM_CHECK_SHAPE(kernel == 0 || kernel == SPMM_GEMM_AUTO_TILES || kernel == 8 || kernel == 9, "spmm_gemm_nt: the 8-bit gelu' epilogues run on the 8-phase kernel only");
-    k = (k == 9 || kernel == SPMM_GEMM_AUTO_TILES) ? 9 : 8;
   }
   // 5 = the 128x128 tile with loader + compute waves (any epilogue of kernel 1, split-K too; operands < 4 GiB: 32-bit DMA offsets)
   const bool pc_fits = (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 32) && (unsigned long)p.N * (unsigned long)p.ldw * 2ul < (1ul << 32);

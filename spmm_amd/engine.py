@@ -509,8 +509,7 @@ class Engine:
         h = self._new(M, I)
         # backward needs only gelu'(pre-activation): the forward epilogue stores it (it shares the exponential with the erf) and the
         # backward epilogue is a plain multiply -- the erf / exp work of xbert.py:436's backward leaves the dgrad GEMM
-        u8 = self.opt.gelu_deriv_u8 and not self.fp8 and not ops._DRY_RUN and H % 128 == 0 and I % 128 == 0     # (the 8-phase kernel's shapes)
-        dact = (self._new(M, I, dtype=torch.uint8) if u8 else self._new(M, I)) if save else None
+        dact = self._new(M, I) if save else None
         fp8 = self.fp8 and H % 256 == 0 and I % 256 == 0 and self._md(a) is None
         x = self._new(M, H) if fp8 else None
         if fp8:
@@ -525,7 +524,7 @@ class Engine:
             ops.gemm_nt_f8(h8, sh, w8, sw, x, bias=P.w(lp + "output.dense.bias"))
         else:
             ops.gemm_nt(a, P.wb(lp + "intermediate.dense.weight"), h, bias=P.w(lp + "intermediate.dense.bias"),
-                        epi=(ops.EPI_GELU_DERIV8 if u8 else ops.EPI_GELU_DERIV) if save else ops.EPI_GELU, C2=dact, M_dev=self._md(a))
+                        epi=ops.EPI_GELU_DERIV if save else ops.EPI_GELU, C2=dact, M_dev=self._md(a))
         if fp8:
             y = self._new(M, H)
             mean = self._new(M, dtype=torch.float32) if save else None
@@ -551,7 +550,7 @@ class Engine:
         self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
         ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre,
-                    epi=ops.EPI_MUL8 if sv["dact"].dtype == torch.uint8 else ops.EPI_MUL, G=sv["dact"], colsum=P.g(lp + "intermediate.dense.bias"),
+                    epi=ops.EPI_MUL, G=sv["dact"], colsum=P.g(lp + "intermediate.dense.bias"),
                     M_dev=self._md(dx))
         self._wgrad(dpre, sv["a"], P.g(lp + "intermediate.dense.weight"))
         da = self._new(M, H)

@@ -7,7 +7,7 @@ import torch
 
 from ._lib import lib
 
-EPI_BF16, EPI_GELU, EPI_F32, EPI_F32_ATOMIC, EPI_GELU_GRAD, EPI_F32_ACC, EPI_GELU_DERIV, EPI_MUL, EPI_GELU_DERIV8, EPI_MUL8 = range(10)
+EPI_BF16, EPI_GELU, EPI_F32, EPI_F32_ATOMIC, EPI_GELU_GRAD, EPI_F32_ACC, EPI_GELU_DERIV, EPI_MUL = range(8)
 BF16 = torch.bfloat16
 
 
@@ -106,10 +106,8 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
     N = W.shape[0]
     K = Ka if K is None else K
     assert A.dtype == BF16 and W.dtype == BF16 and W.shape[1] >= K and C.shape[0] >= M and C.shape[1] >= N
-    if epi in (EPI_BF16, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_DERIV, EPI_MUL, EPI_GELU_DERIV8, EPI_MUL8):
+    if epi in (EPI_BF16, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_DERIV, EPI_MUL):
         assert C.dtype == BF16
-        assert epi != EPI_GELU_DERIV8 or C2 is None or C2.dtype == torch.uint8
-        assert epi != EPI_MUL8 or G.dtype == torch.uint8
     else:
         assert C.dtype == torch.float32
     if (_FP8_TIMING and M_dev is None and epi in (EPI_BF16, EPI_GELU_DERIV) and K % 256 == 0 and N % 8 == 0 and M >= 4096 and div is None and colsum is None

@@ -20,7 +20,6 @@ _ENV = {
     "fp8": ("SPMM_FP8", lambda s: s == "1"),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
     "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
-    "gelu_deriv_u8": ("SPMM_GELU_DERIV_U8", lambda s: s != "0"),
     "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
     "grad_wire": ("SPMM_GRAD_WIRE", str),
     "nt_under_comm": ("SPMM_NT_UNDER_COMM", str),
@@ -43,8 +42,6 @@ class EngineOptions:
     #                               instead of 1.3e-3, loss_ita 4.8e-3 instead of 3.6e-3 (EXPERIMENTS.md 3.4)
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
-    gelu_deriv_u8: bool = False   # gelu'(x) kept for the FFN backward as 8-bit codes instead of bf16 (half the bytes written and re-read;
-    #                               6e-4 of the whole gradient, profiles/r03_gelu_deriv_u8_error.txt)
     fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)
     # --- precision tiers (NOT the headline configuration) ---
     fp8: bool = False             # E4M3 FFN forward GEMMs (BASELINE configs[4])

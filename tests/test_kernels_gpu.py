@@ -92,36 +92,6 @@ def test_gemm_tile_kernels(ops, M, N, K, kernel):
     close(cs, 1.0 + D[:, :N].float().sum(0), 5e-2 * math.sqrt(M / 256), 2e-3, "fused column sums (multiply epilogue)")
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (777, 3072, 768), (33000, 3072, 768), (300, 264, 128)])
-def test_gemm_gelu_derivative_as_8bit_codes(ops, M, N, K):
-    """SPMM_EPI_GELU_DERIV8 / SPMM_EPI_MUL8 (EngineOptions.gelu_deriv_u8): the FFN forward keeps gelu'(pre) as 8-bit codes -- linear over
-    [-0.1298, 1.1298], |error| <= half a step = 2.5e-3 -- and the backward multiplies by the decoded value.  Against fp32 torch, ragged M / N
-    (edge tiles) included; the activation output must equal the bf16-derivative epilogue's bit for bit."""
-    A, W = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
-    bias = torch.randn(N, device="cuda") * 0.5
-    pre = A.float() @ W.float().t() + bias
-    pg = pre.clone().requires_grad_(True)
-    torch.nn.functional.gelu(pg).sum().backward()
-    C, Cb = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF, device="cuda")
-    Q = torch.full((M, N), 77, dtype=torch.uint8, device="cuda")
-    C2b = torch.empty(M, N, dtype=BF, device="cuda")
-    ops.gemm_nt(A, W, C, bias=bias, epi=ops.EPI_GELU_DERIV8, C2=Q)
-    ops.gemm_nt(A, W, Cb, bias=bias, epi=ops.EPI_GELU_DERIV, C2=C2b, kernel=8)
-    assert torch.equal(C, Cb)
-    lo, step = -0.1298, (1.1298 + 0.1298) / 255.0
-    dec = Q.float() * step + lo
-    # the code is taken from the fp32 derivative the epilogue computed (A&S erf, |err| < 2e-7) of the bf16-MFMA pre-activation
-    assert (dec - pg.grad).abs().max().item() <= 0.5 * step + 4e-3, (dec - pg.grad).abs().max().item()
-    assert (dec - C2b.float()).abs().max().item() <= 0.5 * step + 4e-3          # bf16 rounding of the other form: 2^-9 of a value <= 1.13
-    dY, Wt = rnd(M, N, seed=3), rnd(K, N, scale=0.05, seed=4)                    # backward: dpre = (dY Wt^T) * gelu'   with N as the output width
-    D = torch.empty(M, N, dtype=BF, device="cuda")
-    cs = torch.ones(N, device="cuda")
-    X = rnd(M, K, seed=5)
-    ops.gemm_nt(X, W, D, epi=ops.EPI_MUL8, G=Q, colsum=cs)
-    close(D, (X.float() @ W.float().t()) * dec, 3e-2, 1.5e-2, "multiply by the decoded codes")
-    close(cs, 1.0 + D.float().sum(0), 5e-2 * math.sqrt(M / 256), 2e-3, "fused column sums (8-bit multiply epilogue)")
-
-
 def test_gemm_one_workgroup_per_tile_mode_is_bit_identical(ops):
     """`ops.nt_tiles_per_workgroup()` (what the data-parallel backward switches on while collectives hold CUs): automatically chosen
     NT GEMMs launch one workgroup per tile; the tiles and their accumulation order are the persistent kernel's, so every output --

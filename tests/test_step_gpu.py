@@ -327,35 +327,6 @@ def test_dropout_and_residual_in_the_projection_epilogue_inside_the_step(env):
     assert rel > 1e-5 and rel < 1.5e-2                       # (the fused form really ran)
 
 
-def test_gelu_derivative_as_8bit_codes_inside_the_step(env):
-    """EngineOptions.gelu_deriv_u8 inside the real step (H = 768, 2+2 layers, train mode with dropout, same seed).  The forward computes the
-    same function (the option pins the FFN-up GEMM to the 8-phase kernel, so at this small M the accumulation order -- and with it a few
-    bf16 roundings -- differs from the default's tile choice: losses within 5e-3); the gradient additionally differs through gelu' kept as
-    8-bit codes (step 4.9e-3 over [-0.13, 1.13]; profiles/r03_gelu_deriv_u8_error.txt measured 6e-4 of the whole gradient at full depth):
-    whole-gradient relative L2 difference below 1e-2 (measured 1.1e-3)."""
-    O, SPMM, tiny_config, *_ = env
-    from spmm_amd.options import EngineOptions
-    cfg, ocfg = _mid_cfg(env)
-    sd = O.init_state_dict(ocfg, seed=3)
-    B, Lt = 16, 48
-    prop, ids, mask = O.synthetic_batch(B, Lt, seed=23)
-    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(1))
-    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
-    res = {}
-    for u8 in (False, True):
-        m = SPMM(config=None, spmm_config=cfg, options=EngineOptions.from_env(gelu_deriv_u8=u8))
-        m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
-        m.train()
-        m.engine.seed.fill_(4242)
-        losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
-        sum(losses).backward()
-        res[u8] = (np.array([float(x) for x in losses]), m.store.grad.detach().clone())
-    np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=5e-3)
-    rel = ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item()
-    print(f"gelu' as 8-bit codes: losses {res[True][0]} vs {res[False][0]}, whole-gradient relative L2 difference {rel:.3g}")
-    assert 0 < rel < 1e-2
-
-
 def test_full_depth_forward_matches_oracle(env):
     """The published architecture (12 text layers with 6 fusion + 6 PV layers, H=768), random-init weights, B=8, Lt=32,
     queue 1024: bf16 pipeline vs the fp32 CPU oracle.  This is the depth at which bf16 rounding has accumulated most."""
