@@ -172,6 +172,7 @@ class Engine:
         self._wg_stream, self._wg_pending, self._wg_keep = None, False, []
         self.fp8 = self.opt.fp8                             # opt-in fp8 (E4M3) FFN forward: NOT the headline configuration
         self._salt = 0
+        self._off_path_ok, self._pre_bwd = False, None     # (set per step by SPMM.fused_step: single-rank runs only)
         self._dyn = None                  # (rows a batch is allocated for, int32 [1] device tensor with the rows it really has): step.py, fusion batch
         self.tape = None
         self.last32 = None
@@ -256,6 +257,28 @@ class Engine:
             return None
         self._wg_stream = streams.get(self.dev, "wgrad")
         return self._wg_stream
+
+    def off_path(self, fn):
+        """Maintenance that nothing needs before the next BACKWARD -- zeroing the gradient arena, rebuilding the transposed weight shadows
+        of the data-gradient GEMMs after the optimiser -- runs on the weight-gradient stream (idle during the forward) behind everything
+        enqueued so far; `backward()` waits for it.  Inline when that stream is not in use (one-stream schedule, data-parallel runs: their
+        stream order is part of the schedule) or while a graph is being captured."""
+        ws = self._wgrad_side() if self._off_path_ok else None
+        if ws is None or torch.cuda.is_current_stream_capturing():
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            fn()
+            self._pre_bwd = torch.cuda.Event()
+            self._pre_bwd.record(ws)
+
+    def pre_backward_wait(self):
+        ev, self._pre_bwd = self._pre_bwd, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def wgrad_join(self, release: bool = False):
         """The current stream waits for every weight-gradient launch issued so far."""

@@ -69,8 +69,9 @@ class _FusedAdamW:
         ops.adamw_step(self.store.flat, self.store.grad, self.store.adam_m, self.store.adam_v, self.store.shadow, lr=self.eng.lr,
                        beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], normsq=self.normsq,
                        max_norm=5.0, step=self.step_count, nan_flag=self.eng.nan_flag, scalars=self.scalars)
-        self.store.refresh_shadows(transposed_only=True)
-        self.eng.refresh_padded_shadows()
+        # the transposed weight shadows are operands of the NEXT backward's data-gradient GEMMs only
+        self.store.refresh_shadows(transposed_only=True, part="forward")
+        self.eng.off_path(lambda: (self.store.refresh_shadows(transposed_only=True, part="transposed"), self.eng.refresh_padded_shadows()))
 
     @property
     def grad_norm(self) -> torch.Tensor:
@@ -333,7 +334,8 @@ class SPMM(_Base):
         check = self._schedule_check_begin(grad_sync)
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
-        ops.zero_(self.store.grad)
+        eng._off_path_ok = grad_sync is None
+        eng.off_path(lambda: ops.zero_(self.store.grad))        # nothing reads or writes a gradient before the backward
         dev = self.device_
         losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn(),
                              n_tokens=n_tokens)

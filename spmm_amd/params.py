@@ -155,17 +155,22 @@ class ParamStore:
         return self._w8[name][1], self._w8[name][2]
 
     # ---- maintenance -----------------------------------------------------------------------------------------
-    def refresh_shadows(self, transposed_only: bool = False):
+    def refresh_shadows(self, transposed_only: bool = False, part: str = "all"):
         """bf16 shadows <- fp32 masters (after load_state_dict / optimiser step).  AdamW and the EMA kernels already
-        refresh the flat shadows; the transposed dgrad shadows are rebuilt here, one launch per weight matrix."""
+        refresh the flat shadows; the transposed dgrad shadows are rebuilt here, one launch for all of them.
+        part: "forward" = only what the next FORWARD reads (fp8 weight images, fragment-ordered images of the fused cross-attention),
+        "transposed" = only the data-gradient GEMMs' transposed shadows (read by the next BACKWARD: Engine.off_path), "all" = both."""
         if not transposed_only:
             ops.cast_f32_bf16(self.flat, self.shadow)
             ops.cast_f32_bf16(self.flat_m, self.shadow_m)
-        for src, q, sc in self._w8.values():
-            ops.quant_rows_fp8(src, q, sc)
-        self.refresh_frag(False)
-        if not transposed_only:
-            self.refresh_frag(True)
+        if part in ("all", "forward"):
+            for src, q, sc in self._w8.values():
+                ops.quant_rows_fp8(src, q, sc)
+            self.refresh_frag(False)
+            if not transposed_only:
+                self.refresh_frag(True)
+        if part == "forward":
+            return
         srcs = getattr(self, "_wT_src", {})
         if not srcs:
             return

@@ -390,6 +390,7 @@ class PretrainStep(Engine):
         T = self.tape
         if T is None:
             raise RuntimeError("backward() without a taped forward()")
+        self.pre_backward_wait()                                   # gradient arena zeroed, transposed weight shadows rebuilt (Engine.off_path)
         cfg, P = self.cfg, self.P
         ct, cp = cfg.text, cfg.prop
         H, E, Lp, f, n = ct.hidden_size, cfg.embed_dim, cfg.n_props + 1, ct.fusion_layer, ct.num_hidden_layers
