@@ -244,7 +244,8 @@ int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int
  *  spmm_pack_plan: from the attention mask [B, Lt] and the host's count M of valid tokens: per sequence length / first packed row
  *   (lens32, row0_32, row0_64), rows[M] = dense row of every packed row, gidx2[M + B Lt] / gidx4[2M] = gather indices that build the
  *   [packed | dense] and [packed | packed] batches of the text encoders from their dense [2B Lt] embeddings, inv[2 B Lt] = packed row of
- *   every dense row (-1: padding) for the way back; *bad |= 1 when the mask is not B non-empty prefixes with M tokens in all.
+ *   every dense row (-1: padding) for the way back, idx_m[B + M] = rows the momentum text encoder's last layer keeps of its [packed | packed]
+ *   batch (position 0 of the first copy, every row of the second); *bad |= 1 when the mask is not B non-empty prefixes with M tokens in all.
  *  spmm_fusion_plan: index arrays of the fusion batch (layout in csrc/plan.hip) from the sampled negatives neg[2B] (prop | text):
  *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]; the text negatives re-enter as PACKED
  *   query rows at the end of the batch, Mn = sum of their lengths known only on the device), neg_rows [B Lt] (row of text_embeds behind
@@ -257,7 +258,7 @@ int spmm_zero_bytes(void* p, long nbytes, spmm_stream_t stream);
 int spmm_zero_rows(void* p, long rows, long row_bytes, long stride_bytes, spmm_stream_t stream);
 int spmm_gelu_bwd(const void* dz, const void* pre, void* out, long n, spmm_stream_t stream);
 int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32, int* row0_32, long* row0_64, long* rows, long* gidx2,
-                   long* gidx4, long* inv, int* bad, spmm_stream_t stream);
+                   long* gidx4, long* inv, long* idx_m, int* bad, spmm_stream_t stream);
 int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, int B, int Lt, int Lp, int M,
                      long* idx6, long* neg_rows, long* idx_top, int* small32, spmm_stream_t stream);
 

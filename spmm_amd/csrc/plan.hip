@@ -73,7 +73,7 @@ __global__ void gelu_bwd_kernel(const bf16* __restrict__ dz, const bf16* __restr
 __global__ __launch_bounds__(1024) void pack_plan_kernel(const int* __restrict__ mask, int B, int Lt, int M, int* __restrict__ lens32,
                                                           int* __restrict__ row0_32, long* __restrict__ row0_64, long* __restrict__ rows,
                                                           long* __restrict__ gidx2, long* __restrict__ gidx4, long* __restrict__ inv,
-                                                          int* __restrict__ bad) {
+                                                          long* __restrict__ idx_m, int* __restrict__ bad) {
   extern __shared__ int sh[];             // [B] valid counts, [B] exclusive starts, [2] flags
   int* cnt = sh;
   int* start = sh + B;
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(const int* __restrict__
     int n = cnt[s] < M - r0 ? cnt[s] : M - r0;
     n = n < 1 ? 1 : n;
     lens32[s] = n; row0_32[s] = r0; row0_64[s] = r0;
-  }
+    idx_m[s] = r0;                                  // [position 0 of every packed sequence | every row of the second packed copy]: the momentum
+  }                                                 // text encoder's last layer keeps these rows of its [packed | packed] batch (step.py)
+  for (int i = tid; i < M; i += blockDim.x) idx_m[B + i] = (long)M + i;
   // pass 2: packed row of every valid token, dense row of every packed row
   for (int s = wave; s < B; s += nw) {
     int base = start[s];
@@ -288,10 +290,10 @@ extern "C" int spmm_gelu_bwd(const void* dz, const void* pre, void* out, long n,
 }
 
 extern "C" int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32, int* row0_32, long* row0_64, long* rows, long* gidx2,
-                              long* gidx4, long* inv, int* bad, hipStream_t stream) {
+                              long* gidx4, long* inv, long* idx_m, int* bad, hipStream_t stream) {
   SPMM_CHECK_SHAPE(B >= 1 && B <= 8192 && Lt >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_pack_plan: B=%d Lt=%d M=%d", B, Lt, M);
   hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), (2 * B + 2) * sizeof(int), stream, mask, B, Lt, M, lens32, row0_32, row0_64, rows,
-                     gidx2, gidx4, inv, bad);
+                     gidx2, gidx4, inv, idx_m, bad);
   SPMM_LAUNCH_CHECK("spmm_pack_plan");
   return SPMM_OK;
 }

@@ -329,15 +329,15 @@ def pack_plan(mask32, M, bad):
     dev = mask32.device
     alloc = torch.zeros if _DRY_RUN else torch.empty          # (dry runs launch nothing: index 0 keeps the host-side indexing valid)
     i32 = alloc(2 * B, dtype=torch.int32, device=dev)
-    i64 = alloc(B + M + (M + B * Lt) + 2 * M + 2 * B * Lt, dtype=torch.int64, device=dev)
+    i64 = alloc(B + M + (M + B * Lt) + 2 * M + 2 * B * Lt + (B + M), dtype=torch.int64, device=dev)
     o = [0]
 
     def cut(n):
         o[0] += n
         return i64[o[0] - n:o[0]]
-    row0_64, rows, gidx2, gidx4, inv = cut(B), cut(M), cut(M + B * Lt), cut(2 * M), cut(2 * B * Lt)
-    _call("spmm_pack_plan", _p(mask32), B, Lt, M, _p(i32[:B]), _p(i32[B:]), _p(row0_64), _p(rows), _p(gidx2), _p(gidx4), _p(inv), _p(bad), _st())
-    return dict(M=M, rows=rows, row0=i32[B:], row0_64=row0_64, len=i32[:B], gidx2=gidx2, gidx4=gidx4, inv=inv)
+    row0_64, rows, gidx2, gidx4, inv, idx_m = cut(B), cut(M), cut(M + B * Lt), cut(2 * M), cut(2 * B * Lt), cut(B + M)
+    _call("spmm_pack_plan", _p(mask32), B, Lt, M, _p(i32[:B]), _p(i32[B:]), _p(row0_64), _p(rows), _p(gidx2), _p(gidx4), _p(inv), _p(idx_m), _p(bad), _st())
+    return dict(M=M, rows=rows, row0=i32[B:], row0_64=row0_64, len=i32[:B], gidx2=gidx2, gidx4=gidx4, inv=inv, idx_m=idx_m)
 
 
 FUSION_SMALL = dict(ar=(0, 1), kvidx_pv=(1, 3), kvidx_tp=(4, 2), qrow0_tp=(6, 2), qlen_tp=(8, 2), row0_8=(10, 1), len_8=(11, 1),

@@ -189,8 +189,20 @@ class PretrainStep(Engine):
                 g4 = [g2[0], Group(M, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
             else:
                 g4 = g2
-            y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False, X32=x4_32)
-            text_embeds_m, hidden9 = y4[:M], y4[M:]
+            cls_m = bool(pk) and self.opt.cls_only_top and not r32 and f >= 1
+            if cls_m:
+                # text_embeds_m feeds only position 0 to a loss (text_feat_m, :105): the momentum text encoder's LAST unimodal layer runs on
+                # [position 0 of the B packed sequences | every row of the causal copy], the position-0 queries attending keys / values
+                # projected from the full sequences (engine.SelfKV; the student's counterpart is a key / value source of the fusion layers)
+                y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f - 1), True, x4, g4, False)
+                x4t = ops.gather_rows2(self._new(B + M, H), y4, pk["idx_m"])
+                g4t = [Group(0, B, 1, None, B, self_src=SelfKV(y4[:M]), skv_row0=pk["row0"], skv_len=pk["len"], skv_L=Lt),
+                       Group(B, B, Lt, None, 0, q_row0=pk["row0"], q_len=pk["len"], nrows=M)]
+                y4t, _, _ = self._layer_fwd(f"text_encoder_m.bert.encoder.layer.{f - 1}.", ct, False, x4t, g4t, False)
+                text_embeds_m, hidden9 = y4t[:B], y4t[B:]          # (position-0 rows only)
+            else:
+                y4, _ = self.stack_fwd("text_encoder_m.bert.", ct, range(0, f), True, x4, g4, False, X32=x4_32)
+                text_embeds_m, hidden9 = y4[:M], y4[M:]
             text_embeds_m_32, hidden9_32 = (self.last32[:M], self.last32[M:]) if r32 else (None, None)
         x1, esv1 = self.embed_pv("property_encoder.", cp, prop, mpm_mask, 2 * B, B, save)
         g1 = [Group(0, 2 * B, Lp, None, B)]
@@ -234,8 +246,11 @@ class PretrainStep(Engine):
                                                   ("text_proj", text_embeds, Lt, None, None),
                                                   ("property_proj_m", prop_embeds_m, Lp, *bank["prop"]),
                                                   ("text_proj_m", text_embeds_m, Lt, *bank["text"]))):
-            raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save, cls_rows=pk["row0_64"] if (pk and proj.startswith("text_proj")) else None,
-                                                 X32=twins[proj])
+            if proj == "text_proj_m" and cls_m:                  # X holds the position-0 rows already
+                raw, feat, nrm, cls = self._feat_fwd(proj, X, 1, B, save, X32=None)
+            else:
+                raw, feat, nrm, cls = self._feat_fwd(proj, X, L, B, save, cls_rows=pk["row0_64"] if (pk and proj.startswith("text_proj")) else None,
+                                                     X32=twins[proj])
             ops.l2norm_fwd(raw, feat, nrm, a3=A3[k * B:(k + 1) * B], w3=None if w3 is None else w3[:B], yT=qT)
             feats[proj] = (feat, nrm, cls)
         S_text = self._new(4 * B, J, dtype=torch.float32)     # rows: i2t | t2t | i2t_m | t2t_m
