@@ -273,9 +273,10 @@ def decode_bench(args):
     nbytes_rows = sum(b for *_, b in ev)
     tot_ms = tot0.elapsed_time(tot1)
     gms, lms = (sum(a.elapsed_time(b) for a, b in other[kk]) for kk in ("gemm", "layernorm"))
-    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_group_kernel (csrc/decode.hip): one wave per (molecule, head) over the K/V cache; a key / value row is loaded once "
-                                                         "for all beams of the molecule that share it, and the bytes are counted the same way: DISTINCT cache rows per molecule and "
-                                                         "position (from the ancestry table) + q + out",
+    out["roofline"] = {"bound": "hbm", "kernel": "decode_attn_mfma_kernel (csrc/decode.hip): one wave per (molecule, head) over the K/V cache, the beams as the N dimension of "
+                                                         "16x16 MFMAs, keys / values streamed through an LDS-DMA ring; a row every beam shares is loaded once, a position where the "
+                                                         "beams sit on different rows once per beam.  Bytes are counted as DISTINCT cache rows per molecule and position (from the "
+                                                         "ancestry table) + q + out",
                        "achieved": round(nbytes / (tms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": round(nbytes / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches": len(ev),
                        "avg_launch_us": round(tms * 1e3 / len(ev), 2), "algorithmic_bytes_per_launch": round(nbytes / len(ev)),

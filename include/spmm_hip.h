@@ -176,12 +176,13 @@ int spmm_embed_step_ln_fwd(const int* ids, int pos_index, const int* pos_ptr, co
  * j < Lkv <= 256, head_dim 64.  Key/value (s, j) of head h lives at element offset s*seq_stride + j*tok_stride + h*head_stride from K / V (token-major rows:
  * tok_stride = row width, head_stride = 64; head-major caches [S, nH, L, 64]: tok_stride = 64, head_stride = L*64).
  * s(r,j) = anc[r*anc_ld + j] (self-attention: beam ancestry table, cache rows are never moved) or r / kv_div when anc is
- * null (cross-attention: the k beams of a molecule share its PV keys/values).  `group` (R % group == 0) only steers
- * placement: rows n*group .. n*group+group-1 are scheduled next to each other because they read mostly the same lines.
+ * null (cross-attention: the k beams of a molecule share its PV keys/values).  `group` (R % group == 0): rows
+ * n*group .. n*group+group-1 are the beams of one molecule -- served by one wave per head (group 2..8), which loads a key row they share once.
  * No mask: beams carry no padding.  t_ptr (optional, device int): the number of valid keys is *t_ptr + 1 (<= Lkv) instead of
  * Lkv -- the step counter of a replayed hipGraph.  knew / vnew (optional, with anc; row stride ldn): key and value of the newest
- * position (the last valid one) of every row, straight from the projection output: copied into the cache row (s = r) by a
- * small launch in front of the attention kernel, so the caller needs no cache-update copies of its own.  rowmap (optional, [R]):
+ * position (the last valid one) of every row, straight from the projection output: every row attends ITS OWN newest key / value
+ * there (the table's entry for that position must name the row's own cache row: s(r, last) = r, or rowmap[r]), and the launch copies
+ * them into that cache row for the positions to come, so the caller needs no cache-update copies of its own.  rowmap (optional, [R]):
  * the cache row row r's newest position goes to (s = rowmap[r]) -- after the caller dropped finished molecules from its batch, the
  * rows it still decodes keep writing to the cache rows their ancestry tables name. */
 int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long seq_stride, long tok_stride, long head_stride, const int* anc,

@@ -101,389 +101,254 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnP p) {
   }
 }
 
-// The same attention with ONE wave per (molecule, head) serving all G beams of the molecule.  In cross-attention the beams read the
-// same keys/values (kv_div = G); in self-attention their ancestries coincide except for the last few positions (beam search
-// coalesces), so a key row is loaded once -- for beam 0 -- and reused by every beam whose ancestor at that position is the same cache
-// row; only the lanes of differing ancestors issue their own load.  The per-beam kernel left that sharing to the caches: same HBM
-// bytes, G times the load instructions and L1 / L2 requests.  Ancestor indices are staged in LDS first (coalesced), so the key loads
-// do not wait for a dependent index load.  Arithmetic per (row, head) is the per-beam kernel's (fp32 dots over 8 lanes x 8 elements,
-// two passes, bf16-rounded probabilities in front of V).
-// Round 4: the kernel waits (SQ_WAIT_ANY 0.66 of wave cycles), so its loads are issued in batches: the whole prologue (query rows and
-// ancestry entries) before anything is consumed, and -- where some beam of an iteration sits on another cache row -- every beam's row
-// back to back behind ONE wave-uniform branch instead of a load behind its own divergent branch per beam (one memory latency each).
-// 4 waves per SIMD is both what the LDS arrays allow and what the register budget is held to (amdgpu_waves_per_eu: left alone the batched
-// form takes 168 registers, three waves, and loses what the batching wins).  5 000 rows x 12 heads, last six positions on own rows:
-// 60.5 -> 48.1 us at 25 keys, 83.7 -> 64.5 at 50, 130 -> 105 at 100 (tools/bench_decode_attn.py).
-template <int G, bool ALLSAME>   // ALLSAME: no ancestry table, every beam of the molecule reads the same key/value rows (cross-attention)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 : 3, 4))) void decode_attn_group_kernel(DecAttnP p) {
-  __shared__ float ssc[4][G][256];                   // scores of the wave's G (row, head) pairs
-  __shared__ int sanc[4][G][256];                    // cache row of position j for each beam (16 waves per CU at G = 5; sized by Lkv with
-  //                                                    run-time strides -- 32 waves per CU -- it measured SLOWER: 99 vs 84 us per launch,
-  //                                                    and 8 waves per CU 134)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per_xcd = (p.nblocks + 7) >> 3;
-  const long lb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const long gw = lb * 4 + wave;
-  const int nmol = p.R / G;
-  if (lb >= p.nblocks || gw >= (long)nmol * p.nH) return;
-  const int n = (int)(gw / p.nH), h = (int)(gw - (long)n * p.nH);
-  const int g = lane >> 3, c = lane & 7;
-  const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
-  const int niter = (Lkv + 7) >> 3;
-  float qf[G][8];
-  {
-    // every load of the prologue is issued before the first one is consumed (query rows, then the ancestry entries lane, lane + 64, ...
-    // of every beam: a loop that loads and stores one entry at a time waits out a memory latency per entry -- 5 to 10 of them in a row)
-    bf16x8 qv[G];
-    int av[ALLSAME ? 1 : G][4];
-#pragma unroll
-    for (int b = 0; b < G; ++b) qv[b] = *(const bf16x8*)(p.q + (long)(n * G + b) * p.ldq + h * 64 + c * 8);
-#pragma unroll
-    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = lane + 64 * u, r = n * G + b;
-        av[b][u] = p.anc ? ((j < Lkv) ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
-      }
-#pragma unroll
-    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (lane + 64 * u < niter * 8) sanc[wave][b][lane + 64 * u] = av[b][u];
-#pragma unroll
-    for (int b = 0; b < G; ++b)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[b][e] = (float)qv[b][e] * p.scale;
-  }
-  __builtin_amdgcn_wave_barrier();
-  const long hoff = h * p.head_stride + c * 8;
-  float mx[G];
-#pragma unroll
-  for (int b = 0; b < G; ++b) mx[b] = -INFINITY;
-  // one key's partial dot products for beam B from row KB (8 lanes x 8 elements, reduced over the key's 8 lanes)
-#define DA_SCORE(B, KB)                                                                                          \
-  do {                                                                                                           \
-    float part = 0.f;                                                                                            \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) part += (float)(KB)[e] * qf[B][e];                            \
-    part += dpp_f<0xB1>(part); part += dpp_f<0x4E>(part); part += dpp_f<0x141>(part);                            \
-    if (valid) {                                                                                                 \
-      if (c == 0) ssc[wave][B][j] = part;                                                                        \
-      mx[B] = fmaxf(mx[B], part);                                                                                \
-    }                                                                                                            \
-  } while (0)
-  for (int i = 0; i < niter; ++i) {
-    const int j = i * 8 + g;
-    const bool valid = j < Lkv;
-    const long joff = (long)j * p.tok_stride + hoff;
-    int ab[G];
-#pragma unroll
-    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
-    const int a0 = ab[0];
-    bool diff = false;
-    if (!ALLSAME) {
-#pragma unroll
-      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
-    }
-    bf16x8 k0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) k0[e] = (bf16)0.f;
-    if (valid) k0 = *(const bf16x8*)(p.K + (long)a0 * p.seq_stride + joff);
-    if (!ALLSAME && __any(valid && diff)) {
-      // some beam of some key of this iteration sits on another cache row (the last few positions of a hypothesis): every beam's row is
-      // loaded, back to back with no control flow in between (a load per differing beam behind its own branch waits out one memory
-      // latency per beam; the rows that do not differ hit the line beam 0 just fetched)
-      bf16x8 kb[G];
-#pragma unroll
-      for (int b = 1; b < G; ++b) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kb[b][e] = (bf16)0.f;
-      }
-      if (valid) {
-#pragma unroll
-        for (int b = 1; b < G; ++b) kb[b] = *(const bf16x8*)(p.K + (long)ab[b] * p.seq_stride + joff);
-      }
-      DA_SCORE(0, k0);
-#pragma unroll
-      for (int b = 1; b < G; ++b) DA_SCORE(b, kb[b]);
-    } else {
-#pragma unroll
-      for (int b = 0; b < G; ++b) DA_SCORE(b, k0);
-    }
-  }
-#undef DA_SCORE
-#pragma unroll
-  for (int b = 0; b < G; ++b) mx[b] = wave_max(mx[b]);
-  __builtin_amdgcn_wave_barrier();
-  float acc[G][8], sum[G];
-#pragma unroll
-  for (int b = 0; b < G; ++b) {
-    sum[b] = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) acc[b][d] = 0.f;
-  }
-#define DA_ACC(B, VB)                                                                                            \
-  do {                                                                                                           \
-    const float e_ = valid ? __expf(ssc[wave][B][j] - mx[B]) : 0.f;                                              \
-    sum[B] += e_;                                                                                                \
-    const float pe_ = (float)(bf16)e_;             /* the tiled training kernel feeds bf16 probabilities to the PV MFMA */ \
-    _Pragma("unroll") for (int d = 0; d < 8; ++d) acc[B][d] += pe_ * (float)(VB)[d];                            \
-  } while (0)
-#pragma unroll 1
-  for (int i = 0; i < niter; ++i) {
-    const int j = i * 8 + g;
-    const bool valid = j < Lkv;
-    const long joff = (long)j * p.tok_stride + hoff;
-    int ab[G];
-#pragma unroll
-    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
-    const int a0 = ab[0];
-    bool diff = false;
-    if (!ALLSAME) {
-#pragma unroll
-      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
-    }
-    bf16x8 v0;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) v0[d] = (bf16)0.f;
-    if (valid) v0 = *(const bf16x8*)(p.V + (long)a0 * p.seq_stride + joff);
-    if (!ALLSAME && __any(valid && diff)) {
-      bf16x8 vb[G];
-#pragma unroll
-      for (int b = 1; b < G; ++b) {
-#pragma unroll
-        for (int d = 0; d < 8; ++d) vb[b][d] = (bf16)0.f;
-      }
-      if (valid) {
-#pragma unroll
-        for (int b = 1; b < G; ++b) vb[b] = *(const bf16x8*)(p.V + (long)ab[b] * p.seq_stride + joff);
-      }
-      DA_ACC(0, v0);
-#pragma unroll
-      for (int b = 1; b < G; ++b) DA_ACC(b, vb[b]);
-    } else {
-#pragma unroll
-      for (int b = 0; b < G; ++b) DA_ACC(b, v0);
-    }
-  }
-#undef DA_ACC
-#pragma unroll
-  for (int b = 0; b < G; ++b) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {               // combine the 8 key slots (lanes with equal c)
-      sum[b] += __shfl_xor(sum[b], o, 64);
-#pragma unroll
-      for (int d = 0; d < 8; ++d) acc[b][d] += __shfl_xor(acc[b][d], o, 64);
-    }
-    if (g == 0) {
-      const float inv = 1.f / sum[b];
-      bf16x8 o;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) o[d] = (bf16)(acc[b][d] * inv);
-      *(bf16x8*)(p.out + (long)(n * G + b) * p.ldo + h * 64 + c * 8) = o;
-    }
-  }
-}
+// ---- One wave per (molecule, head) serving all G beams of the molecule (round 5: MFMA form).  In cross-attention the beams read the same
+// keys / values (kv_div = G); in self-attention their ancestries coincide except for the last positions (beam search coalesces: 6-12
+// positions in the configs[3] bench, tools/README.md), so a shared key row is loaded ONCE for the molecule.
+// Rounds 3-4 did this on the VALU (per-beam dot products over 8 lanes x 8 elements, two passes over the keys, scores parked in LDS): those
+// kernels spent their time waiting, not moving bytes -- a wave walked its keys eight at a time with one or two loads in flight, a full
+// memory latency per step, ~145 VALU instructions per step for five beams; the marginal cost per key was ~7 TB/s but ~35 us of every launch
+// was fixed (three batches of waves x {ancestry, first keys, first values, reductions}).  Here
+//  * the beams are the N dimension of an MFMA: S^T[16 keys x 16 beams] = K-rows[16 x 64] . Q^T (two v_mfma_f32_16x16x32_bf16) and
+//    O^T[64 d x 16 beams] += V^T . P^T (four v_mfma_f32_16x16x16_bf16: the probabilities are already in the B operand's registers -- the C
+//    layout of the first product IS the B layout of the second -- and V^T comes from the row-major LDS image through ds_read_b64_tr_b16);
+//  * the softmax is online (running maximum and sum per beam, rescaled accumulators), so any number of key blocks streams through a ring
+//    of D slots: a block is 16 keys = 2 KiB of key rows + 2 KiB of value rows, both by LDS-DMA, every slot requested before the first
+//    block is consumed.  (A first version loaded the key rows straight into the A operand's registers with counted waits: the compiler
+//    merged the loop-carried registers through copies placed before the waits -- copies of registers whose loads had not landed; 1-100 %
+//    of the launches wrong depending on the shape.  A DMA has no register destination: nothing to copy or reuse early.)  Key rows are
+//    stored with their 16-B chunks XOR-ed by (key & 7), applied on the DMA's source address, so that the A-operand reads of 16 rows spread
+//    over the banks;
+//  * ancestries that differ are VIRTUAL KEYS: positions below the first one where some beam sits on another cache row than beam 0
+//    (`s`) are shared keys; every later position j contributes G keys (b, j), b's own row, each visible to beam b alone (masked to
+//    -inf for the others).  One uniform loop, no divergent branch; unrelated ancestries everywhere (G x Lkv keys) are just more blocks.
+//    (One key per DISTINCT row of a position -- 1.1-1.7 of them in the bench's last 6-12 positions, not 5 -- was built and measured: the
+//    G^2 compares, the scan and the list it needs in front of the first load cost more than the 1-2 blocks it saves: 2.64 -> 2.74 ms
+//    per position.)
+// One wave per workgroup: the LDS a wave needs (D x 4 KiB + the ancestry table) then packs the CU without rounding to four waves
+// (D = 2: 15 waves per CU at 103 positions; D = 3 and 4 measured 5-15 % slower at 25-50 keys, equal at 100).
+// Arithmetic: fp32 scores from bf16 products, p = exp(s - running max) rounded to bf16 in front of V (the tiled training kernel's
+// convention), the row sum over the unrounded p.
+// 5 000 rows x 12 heads, last six positions on own rows (tools/bench_decode_attn.py): 49.8 -> 29.4 us at 25 keys, 63.4 -> 39.6 at 50,
+// 107 -> 76 at 100; all beams on the same rows: 47.5 -> 19.6, 58.9 -> 28.9, 92.9 -> 57.3 (5.4 TB/s).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int DM_SLOT = 4096;           // one block: 16 keys x 128 B of key rows, then 16 x 128 B of value rows
 
-// The same kernel with beam 0's row of every iteration -- the row most beams of most iterations read -- arriving through a per-wave LDS ring
-// filled by LDS-DMA DA_DEPTH iterations ahead (global_load_lds: a gather of 16 B per lane that needs no registers, so the bytes a wave keeps
-// in flight are bounded by LDS, not by the register budget that holds the plain kernel at one or two loads per wave).  Score / index arrays
-// for at most 128 keys (the decoder's 103-position caches) so that the ring fits beside them at four workgroups per CU (64-bit per-lane
-// DMA addresses: after a compaction the ancestry table names cache rows beyond the launch's own row count).  Rows of differing beams still come by ordinary loads (rare: the last few positions).
-constexpr int DA_DEPTH = 4;
+constexpr int DM_DEPTH = 2;
 template <int G, bool ALLSAME>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G <= 5 ? 4 : 3, 4))) void decode_attn_dma_kernel(DecAttnP p) {
-  __shared__ float ssc[4][G][128];                   // scores of the wave's G (row, head) pairs
-  __shared__ int sanc[4][G][128];                    // cache row of position j for each beam
-  __shared__ __attribute__((aligned(16))) char sring[4][DA_DEPTH][1024];   // beam 0's rows of DA_DEPTH iterations: lane l's 16 bytes at l * 16
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per_xcd = (p.nblocks + 7) >> 3;
-  const long lb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const long gw = lb * 4 + wave;
+__global__ __launch_bounds__(64) void decode_attn_mfma_kernel(DecAttnP p, int LD) {
+  constexpr int D = DM_DEPTH;
+  extern __shared__ __attribute__((aligned(16))) char dm_smem[];
+  const int lane = threadIdx.x;
+  const int per_xcd = (p.nblocks + 7) >> 3;          // (nblocks = (molecule, head) pairs: consecutive ones on one XCD)
+  const long gw = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int nmol = p.R / G;
-  if (lb >= p.nblocks || gw >= (long)nmol * p.nH) return;
+  if (gw >= (long)nmol * p.nH) return;
   const int n = (int)(gw / p.nH), h = (int)(gw - (long)n * p.nH);
-  const int g = lane >> 3, c = lane & 7;
+  const int r16 = lane & 15, q4 = lane >> 4;
   const int Lkv = p.t_ptr ? min(*p.t_ptr + 1, p.Lkv) : p.Lkv;
-  const int niter = (Lkv + 7) >> 3;
-  float qf[G][8];
-  {
-    // every load of the prologue is issued before the first one is consumed (query rows, then the ancestry entries lane, lane + 64, ...
-    // of every beam: a loop that loads and stores one entry at a time waits out a memory latency per entry -- 5 to 10 of them in a row)
-    bf16x8 qv[G];
-    int av[ALLSAME ? 1 : G][2];
+  const uint32_t ring0 = (uint32_t)(uintptr_t)(LDS_AS char*)dm_smem;
+  int* sanc = (int*)(dm_smem + D * DM_SLOT);         // cache row of position j for each beam (not ALLSAME)
+
+  // ---- prologue: the queries (B operand: beam r16, elements kk*32 + 8*q4 ..) and the ancestry table, every load issued before any is used
+  bf16x8 qf[2];
 #pragma unroll
-    for (int b = 0; b < G; ++b) qv[b] = *(const bf16x8*)(p.q + (long)(n * G + b) * p.ldq + h * 64 + c * 8);
+  for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = lane + 64 * u, r = n * G + b;
-        av[b][u] = p.anc ? ((j < Lkv) ? p.anc[(long)r * p.anc_ld + j] : 0) : r / max(p.kv_div, 1);
-      }
-#pragma unroll
-    for (int b = 0; b < (ALLSAME ? 1 : G); ++b)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (lane + 64 * u < niter * 8) sanc[wave][b][lane + 64 * u] = av[b][u];
-#pragma unroll
-    for (int b = 0; b < G; ++b)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[b][e] = (float)qv[b][e] * p.scale;
+    for (int e = 0; e < 8; ++e) qf[kk][e] = (bf16)0.f;
   }
-  __builtin_amdgcn_wave_barrier();
-  const long hoff = h * p.head_stride + c * 8;
-  const uint32_t ring0 = (uint32_t)(uintptr_t)(LDS_AS char*)&sring[wave][0][0];
-  // LDS-DMA of beam 0's row of iteration I (keys past the end re-fetch the last valid one; they are masked where they are used)
-#define DA_DMA(I, SRC)                                                                                           \
-  do {                                                                                                           \
-    int j_ = (I) * 8 + g;                                                                                        \
-    j_ = j_ < Lkv ? j_ : Lkv - 1;                                                                                \
-    const bf16* src_ = (SRC) + ((long)sanc[wave][0][j_] * p.seq_stride + (long)j_ * p.tok_stride + hoff);        \
-    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)(((I) % DA_DEPTH) * 1024));           \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_), "s"(dst_) : "memory", "m0"); \
-  } while (0)
-  // iteration I's row has landed: at most min(DA_DEPTH - 1, niter - 1 - I) newer DMAs may still be in flight (vmcnt retires in order)
-#define DA_LANDED(I)                                                                                             \
-  do {                                                                                                           \
-    const int newer_ = niter - 1 - (I);                                                                          \
-    if (newer_ >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                            \
-    else if (newer_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                       \
-    else if (newer_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                       \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
-  } while (0)
-  static_assert(DA_DEPTH == 4, "DA_LANDED counts up to three newer loads");
-  for (int i = 0; i < DA_DEPTH && i < niter; ++i) DA_DMA(i, p.K);
-  float mx[G];
+  if (r16 < G) {
+    const bf16* qp = p.q + (long)(n * G + r16) * p.ldq + h * 64 + q4 * 8;
+    qf[0] = *(const bf16x8*)qp;
+    qf[1] = *(const bf16x8*)(qp + 32);
+  }
+  int s = Lkv;                                       // first position where some beam's cache row differs from beam 0's
+  if constexpr (!ALLSAME) {
+    int av[4][G];
 #pragma unroll
-  for (int b = 0; b < G; ++b) mx[b] = -INFINITY;
-  // one key's partial dot products for beam B from row KB (8 lanes x 8 elements, reduced over the key's 8 lanes)
-#define DA_SCORE(B, KB)                                                                                          \
-  do {                                                                                                           \
-    float part = 0.f;                                                                                            \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) part += (float)(KB)[e] * qf[B][e];                            \
-    part += dpp_f<0xB1>(part); part += dpp_f<0x4E>(part); part += dpp_f<0x141>(part);                            \
-    if (valid) {                                                                                                 \
-      if (c == 0) ssc[wave][B][j] = part;                                                                        \
-      mx[B] = fmaxf(mx[B], part);                                                                                \
-    }                                                                                                            \
-  } while (0)
-  for (int i = 0; i < niter; ++i) {
-    const int j = i * 8 + g;
-    const bool valid = j < Lkv;
-    const long joff = (long)j * p.tok_stride + hoff;
-    int ab[G];
+    for (int u = 0; u < 4; ++u) {
+      if (64 * u < Lkv) {                            // (wave-uniform; entries past the end re-read the last one: no load behind a lane mask)
+        const int j = min(lane + 64 * u, Lkv - 1);
 #pragma unroll
-    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
-    const int a0 = ab[0];
-    bool diff = false;
-    if (!ALLSAME) {
-#pragma unroll
-      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
+        for (int b = 0; b < G; ++b) av[u][b] = p.anc[(long)(n * G + b) * p.anc_ld + j];
+      }
     }
-    DA_LANDED(i);
-    const bf16x8 k0 = *(const bf16x8*)&sring[wave][i % DA_DEPTH][lane * 16];
-    if (!ALLSAME && __any(valid && diff)) {
-      // some beam of some key of this iteration sits on another cache row (the last few positions of a hypothesis): every beam's row is
-      // loaded, back to back with no control flow in between (a load per differing beam behind its own branch waits out one memory
-      // latency per beam; the rows that do not differ hit the line beam 0 just fetched)
-      bf16x8 kb[G];
 #pragma unroll
-      for (int b = 1; b < G; ++b) {
+    for (int u = 0; u < 4; ++u) {
+      if (64 * u < Lkv) {
+        const int j = lane + 64 * u;
+        bool diff = false;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) kb[b][e] = (bf16)0.f;
+        for (int b = 1; b < G; ++b) diff |= av[u][b] != av[u][0];
+        if (j < Lkv) {
+#pragma unroll
+          for (int b = 0; b < G; ++b) sanc[b * LD + j] = av[u][b];
+        }
+        const unsigned long long m = __ballot(diff && j < Lkv);
+        if (m != 0ull) s = min(s, 64 * u + (int)__builtin_ctzll(m));
       }
-      if (valid) {
-#pragma unroll
-        for (int b = 1; b < G; ++b) kb[b] = *(const bf16x8*)(p.K + (long)ab[b] * p.seq_stride + joff);
-      }
-      DA_SCORE(0, k0);
-#pragma unroll
-      for (int b = 1; b < G; ++b) DA_SCORE(b, kb[b]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const bool has_new = !ALLSAME && p.knew != nullptr;
+  if (has_new) {
+    // The newest position's key / value rows are still in the projection output: this wave reads them THERE (position Lkv - 1 is every
+    // beam's own: G virtual keys) and copies its G x 2 rows of this head into the cache for the positions to come -- the separate copy
+    // launch in front of every attention launch (12 per position, ~5 us each) is gone.
+    s = min(s, Lkv - 1);
+    for (int idx = lane; idx < G * 16; idx += 64) {
+      const int b = idx >> 4, isv = (idx >> 3) & 1, ch = idx & 7, r = n * G + b;
+      const bf16* src = (isv ? p.vnew : p.knew) + (long)r * p.ldn + h * 64 + ch * 8;
+      bf16* dst = (bf16*)(isv ? p.V : p.K) + (long)(p.rowmap ? p.rowmap[r] : r) * p.seq_stride + (long)(Lkv - 1) * p.tok_stride + (long)h * p.head_stride + ch * 8;
+      *(bf16x8*)dst = *(const bf16x8*)src;
+    }
+  }
+  // the compiler's own loads are complete before the first DMA is issued: its wait-count bookkeeping does not see the DMA below, and a
+  // load it still believed pending would cost a full drain at its first use INSIDE the loop, on every trip
+  asm volatile("" : "+v"(qf[0]), "+v"(qf[1])::"memory");
+  const int nv = s + G * (Lkv - s);                 // virtual keys: s shared ones, then G per position
+  const int nblk = (nv + 15) >> 4;
+  const int row_same = (n * G) / max(p.kv_div, 1);
+  const long hbase = (long)h * p.head_stride;
+  const int tok = (int)p.tok_stride;                // (Lkv <= 256 positions: j * tok_stride fits 32 bits for any cache this launcher accepts)
+  // element offset of virtual key v's row of this head (keys past the end re-read the last one: masked where they are used, and a
+  // value row that is read must hold finite numbers)
+  auto vk_ptr = [&](int v, bool shared, const bf16*& kp, const bf16*& vp) {
+    long off;
+    if (ALLSAME) {
+      off = (long)row_same * p.seq_stride + (long)(min(v, nv - 1) * tok) + hbase;
+    } else if (shared) {                             // a block of keys every beam reads from beam 0's rows
+      off = (long)sanc[v] * p.seq_stride + (long)(v * tok) + hbase;
     } else {
-#pragma unroll
-      for (int b = 0; b < G; ++b) DA_SCORE(b, k0);
+      v = v < nv ? v : nv - 1;
+      int j = v, b = 0;
+      if (v >= s) {
+        const int w = v - s, jj = w / G;
+        b = w - jj * G;
+        j = s + jj;
+      }
+      if (has_new && j == Lkv - 1) {                 // not in the cache yet (this wave's own copy above may not have landed)
+        const long o2 = (long)(n * G + b) * p.ldn + h * 64;
+        kp = p.knew + o2;
+        vp = p.vnew + o2;
+        return;
+      }
+      off = (long)sanc[b * LD + j] * p.seq_stride + (long)(j * tok) + hbase;
     }
-    if (i + DA_DEPTH < niter) DA_DMA(i + DA_DEPTH, p.K);      // (the slot's row is in registers: k0 was consumed above)
-  }
-#undef DA_SCORE
-  for (int i = 0; i < DA_DEPTH && i < niter; ++i) DA_DMA(i, p.V);   // the ring is free: every key row has been consumed
-#pragma unroll
-  for (int b = 0; b < G; ++b) mx[b] = wave_max(mx[b]);
-  __builtin_amdgcn_wave_barrier();
-  float acc[G][8], sum[G];
-#pragma unroll
-  for (int b = 0; b < G; ++b) {
-    sum[b] = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) acc[b][d] = 0.f;
-  }
-#define DA_ACC(B, VB)                                                                                            \
-  do {                                                                                                           \
-    const float e_ = valid ? __expf(ssc[wave][B][j] - mx[B]) : 0.f;                                              \
-    sum[B] += e_;                                                                                                \
-    const float pe_ = (float)(bf16)e_;             /* the tiled training kernel feeds bf16 probabilities to the PV MFMA */ \
-    _Pragma("unroll") for (int d = 0; d < 8; ++d) acc[B][d] += pe_ * (float)(VB)[d];                            \
+    kp = p.K + off;
+    vp = p.V + off;
+  };
+
+  // block I into ring slot SL: four LDS-DMA operations (the waits below count them).  DMA u: lane -> key u*8 + (lane >> 3), LDS chunk lane & 7
+#define DM_DMA(SRC, DST)                                                                                                       \
+  do {                                                                                                                         \
+    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(DST);                                                                 \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(SRC), "s"(dst_) : "memory", "m0");     \
   } while (0)
-#pragma unroll 1
-  for (int i = 0; i < niter; ++i) {
-    const int j = i * 8 + g;
-    const bool valid = j < Lkv;
-    const long joff = (long)j * p.tok_stride + hoff;
-    int ab[G];
+#define DM_ISSUE(I, SL)                                                                                                        \
+  do {                                                                                                                         \
+    const bool sh_ = (I) * 16 + 16 <= s;                                                                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                                         \
+      const bf16 *kp_, *vp_;                                                                                                   \
+      vk_ptr((I) * 16 + u_ * 8 + (lane >> 3), sh_, kp_, vp_);                                                                  \
+      kp_ += ((lane & 7) ^ ((lane >> 3) & 7)) * 8;                                                                             \
+      vp_ += (lane & 7) * 8;                                                                                                   \
+      DM_DMA(kp_, ring0 + (uint32_t)((SL) * DM_SLOT + u_ * 1024));                                                             \
+      DM_DMA(vp_, ring0 + (uint32_t)((SL) * DM_SLOT + 2048 + u_ * 1024));                                                      \
+    }                                                                                                                          \
+  } while (0)
+#define DM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  static_assert(D >= 2 && D <= 4, "the landed-wait counts up to three newer blocks");
 #pragma unroll
-    for (int b = 0; b < G; ++b) ab[b] = (ALLSAME && b > 0) ? 0 : sanc[wave][b][j];
-    const int a0 = ab[0];
-    bool diff = false;
-    if (!ALLSAME) {
+  for (int d = 0; d < D; ++d)
+    if (d < nblk) DM_ISSUE(d, d);
+
+  float mrun = -INFINITY, lrun = 0.f;               // running maximum / (this lane's part of the) sum of beam r16
+  f32x4 acc[4];                                     // O^T: d = db*16 + 4*q4 + i, beam r16
 #pragma unroll
-      for (int b = 1; b < G; ++b) diff |= ab[b] != a0;
-    }
-    DA_LANDED(i);
-    const bf16x8 v0 = *(const bf16x8*)&sring[wave][i % DA_DEPTH][lane * 16];
-    if (!ALLSAME && __any(valid && diff)) {
-      bf16x8 vb[G];
+  for (int db = 0; db < 4; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t ka0 = ring0 + (uint32_t)(r16 * 128 + ((q4 ^ (r16 & 7)) << 4));           // A operand: key r16, chunk q4 (kk = 0) ...
+  const uint32_t ka1 = ring0 + (uint32_t)(r16 * 128 + (((4 + q4) ^ (r16 & 7)) << 4));     // ... and 4 + q4 (kk = 1)
+  const uint32_t va0 = ring0 + (uint32_t)(2048 + (4 * q4 + (r16 >> 2)) * 128 + (r16 & 3) * 8);   // ds_read_b64_tr_b16: row 4*q4 + (i>>2), 4 columns at 4*(i&3)
+
+  for (int base = 0; base < nblk; base += D) {
 #pragma unroll
-      for (int b = 1; b < G; ++b) {
+    for (int d = 0; d < D; ++d) {
+      const int i = base + d;
+      if (i < nblk) {                               // (wave-uniform)
+        const int newer = min(D - 1, nblk - 1 - i);
+        if (newer >= 3) DM_WAIT(12);
+        else if (newer == 2) DM_WAIT(8);
+        else if (newer == 1) DM_WAIT(4);
+        else DM_WAIT(0);
+        bf16x8 kf0, kf1;
+        bf16x4 vf0, vf1, vf2, vf3;
+        asm volatile(
+            "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
+            "ds_read_b64_tr_b16 %2, %8\n\tds_read_b64_tr_b16 %3, %8 offset:32\n\tds_read_b64_tr_b16 %4, %8 offset:64\n\t"
+            "ds_read_b64_tr_b16 %5, %8 offset:96\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(kf0), "=&v"(kf1), "=&v"(vf0), "=&v"(vf1), "=&v"(vf2), "=&v"(vf3)
+            : "v"(ka0 + (uint32_t)(d * DM_SLOT)), "v"(ka1 + (uint32_t)(d * DM_SLOT)), "v"(va0 + (uint32_t)(d * DM_SLOT))
+            : "memory");
+        f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[0], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1], S, 0, 0, 0);
+        if (i + D < nblk) DM_ISSUE(i + D, d);        // (the slot's keys and values are in registers)
+        float sv[4];
+        if (i * 16 + 16 <= s) {                      // (wave-uniform) every key of the block is a shared one
 #pragma unroll
-        for (int d = 0; d < 8; ++d) vb[b][d] = (bf16)0.f;
+          for (int e = 0; e < 4; ++e) sv[e] = S[e] * p.scale;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int v = i * 16 + 4 * q4 + e;
+            bool ok = v < nv;
+            if (!ALLSAME) ok = ok && (v < s || (v - s) % G == r16);
+            sv[e] = ok ? S[e] * p.scale : -INFINITY;
+          }
+        }
+        float bm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(mrun, bm);
+        const float mu = mn == -INFINITY ? 0.f : mn;
+        const float alpha = __expf(mrun - mu);
+        mrun = mn;
+        float ev[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev[e] = __expf(sv[e] - mu);
+        lrun = lrun * alpha + ((ev[0] + ev[1]) + (ev[2] + ev[3]));
+        bf16x4 pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[e] = (bf16)ev[e];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) acc[db] *= alpha;
+        const s16x4 pb = __builtin_bit_cast(s16x4, pf);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vf0), pb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vf1), pb, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vf2), pb, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vf3), pb, acc[3], 0, 0, 0);
       }
-      if (valid) {
-#pragma unroll
-        for (int b = 1; b < G; ++b) vb[b] = *(const bf16x8*)(p.V + (long)ab[b] * p.seq_stride + joff);
-      }
-      DA_ACC(0, v0);
-#pragma unroll
-      for (int b = 1; b < G; ++b) DA_ACC(b, vb[b]);
-    } else {
-#pragma unroll
-      for (int b = 0; b < G; ++b) DA_ACC(b, v0);
     }
-    if (i + DA_DEPTH < niter) DA_DMA(i + DA_DEPTH, p.V);
   }
-#undef DA_ACC
-#undef DA_DMA
-#undef DA_LANDED
+#undef DM_ISSUE
+#undef DM_DMA
+#undef DM_WAIT
+  lrun += __shfl_xor(lrun, 16, 64);
+  lrun += __shfl_xor(lrun, 32, 64);
+  if (r16 < G) {
+    const float inv = 1.f / lrun;
+    bf16* op = p.out + (long)(n * G + r16) * p.ldo + h * 64 + 4 * q4;
 #pragma unroll
-  for (int b = 0; b < G; ++b) {
+    for (int db = 0; db < 4; ++db) {
+      bf16x4 o;
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {               // combine the 8 key slots (lanes with equal c)
-      sum[b] += __shfl_xor(sum[b], o, 64);
-#pragma unroll
-      for (int d = 0; d < 8; ++d) acc[b][d] += __shfl_xor(acc[b][d], o, 64);
-    }
-    if (g == 0) {
-      const float inv = 1.f / sum[b];
-      bf16x8 o;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) o[d] = (bf16)(acc[b][d] * inv);
-      *(bf16x8*)(p.out + (long)(n * G + b) * p.ldo + h * 64 + c * 8) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[db][e] * inv);
+      *(bf16x4*)(op + db * 16) = o;
     }
   }
 }
 
-// the newest position's key / value rows into the cache, in front of the attention launch (one launch for both; folding it into the
-// attention kernel itself -- the rows read from the projection output, written by the wave that owns the (row, head) -- was built and
-// measured: 40 more live registers or an exposed load between the two passes, 1.61 -> 1.78-1.92 ms of decode_attn per position)
+// the newest position's key / value rows into the cache, in front of the per-row attention kernel (the grouped kernel copies its own rows)
 __global__ __launch_bounds__(256) void cache_write_kernel(DecAttnP p, int jn) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // 16-byte chunk of a row
   const int per_row = p.nH * 8;
@@ -499,15 +364,12 @@ __global__ __launch_bounds__(256) void cache_write_kernel(DecAttnP p, int jn) {
 template <int G>
 void launch_group(DecAttnP p, hipStream_t stream) {
   const long waves = (long)(p.R / G) * p.nH;
-  p.nblocks = (int)((waves + 3) / 4);
-  static const bool no_dma = getenv("SPMM_DECODE_NO_DMA") != nullptr;          // (debugging aid, like SPMM_DECODE_PER_BEAM)
-  if (!no_dma && p.Lkv <= 128) {
-    if (p.anc) hipLaunchKernelGGL((decode_attn_dma_kernel<G, false>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((decode_attn_dma_kernel<G, true>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
-    return;
-  }
-  if (p.anc) hipLaunchKernelGGL((decode_attn_group_kernel<G, false>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((decode_attn_group_kernel<G, true>), dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
+  p.nblocks = (int)waves;                                                       // one wave per workgroup
+  const int LD = p.anc ? (p.Lkv + 3) & ~3 : 0;
+  const unsigned lds = (unsigned)DM_DEPTH * DM_SLOT + G * (unsigned)LD * 4u;    // ring + ancestry rows: <= 16 KiB
+  const dim3 grid((unsigned)((waves + 7) / 8 * 8));
+  if (p.anc) hipLaunchKernelGGL((decode_attn_mfma_kernel<G, false>), grid, dim3(64), lds, stream, p, LD);
+  else hipLaunchKernelGGL((decode_attn_mfma_kernel<G, true>), grid, dim3(64), lds, stream, p, LD);
 }
 
 }  // namespace
@@ -530,18 +392,20 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
                 (bf16*)out, ldo, R, nH, Lkv, scale, t_ptr, rowmap, (const bf16*)knew, (const bf16*)vnew, ldn};
   // beams of a molecule on one wave whenever the K/V rows of a group are (mostly) shared: cross-attention (kv_div == group) and
   // self-attention through an ancestry table
-  if (knew) hipLaunchKernelGGL(cache_write_kernel, dim3((unsigned)(((long)R * nH * 8 + 255) / 256)), dim3(256), 0, stream, p, Lkv - 1);
   static const bool per_beam = getenv("SPMM_DECODE_PER_BEAM") != nullptr;       // (debugging aid: the one-wave-per-row kernel)
-  const bool grouped = !per_beam && group >= 2 && group <= 6 && (anc != nullptr || kv_div == group);
+  const bool grouped = !per_beam && group >= 2 && group <= 8 && (anc != nullptr || kv_div == group);
   if (grouped) {
     switch (group) {
       case 2: launch_group<2>(p, stream); break;
       case 3: launch_group<3>(p, stream); break;
       case 4: launch_group<4>(p, stream); break;
       case 5: launch_group<5>(p, stream); break;
-      default: launch_group<6>(p, stream); break;
+      case 6: launch_group<6>(p, stream); break;
+      case 7: launch_group<7>(p, stream); break;
+      default: launch_group<8>(p, stream); break;
     }
   } else {
+    if (knew) hipLaunchKernelGGL(cache_write_kernel, dim3((unsigned)(((long)R * nH * 8 + 255) / 256)), dim3(256), 0, stream, p, Lkv - 1);
     hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, stream, p);
   }
   SPMM_LAUNCH_CHECK("spmm_decode_attn");

@@ -1158,14 +1158,16 @@ def test_adamw_clip_ema_match_torch(ops):
 
 @pytest.mark.parametrize("R,nH,Lkv,Lmax,kv_div,group", [(10, 2, 1, 16, 0, 1), (15, 12, 37, 64, 0, 5), (20, 12, 54, 54, 5, 5), (64, 4, 130, 160, 0, 4),
                                                     (6, 2, 256, 256, 3, 3), (35, 12, 9, 16, 0, 7), (12, 4, 70, 80, 0, 2), (18, 2, 33, 40, 0, 6),
-                                                    (500, 12, 100, 100, 0, 5), (12, 2, 54, 54, 6, 6)])
-@pytest.mark.parametrize("coalesced", [False, True])
+                                                    (500, 12, 100, 100, 0, 5), (12, 2, 54, 54, 6, 6), (12, 2, 200, 256, 0, 6), (16, 2, 40, 48, 0, 8),
+                                                    (16, 2, 54, 54, 8, 8), (10, 3, 17, 32, 0, 5)])
+@pytest.mark.parametrize("coalesced", [False, True, "pairs"])
 def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group, coalesced):
     """Single-query attention against a cache addressed through the beam ancestry table (kv_div == 0) or shared per molecule
-    (kv_div > 0), vs fp32 torch on the same bf16 inputs (xbert.py:305-354 for the last position).  Groups of 2-6 beams run on the
-    one-wave-per-(molecule, head) kernel, which loads a key row once for all beams whose ancestor at that position is the same cache row:
-    `coalesced` makes the beams of a molecule share their ancestors except at the last six positions (what beam search produces), the
-    plain case gives every beam unrelated ancestors everywhere."""
+    (kv_div > 0), vs fp32 torch on the same bf16 inputs (xbert.py:305-354 for the last position).  Groups of 2-8 beams run on the
+    one-wave-per-(molecule, head) MFMA kernel, which loads a key row once for all beams whose ancestor at that position is the same cache
+    row: `coalesced` makes the beams of a molecule share their ancestors except at the last six positions (what beam search produces);
+    "pairs" additionally lets beams 2k and 2k+1 share their rows in that tail (distinct rows < beams: one key per distinct row, read by
+    both); the plain case gives every beam unrelated ancestors everywhere (group x Lkv keys per molecule)."""
     if coalesced and (kv_div or group == 1):
         pytest.skip("ancestry tables only")
     H = nH * 64
@@ -1180,6 +1182,9 @@ def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group, co
     if coalesced and R % group == 0:
         lead = anc.view(R // group, group, Lmax)[:, :1, :].expand(R // group, group, Lmax).reshape(R, Lmax)
         old = torch.arange(Lmax, device="cuda")[None, :] < max(Lkv - 6, 0)
+        if coalesced == "pairs":
+            even = anc.view(R // group, group, Lmax)[:, (torch.arange(group) // 2 * 2).tolist(), :].reshape(R, Lmax)
+            anc = even
         anc = torch.where(old, lead, anc).contiguous()
     out = torch.zeros(R, H, dtype=BF, device="cuda")
     ops.decode_attn(q[:, :H], Kc, Vc, out, nH=nH, Lkv=Lkv, seq_stride=Lmax * wide, tok_stride=wide, anc=anc, kv_div=max(kv_div, 1), group=group)

@@ -948,12 +948,14 @@ def test_batched_decode_against_the_reference_search(env, golden_dir):
     assert same >= props.shape[0] - 2, diff
 
 
-@pytest.mark.parametrize("seed,gap,scale", [(5, 0.9, 10.0), (2, 0.9, 2.0)])
+@pytest.mark.parametrize("seed,gap,scale", [(5, 0.9, 10.0), (7, 1.1, 5.0), (7, 1.1, 20.0)])
 def test_batched_decode_drops_finished_molecules(env, seed, gap, scale):
     """Molecules that hold their k finals leave the decoded batch (decode.beam_search_batched(compact=True): activations, ancestry rows and
     cross-attention keys / values are gathered for the live ones, the K/V caches stay in place behind a row map): the hypotheses are those
     of the run that keeps every molecule to the end -- token for token, scores within 1e-4 -- on a model whose molecules finish at different
-    positions (some never collect five finals), and the batch really shrank."""
+    positions (some never collect five finals), and the batch really shrank.  (The tiny closed-form model hardly reacts to the properties:
+    which molecules finish when is decided by near-ties, so the scenarios are picked per attention kernel -- these three shrink the batch
+    once or twice with the round-5 kernel.)"""
     O, SPMM, tiny_config, *_ = env
     from spmm_amd import decode
     sd = _peaky_lm(O.closed_form_state_dict(O.tiny_cfg()), seed=seed, sep_gap=gap)
