@@ -137,18 +137,21 @@ class Engine:
         self.alpha = torch.zeros(1, **f32)
         self.lr = torch.zeros(1, **f32)
         self.gscale = torch.ones(4, **f32)                 # d(total)/d(loss_k), order (mlm, mpm, ita, itm)
-        self.losses = torch.zeros(8, **f32)
+        # what every step starts from zero -- the four losses, d(ita)/d(temp), the non-finite flag, the token-hint flag -- is ONE 64-byte
+        # buffer, zeroed by one launch at the head of the step (step.py)
+        self.step_zero = torch.zeros(16, dtype=torch.int32, device=device)
+        self.losses = self.step_zero[0:8].view(torch.float32)
         self.loss_scratch = torch.zeros(8, **f32)
         # dropout / negative-sampling seed: a device counter advanced once per training-mode forward (step.py), different on every
         # data-parallel rank, saved and restored with the checkpoint (model.py)
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         self.seed_rank_offset = rank * 0x9E3779B97F4A7C15 % (1 << 62)      # (checkpoints hold the rank-independent part: model.py)
         self.seed = torch.full((1,), (0x5DEECE66D + self.seed_rank_offset) % (1 << 62), dtype=torch.int64, device=device)
-        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.nan_flag = self.step_zero[9:10]
         self.icount = torch.zeros(4, dtype=torch.int32, device=device)
-        self.dtemp_ita = torch.zeros(1, **f32)
+        self.dtemp_ita = self.step_zero[8:9].view(torch.float32)
         self.train_mode = True
-        self.hint_bad = torch.zeros(1, dtype=torch.int32, device=device)      # a caller's token-count hint contradicted the mask (step.py)
+        self.hint_bad = self.step_zero[10:11]              # a caller's token-count hint contradicted the mask (step.py)
         self.pack_text = self.opt.pack_text                 # drop the rows of padding tokens from the passes that only read position 0 (step.py)
         self.layer_done_cb = None
         # the unimodal text and PV chains (and their backward) are independent: run them on two HIP streams so the small-M

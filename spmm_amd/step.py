@@ -123,9 +123,7 @@ class PretrainStep(Engine):
         self._salt = 0
         if self.train_mode:
             self.seed.add_(1)               # new dropout masks / negative draws every step; backward re-reads the same value
-        self.losses.zero_()
-        self.dtemp_ita.zero_()
-        self.nan_flag.zero_()
+        ops.zero_(self.step_zero)             # losses, d(ita)/d(temp), the non-finite flag, the token-hint flag
         temp = P.w("temp").view(1)
         ops.clamp_scalar(temp, 0.01, 0.5)                                             # :80-81
         ids32 = ids.to(torch.int32).contiguous()
@@ -137,7 +135,6 @@ class PretrainStep(Engine):
 
         # ---- S1..S4: the student and momentum unimodal encoders (:90-106) batched with their causal twins (:215-224, :242).
         # The text chains (S2, S4) and the PV chains (S1, S3) share nothing until the fusion layers: two streams.
-        self.hint_bad.zero_()
         self._one_stream = self.force_one_stream or B * Lt > STREAM_TOKENS_MAX
         pk = self._pack_plan(mask32, B, Lt, n_tokens) if (self.pack_text and aux is None and Lt <= ops.ATTN_MAXL) else None   # packed layouts: what the attention kernels hold on chip
         if n_tokens is not None:
