@@ -543,9 +543,31 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamP p) {
           if (p.parent_out) p.parent_out[crow] = flat[r] / k;
         }
       }
-  } else if (lane < k) {
-    p.ids_out[(long)ci * k + lane] = 0;                                 // a finished molecule keeps decoding [PAD]s nobody reads
-    if (p.parent_out) p.parent_out[(long)ci * k + lane] = lane;
+  } else {
+    if (!was_done && p.anc) {
+      // A molecule that has just finished stays in the batch until the next compaction (or to the end, under a replayed graph) and keeps
+      // decoding [PAD]s nobody reads.  Left alone its ancestry rows would say "own row" for every later position -- k unrelated rows per
+      // position, the attention kernel's expensive case, growing with every step.  All its beams take beam 0's ancestry instead: one
+      // shared row per position.
+      const long crow0 = (long)ci * k;
+      const int own0 = p.rowmap ? p.rowmap[crow0] : (int)crow0;
+      int a0[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pos = lane + 64 * q;
+        a0[q] = pos < L ? (pos < t ? p.anc[crow0 * p.anc_ld + pos] : own0) : 0;
+      }
+      for (int r = 0; r < k; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pos = lane + 64 * q;
+          if (pos < L) p.anc[(crow0 + r) * p.anc_ld + pos] = a0[q];
+        }
+    }
+    if (lane < k) {
+      p.ids_out[(long)ci * k + lane] = 0;
+      if (p.parent_out) p.parent_out[(long)ci * k + lane] = lane;
+    }
   }
   if (lane == 0) {
     p.fin_n[n] = fin_n;

@@ -1307,6 +1307,10 @@ def test_beam_step_kernel_matches_tensor_bookkeeping(N, k, V):
         assert torch.equal(ids.long()[lr], tok.reshape(R)[lr]), s
         assert torch.equal(anc_fus[lr], anc_ref[lr]), s
         anc_ref = torch.where(lr[:, None], anc_ref, anc_fus)         # finished molecules: the tensor form permutes rows nobody reads
+        # a finished molecule stays in the batch until a compaction: the kernel gives all its beams beam 0's ancestry (one shared cache row
+        # per position instead of k unrelated ones per position after its end -- the attention kernel's expensive case)
+        af = anc_fus.view(N, k, L)
+        assert torch.equal(af[ref.done], af[ref.done][:, :1].expand(-1, k, -1)), s
         n_fin = int(ref.fin_n.sum())
         if bool(ref.done.all()):
             break
