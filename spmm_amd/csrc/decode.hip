@@ -393,9 +393,10 @@ extern "C" int spmm_decode_attn(const void* q, long ldq, const void* K, const vo
   // beams of a molecule on one wave whenever the K/V rows of a group are (mostly) shared: cross-attention (kv_div == group) and
   // self-attention through an ancestry table
   static const bool per_beam = getenv("SPMM_DECODE_PER_BEAM") != nullptr;       // (debugging aid: the one-wave-per-row kernel)
-  const bool grouped = !per_beam && group >= 2 && group <= 8 && (anc != nullptr || kv_div == group);
+  const bool grouped = !per_beam && group >= 1 && group <= 8 && (anc != nullptr || kv_div == group);
   if (grouped) {
     switch (group) {
+      case 1: launch_group<1>(p, stream); break;
       case 2: launch_group<2>(p, stream); break;
       case 3: launch_group<3>(p, stream); break;
       case 4: launch_group<4>(p, stream); break;

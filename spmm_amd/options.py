@@ -17,6 +17,7 @@ _ENV = {
     "fuse_drop_res": ("SPMM_FUSE_DROP_RES", lambda s: s == "1"),
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
+    "pv_wgrad_inline": ("SPMM_PV_WGRAD_INLINE", int),
     "fp8": ("SPMM_FP8", lambda s: s == "1"),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
     "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
@@ -42,6 +43,9 @@ class EngineOptions:
     #                               instead of 1.3e-3, loss_ita 4.8e-3 instead of 3.6e-3 (EXPERIMENTS.md 3.4)
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
+    pv_wgrad_inline: int = 3      # ... except those of the PV encoder's first `n` layers (the LAST its backward reaches), which stay on that chain's
+    #                               own stream: it ends ~2 ms before the text encoder's on the side stream, and the one weight-gradient stream,
+    #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10)
     fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)
     # --- precision tiers (NOT the headline configuration) ---
     fp8: bool = False             # E4M3 FFN forward GEMMs (BASELINE configs[4])
@@ -80,5 +84,5 @@ class EngineOptions:
 # Debugging aids outside EngineOptions (they change no result): SPMM_DEBUG_SYNC=1 names every launch and drains the GPU after it
 # (ops.py); SPMM_BENCH_WATCHDOG=<s> makes bench.py dump all Python stacks and exit non-zero after <s> seconds;
 # SPMM_DIST_BACKEND=gloo lets the test harness put two ranks on one GPU (bench.py / pretrain.py); SPMM_DECODE_PER_BEAM=1 makes
-# spmm_decode_attn take its one-wave-per-beam-row kernel instead of the one-wave-per-molecule one, SPMM_DECODE_NO_DMA=1 the one-wave-per-molecule kernel without its LDS-DMA ring
-# (csrc/decode.hip, same results).
+# spmm_decode_attn take its one-wave-per-beam-row kernel instead of the one-wave-per-molecule one (csrc/decode.hip; same results up to the
+# summation order).

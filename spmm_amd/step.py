@@ -517,7 +517,13 @@ class PretrainStep(Engine):
         dY1 = self._new(2 * B * Lp, H)
         ops.cast_f32_bf16(d_pe.view(-1), dY1[:B * Lp].view(-1))
         dY1[B * Lp:].copy_(dX12)
-        dX1 = self.stack_bwd("property_encoder.", cp, range(cp.num_hidden_layers), T["tape1"], dY1, T["g1"])
+        # the first layers' weight gradients (the last ones this chain reaches) stay on this stream (EngineOptions.pv_wgrad_inline)
+        nl1 = cp.num_hidden_layers
+        k1 = min(max(int(self.opt.pv_wgrad_inline), 0), nl1) if side is not None else 0
+        dX1 = self.stack_bwd("property_encoder.", cp, range(k1, nl1), T["tape1"][k1:], dY1, T["g1"])
+        wa, self.wgrad_async = self.wgrad_async, False
+        dX1 = self.stack_bwd("property_encoder.", cp, range(0, k1), T["tape1"][:k1], dX1, T["g1"])
+        self.wgrad_async = wa
         dz1 = self._embed_ln_bwd("property_encoder.", cp, T["esv1"], dX1)
         pp = "property_encoder.embeddings."
         ops.embed_bwd(1, dz1, nseq=2 * B, L=Lp, H=H, dpos=P.g(pp + "position_embeddings.weight"),
