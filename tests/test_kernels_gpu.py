@@ -1339,6 +1339,7 @@ def test_pack_plan_matches_tensor_bookkeeping(ops, B, Lt):
     inv = torch.full((2 * BL,), -1, dtype=torch.int64, device="cuda")
     inv[rows] = torch.arange(M, device="cuda"); inv[BL:] = M + torch.arange(BL, device="cuda")
     assert torch.equal(pk["inv"], inv)
+    assert torch.equal(pk["idx_m"], torch.cat([row0, M + torch.arange(M, device="cuda")]))      # momentum text encoder's last layer: CLS | causal copy
     # a hint that contradicts the mask, a hole in a row, an empty row: the flag goes up and no index leaves the sized ranges
     for kind in ("short", "hole", "empty"):
         m2, M2 = mask.clone(), M
@@ -1353,6 +1354,7 @@ def test_pack_plan_matches_tensor_bookkeeping(ops, B, Lt):
         assert int(bad) == 1, kind
         assert int(p2["rows"].min()) >= 0 and int(p2["rows"].max()) < BL and int(p2["gidx4"].max()) < 2 * BL and int(p2["inv"][:BL].max()) < M2
         assert int(p2["row0"].max()) < M2 and int((p2["row0"] + p2["len"]).max()) <= M2 and int(p2["len"].min()) >= 1
+        assert int(p2["idx_m"].min()) >= 0 and int(p2["idx_m"].max()) < 2 * M2
 
 
 @pytest.mark.parametrize("B,Lt,Lp", [(4, 16, 6), (128, 128, 54), (8, 37, 54)])
