@@ -37,6 +37,20 @@ def wrap(name):
         return r
     setattr(PretrainStep, name, w)
 wrap("stack_fwd"); wrap("stack_bwd")
+
+
+def wrap_any(name):             # PHASES_DETAIL=1: single layers outside the stacks (the top fusion layer), the heads
+    orig = getattr(PretrainStep, name)
+    def w(self, *a, **k):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); r = orig(self, *a, **k); e1.record(st)
+        log.append((name + (" " + a[0] if a and isinstance(a[0], str) else ""), st.stream_id if hasattr(st, 'stream_id') else id(st), e0, e1))
+        return r
+    setattr(PretrainStep, name, w)
+if os.environ.get("PHASES_DETAIL") == "1":
+    for n_ in ("_layer_fwd", "_layer_bwd", "lm_head_fwd", "lm_head_bwd", "_s6_forward_cls", "_s6_backward_cls", "_banks"):
+        wrap_any(n_)
 opt = model.optimizer if hasattr(model, "optimizer") else None
 marks = []
 for i in range(steps):
