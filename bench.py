@@ -284,7 +284,7 @@ def decode_bench(args):
                        "measured": "HIP events around every decode_attn launch of one eager chunk (event-pair overhead ~2 us included)"}
     npos = T + 1
     out["position_breakdown_ms"] = {"note": "one eager single-stream chunk, HIP events around every launch of the three kernel families (event-pair overhead included); "
-                                            "rest = the beam bookkeeping launch (spmm_beam_step), cache writes, embedding, LM head tail, launch gaps",
+                                            "rest = the beam bookkeeping launch (spmm_beam_step), embedding, LM head tail, launch gaps and the event pairs themselves (the cache update is part of decode_attn since round 5)",
                                     "total": round(tot_ms / npos, 3), "gemm": round(gms / npos, 3), "gemm_launches": len(other["gemm"]) // npos,
                                     "decode_attn": round(tms / npos, 3), "layernorm": round(lms / npos, 3),
                                     "rest": round((tot_ms - gms - tms - lms) / npos, 3)}
