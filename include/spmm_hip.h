@@ -197,7 +197,8 @@ int spmm_decode_attn(const void* q, long ldq, const void* K, const void* V, long
  * *n_done counts them) and keeps its state; otherwise the k best candidates become the new beams: tokens [N, k, Lmax] (int32
  * histories; position t receives the new token), cur_p, ids_out [N*k] (the token to feed next; 0 for finished molecules),
  * parent_out (optional) and the K/V ancestry table anc [N*k, anc_ld] of spmm_decode_attn (optional: positions < t inherited from
- * the parent row, positions >= t the row itself).  t = tokens held by every live beam = *t_ptr + t_off when t_ptr is given (a
+ * the parent row, positions >= t the row itself; the beams of a molecule that finishes at this position all take beam 0's row of the table --
+ * nobody reads their outputs any more, and one shared row per position is the cheap case of spmm_decode_attn).  t = tokens held by every live beam = *t_ptr + t_off when t_ptr is given (a
  * replayed hipGraph), else the argument.  mol (optional, [N]): the batch is a compacted subset -- molecule i of logits / ids_out / anc is
  * molecule mol[i] of the state arrays; rowmap (optional, [N*k]): the K/V cache row of beam row i*k + b (what "the row itself" means in
  * anc).  k <= 8, k <= V <= 512, Lmax <= 256. */
