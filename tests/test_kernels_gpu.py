@@ -1197,6 +1197,35 @@ def test_decode_attention_over_kv_cache(ops, R, nH, Lkv, Lmax, kv_div, group, co
     close(out.float(), ref, 2e-2, 2e-2, "decode_attn")
 
 
+@pytest.mark.parametrize("R,nH,Lkv,Lmax,group,tail", [(500, 12, 100, 100, 5, 6), (5000, 12, 60, 103, 5, 6), (64, 4, 130, 160, 4, 0)])
+def test_decode_attention_is_stable_over_repeated_launches(ops, R, nH, Lkv, Lmax, group, tail):
+    """Race screen (tools/stress_decode_attn.py in small): the kernel streams keys and values through an LDS-DMA ring behind counted waits --
+    a first version that loaded keys into registers was wrong on 1-100 % of the launches depending on the shape.  Six random ancestry tables
+    per shape against fp32 torch, and every launch repeated: bit-identical."""
+    H = nH * 64
+    for trial in range(6):
+        g = torch.Generator().manual_seed(1000 * trial + R + Lkv)
+        q = torch.randn(R, H, generator=g).to(BF).cuda()
+        Kc = torch.randn(R, Lmax, H, generator=g).to(BF).cuda()
+        Vc = torch.randn(R, Lmax, H, generator=g).to(BF).cuda()
+        anc = torch.randint(0, R, (R, Lmax), generator=g).to(torch.int32).cuda()
+        if tail:
+            lead = anc.view(R // group, group, Lmax)[:, :1, :].expand(R // group, group, Lmax).reshape(R, Lmax)
+            old = torch.arange(Lmax, device="cuda")[None, :] < max(Lkv - tail, 0)
+            anc = torch.where(old, lead, anc).contiguous()
+        out = [torch.zeros(R, H, dtype=BF, device="cuda") for _ in range(2)]
+        for o in out:
+            ops.decode_attn(q, Kc, Vc, o, nH=nH, Lkv=Lkv, seq_stride=Lmax * H, tok_stride=H, anc=anc, group=group)
+        assert torch.equal(out[0], out[1]), trial
+        j = torch.arange(Lkv, device="cuda")
+        seq = anc[:, :Lkv].long()
+        K = Kc.float()[seq, j[None, :]].view(R, Lkv, nH, 64)
+        V = Vc.float()[seq, j[None, :]].view(R, Lkv, nH, 64)
+        sc = torch.einsum("rhd,rjhd->rhj", q.float().view(R, nH, 64), K) * 0.125
+        ref = torch.einsum("rhj,rjhd->rhd", torch.softmax(sc, -1), V).reshape(R, H)
+        close(out[0].float(), ref, 2e-2, 2e-2, f"decode_attn trial {trial}")
+
+
 @pytest.mark.parametrize("R,nH,Lkv,Lmax,group", [(15, 12, 37, 64, 5), (10, 2, 1, 16, 1), (35, 4, 9, 16, 7), (500, 12, 100, 103, 5), (12, 2, 54, 64, 6)])
 @pytest.mark.parametrize("head_major", [False, True])
 def test_decode_attention_writes_the_newest_position_into_the_cache(ops, R, nH, Lkv, Lmax, group, head_major):

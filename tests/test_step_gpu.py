@@ -327,6 +327,39 @@ def test_dropout_and_residual_in_the_projection_epilogue_inside_the_step(env):
     assert rel > 1e-5 and rel < 1.5e-2                       # (the fused form really ran)
 
 
+def test_weight_gradients_on_the_backward_chains_own_stream_change_nothing(env):
+    """EngineOptions.pv_wgrad_inline: the PV encoder's first n layers keep their weight-gradient GEMMs on the stream of their own backward
+    chain instead of the shared weight-gradient stream (a scheduling choice: the one launch per weight and step is the same launch).  Same
+    seed, train mode with dropout: for n = 3 and all layers the losses and the WHOLE gradient arena sit as close to n = 0 as a second run of
+    n = 0 does (the step is not bit-reproducible: fp32 atomics in the loss / column-sum / hub reductions)."""
+    O, SPMM, tiny_config, *_ = env
+    from spmm_amd.options import EngineOptions
+    cfg, ocfg = _mid_cfg(env)
+    sd = O.init_state_dict(ocfg, seed=5)
+    B, Lt = 16, 64
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=31)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(2))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
+    res = {}
+    for n in (0, 3, 99, -1):                      # (-1: n = 0 again, the run-to-run noise)
+        m = SPMM(config=None, spmm_config=cfg, options=EngineOptions.from_env(pv_wgrad_inline=max(n, 0)))
+        m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+        m.train()
+        m.engine.seed.fill_(777)
+        losses = m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))
+        sum(losses).backward()
+        torch.cuda.synchronize()
+        res[n] = (torch.stack([x.detach() for x in losses]).clone(), m.store.grad.detach().clone())
+    gn = res[0][1].norm()
+    noise = float((res[-1][1] - res[0][1]).norm() / gn)
+    assert float(gn) > 0 and noise < 1e-4
+    for n in (3, 99):
+        rel = float((res[n][1] - res[0][1]).norm() / gn)
+        print(f"pv_wgrad_inline={n}: whole-gradient relative L2 difference {rel:.3g} (two runs of n = 0: {noise:.3g})")
+        assert (res[n][0] - res[0][0]).abs().max().item() < 1e-4, n
+        assert rel <= max(3.0 * noise, 1e-6), n
+
+
 def test_full_depth_forward_matches_oracle(env):
     """The published architecture (12 text layers with 6 fusion + 6 PV layers, H=768), random-init weights, B=8, Lt=32,
     queue 1024: bf16 pipeline vs the fp32 CPU oracle.  This is the depth at which bf16 rounding has accumulated most."""
