@@ -149,8 +149,9 @@ def cross_attn_executed_flops(groups, q_rows, H=768):
     return 4.0 * H * H * q_rows + 4.0 * H * H * kv_rows + core
 
 
-def cpu_baseline(B, Lt, seconds_budget=45.0):
-    """The oracle (a plain-PyTorch fp32 port of the reference's step) timed on this box's host cores."""
+def cpu_baseline(B, Lt, seconds_budget=150.0):
+    """The oracle (a plain-PyTorch fp32 port of the reference's step) timed on this box's host cores: 3 timed steps after 1 warm-up
+    (BASELINE.md section 4), fewer only on a box so slow that they would not fit `seconds_budget` (~19 s per step on 64 cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import spmm_oracle as O
     cores = min(os.cpu_count() or 1, 64)

@@ -252,7 +252,7 @@ int spmm_gather_rows(void* dst, const void* src, const long* idx, long rows, int
  *   idx6 (assembly gather over A = [prop_embeds ; prop_embeds_causal], B = [text_embeds ; hidden10]; the text negatives re-enter as PACKED
  *   query rows at the end of the batch, Mn = sum of their lengths known only on the device), neg_rows [B Lt] (row of text_embeds behind
  *   every packed negative row, -1 past Mn), idx_top (rows the top fusion layer keeps: position 0 of the 6B ITM sequences, every row of the
- *   LM and causal-PV passes), small32 [35 B] (sequence -> key/value source maps, packed row tables, CSR inverse maps of the two shared
+ *   LM and causal-PV passes), small32 [35 B + 2] (sequence -> key/value source maps, packed row tables, CSR inverse maps of the two shared
  *   key/value sources, and rows_dev = {rows of the batch, Mn}: the device-side row counts of the launches over it). */
 int spmm_gather_rows2(void* dst, const void* srcA, const void* srcB, const long* idx, long rows, int H, spmm_stream_t stream);
 int spmm_add_rows_bf16(void* dst, const long* idx, const void* src, long rows, int H, spmm_stream_t stream);

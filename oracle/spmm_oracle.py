@@ -292,23 +292,33 @@ def _finish_aliases(sd: SD, cfg: SPMMCfg) -> None:
 # EngineOptions.fuse_drop_res form: the projection in front of a residual LayerNorm writes the pre-norm sum itself (spmm_gemm_nt_drop), so
 # that sum is a storage point the LayerNorm reads back (`_ln(..., stored_sum=True)`); in the default form the LayerNorm kernel forms the
 # sum in fp32 registers and only its backward copy is rounded.
+# Round 6: `bf16_storage(only={...})` rounds ONE (or a few) storage classes and leaves the others in fp32 -- the ablation that says which
+# stores carry a loss's deviation (tools/storage_ablation.py -> profiles/r06_storage_ablation.txt).  Classes: "weights" (bf16 GEMM shadows),
+# "qkv" (query / key / value projections), "softmax_e" (the un-normalised numerators fed to the second attention MFMA), "attn_ctx" (attention
+# context), "attn_proj" (attention output projection, before the residual LayerNorm), "ffn_up" (GELU output), "ffn_down" (FFN output
+# projection, before the residual LayerNorm), "ln" (LayerNorm outputs: the residual stream), "heads" (LM-head transform, MPM head).
+STORAGE_CLASSES = ("weights", "qkv", "softmax_e", "attn_ctx", "attn_proj", "ffn_up", "ffn_down", "ln", "heads")
 _BF16_STORAGE = False
 _BF16_STORAGE_BWD = False
 _BF16_FUSED_SUM = False
+_BF16_ONLY = None
 
 
 class bf16_storage:
-    def __init__(self, backward: bool = False, fused_sum: bool = False):
+    def __init__(self, backward: bool = False, fused_sum: bool = False, only=None):
         self.backward, self.fused_sum = backward, fused_sum
+        self.only = None if only is None else frozenset(only)
+        if self.only is not None and not self.only <= set(STORAGE_CLASSES):
+            raise ValueError(f"unknown storage classes {sorted(self.only - set(STORAGE_CLASSES))}")
 
     def __enter__(self):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM
-        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM), True
-        _BF16_STORAGE_BWD, _BF16_FUSED_SUM = self.backward, self.fused_sum
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY
+        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY), True
+        _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY = self.backward, self.fused_sum, self.only
 
     def __exit__(self, *exc):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM
-        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM = self._old
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY
+        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY = self._old
 
 
 class _RoundBothWays(torch.autograd.Function):
@@ -321,9 +331,22 @@ class _RoundBothWays(torch.autograd.Function):
         return g.to(torch.bfloat16).to(torch.float32)
 
 
-def _st(x: Tensor) -> Tensor:
+def _lin_class(p: str) -> str:
+    """Storage class of a Linear's output from its parameter prefix."""
+    if p.endswith((".self.query", ".self.key", ".self.value")):
+        return "qkv"
+    if p.endswith(("attention.output.dense",)):                      # (attention / crossattention)
+        return "attn_proj"
+    if p.endswith("intermediate.dense"):
+        return "ffn_up"
+    if p.endswith("output.dense"):
+        return "ffn_down"
+    return "heads"
+
+
+def _st(x: Tensor, cls: str = "heads") -> Tensor:
     """A tensor as the product holds it in HBM."""
-    if not _BF16_STORAGE:
+    if not _BF16_STORAGE or (_BF16_ONLY is not None and cls not in _BF16_ONLY):
         return x
     if _BF16_STORAGE_BWD and x.requires_grad:
         return _RoundBothWays.apply(x)
@@ -335,17 +358,17 @@ def _lin(sd: SD, p: str, x: Tensor, act=None, f32_out: bool = False, f32_w: bool
     """nn.Linear (+ fused activation).  bf16 storage model: bf16 weight shadow unless `f32_w` (the small loss heads read the fp32
     master), fp32 accumulation + bias + activation, bf16 output unless `f32_out` (logits, feature projections, head outputs)."""
     w = sd[p + ".weight"]
-    y = F.linear(x, w if f32_w else _st(w), sd[p + ".bias"])
+    y = F.linear(x, w if f32_w else _st(w, "weights"), sd[p + ".bias"])
     if act is not None:
         y = act(y)
-    return y if f32_out else _st(y)
+    return y if f32_out else _st(y, _lin_class(p))
 
 
 def _ln(sd: SD, p: str, x: Tensor, eps: float, stored_sum: bool = False) -> Tensor:
     """stored_sum: x is the pre-norm sum dropout(dense(.)) + residual, which the product writes to HBM (bf16) before the LayerNorm reads it."""
     if stored_sum and _BF16_FUSED_SUM:
-        x = _st(x)
-    return _st(F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps))
+        x = _st(x, "ln")
+    return _st(F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps), "ln")
 
 
 def _drop(x: Tensor, p: float, train: bool) -> Tensor:
@@ -398,7 +421,7 @@ def attention(sd: SD, p: str, c: BertCfg, hidden: Tensor, add_mask: Tensor,
         # csrc/attention.hip: e = exp(s - max) in fp32, row sum of the UNROUNDED e, e rounded to bf16 as the MFMA operand,
         # context = (e_bf16 . V) / sum rounded to bf16
         e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
-        ctx = _st(torch.matmul(_st(e), v) / e.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, L, H)
+        ctx = _st(torch.matmul(_st(e, "softmax_e"), v) / e.sum(dim=-1, keepdim=True), "attn_ctx").permute(0, 2, 1, 3).reshape(B, L, H)
     else:
         pr = _drop(torch.softmax(s, dim=-1), c.attention_probs_dropout_prob, train)
         ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
@@ -447,7 +470,7 @@ def mlm_head(sd: SD, p: str, c: BertCfg, x: Tensor) -> Tensor:
     """BertOnlyMLMHead xbert.py:662-706: decoder(LN(gelu(dense(x)))) + bias, decoder tied."""
     h = _lin(sd, p + "cls.predictions.transform.dense", x, act=F.gelu)
     h = _ln(sd, p + "cls.predictions.transform.LayerNorm", h, c.layer_norm_eps)
-    return F.linear(h, _st(sd[p + "cls.predictions.decoder.weight"]), sd[p + "cls.predictions.bias"])
+    return F.linear(h, _st(sd[p + "cls.predictions.decoder.weight"], "weights"), sd[p + "cls.predictions.bias"])
 
 
 # ------------------------------------------------------------------ SPMM_models.py

@@ -263,8 +263,11 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
   // Device-side row count (rows of a batch whose tail only the device knows): the launcher's slicing rule applied here to *M_ptr, with
   // the nsplit slices the grid was sized for; slices left without rows write a zero tile into their slab.
   int Mrows = p.M, rsplit = p.rsplit, rlast_ = p.rlast, ndup_ = p.ndup, nslices = p.nsplit;
+  int mreal = p.M;                                   // rows that really exist: below 256 the slicing runs over 256 rows and the rest is masked (TP_MASK_TAIL)
   if (p.M_ptr != nullptr && p.nsplit > 1) {
     int m_ = *p.M_ptr;
+    m_ = m_ < 0 ? 0 : m_;
+    mreal = m_ < p.M ? m_ : p.M;
     m_ = m_ < p.M ? (m_ > 256 ? m_ : 256) : p.M;
     const int rs = ((((m_ + 127) >> 7) + p.nsplit - 1) / p.nsplit) << 7;
     const int ns = (m_ + rs - 1) / rs;               // >= 2 for m_ > rs; rows [0, m_) cut like the launcher cuts [0, M)
@@ -405,7 +408,21 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
       }                                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
   } while (0)
+  // Fewer than 256 real rows under a device-side row count: the two 128-row slices the grid then runs hold rows past the count, whose
+  // contents nobody wrote (NaN bit patterns included: 0 x NaN would poison the product), so BOTH operands' rows are zeroed after they land.
+#define TP_MASK_TAIL(S)                                                                                              \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                 \
+      if (mbeg + (S) * 64 + i_ * 32 + (tid >> 4) >= mreal) {                                                         \
+        _Pragma("unroll") for (int h_ = 0; h_ < 4; ++h_)                                                             \
+          *(LDS_AS f32x4*)(uintptr_t)(lds0 + ((S) & 1) * TP_BUF + h_ * TP_HT + wave * 1024 + lane * 16 + i_ * 8192) = \
+              f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
+      }                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+  } while (0)
+  const bool tail = mreal < Mrows;                     // (workgroup-uniform; implies Mrows == 256: two slices of two steps)
   if (ndup > 0) TP_MASK(0);                            // (wave-uniform; step 0 has landed: this thread's own pieces)
+  if (tail) TP_MASK_TAIL(0);
   TP_BAR();
   TP_SB();
   if (wr == 1) TP_BAR();                               // the second wave row runs one barrier behind the first
@@ -431,6 +448,10 @@ __device__ __forceinline__ void tn_p8_body(const TnP& p, const int bidx, const i
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (kt == 0 && ndup > 64) TP_MASK(1);                                         // step 1 has landed; it is read from phase 5 on
+    if (kt == 0 && tail) {                                                        // (nk == 2 here: `more` is false, vmcnt(0) above)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TP_MASK_TAIL(1);
+    }
     TP_COMPUTE(1, 0, tb0);
     // ---------------- step kt+1 (buffer 1)
     TP_RD_B(1, 0, tb0); TP_SB(); TP_RD_A(1, 0);                                   // phase 5

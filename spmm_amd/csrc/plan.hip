@@ -291,7 +291,7 @@ extern "C" int spmm_gelu_bwd(const void* dz, const void* pre, void* out, long n,
 
 extern "C" int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32, int* row0_32, long* row0_64, long* rows, long* gidx2,
                               long* gidx4, long* inv, long* idx_m, int* bad, hipStream_t stream) {
-  SPMM_CHECK_SHAPE(B >= 1 && B <= 8192 && Lt >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_pack_plan: B=%d Lt=%d M=%d", B, Lt, M);
+  SPMM_CHECK_SHAPE(B >= 1 && B <= 8191 && Lt >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_pack_plan: B=%d Lt=%d M=%d (B <= 8191: (2B + 2) ints of LDS within 64 KiB)", B, Lt, M);
   hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), (2 * B + 2) * sizeof(int), stream, mask, B, Lt, M, lens32, row0_32, row0_64, rows,
                      gidx2, gidx4, inv, idx_m, bad);
   SPMM_LAUNCH_CHECK("spmm_pack_plan");
@@ -300,7 +300,7 @@ extern "C" int spmm_pack_plan(const int* mask, int B, int Lt, int M, int* lens32
 
 extern "C" int spmm_fusion_plan(const long* neg, const int* lens32, const int* row0_32, int B, int Lt, int Lp, int M,
                                 long* idx6, long* neg_rows, long* idx_top, int* small32, hipStream_t stream) {
-  SPMM_CHECK_SHAPE(B >= 1 && B <= 8192 && Lt >= 1 && Lp >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_fusion_plan: B=%d Lt=%d Lp=%d M=%d", B, Lt, Lp, M);
+  SPMM_CHECK_SHAPE(B >= 1 && B <= 8191 && Lt >= 1 && Lp >= 1 && M >= 1 && (long)M <= (long)B * Lt, "spmm_fusion_plan: B=%d Lt=%d Lp=%d M=%d", B, Lt, Lp, M);
   const long Rcap = 4l * B * Lp + 2l * M + 2l * B * Lt;
   SPMM_CHECK_SHAPE(Rcap < (1l << 31), "spmm_fusion_plan: %ld rows do not fit the int32 row tables", Rcap);
   hipLaunchKernelGGL(fusion_plan_kernel, dim3(blocks_for(Rcap, 256) > 64 ? 64 : blocks_for(Rcap, 256)), dim3(256), (B + 1) * sizeof(int), stream, neg, lens32,

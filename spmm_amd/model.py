@@ -8,6 +8,7 @@ All arithmetic runs in the HIP kernels of libspmm_hip.so; there is no eager / CP
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -62,6 +63,9 @@ class _FusedAdamW:
 
     def step(self, fill_lr: bool = True):
         g = self.param_groups[0]
+        # a second step() without a backward in between: the previous step's off-path shadow rebuild (weight-gradient stream) must not
+        # be overtaken by this step's master update / rebuild
+        self.eng.pre_backward_wait()
         if fill_lr:                                  # (a host value: set outside a captured graph, see SPMM.fused_step_graphed)
             self.eng.lr.fill_(g["lr"])
         self.normsq.zero_()
@@ -195,6 +199,9 @@ class SPMM(_Base):
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True):
+        # an off-path shadow rebuild of the last optimiser step may still be running on the weight-gradient stream: the shadows written
+        # below (current stream) must land AFTER it
+        self.engine.pre_backward_wait()
         missing, unexpected = self.store.load_state_dict(state_dict, strict=strict)
         self.engine.refresh_padded_shadows()
         self.engine.invalidate_banks()
@@ -334,6 +341,8 @@ class SPMM(_Base):
         check = self._schedule_check_begin(grad_sync)
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
+        # (single rank only: beside RCCL's stream the weight-gradient stream shares a hardware slot with the caller's stream -- queue index
+        #  4 = 0 mod 4 -- and two streams that wait for each other there run the step at 74-76 ms instead of 57, profiles/r06_dp_one_rank.txt)
         eng._off_path_ok = grad_sync is None
         eng.off_path(lambda: ops.zero_(self.store.grad))        # nothing reads or writes a gradient before the backward
         dev = self.device_
@@ -438,6 +447,10 @@ class SPMM(_Base):
         eng.alpha.fill_(float(alpha))
         eng.gscale.fill_(1.0)
         eng.lr.fill_(opt.param_groups[0]["lr"])
+        # An eager fused_step() before this call leaves Engine._pre_bwd pending (its optimiser's off-path shadow rebuild): waiting on an
+        # event recorded outside the capture is a StreamCaptureIsolation error, so drain it here and keep the maintenance inline.
+        eng._off_path_ok = False
+        eng.pre_backward_wait()
         st = self._graphs.get(key)
         if st is None:                                   # first step of this shape: eager, dense layout
             pack, eng.pack_text = eng.pack_text, False

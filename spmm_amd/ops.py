@@ -356,7 +356,7 @@ def fusion_plan(neg, pk, Lp):
     alloc = torch.zeros if _DRY_RUN else torch.empty
     i64 = alloc(Rcap + B * Lt + ntop, dtype=torch.int64, device=dev)
     idx6, neg_rows, idx_top = i64[:Rcap], i64[Rcap:Rcap + B * Lt], i64[Rcap + B * Lt:]
-    small = alloc(35 * B, dtype=torch.int32, device=dev)
+    small = alloc(35 * B + 2, dtype=torch.int32, device=dev)     # 34 B-sized tables (FUSION_SMALL), then rows_dev, mn_dev
     _call("spmm_fusion_plan", _p(neg), _p(pk["len"]), _p(pk["row0"]), B, Lt, Lp, M, _p(idx6), _p(neg_rows), _p(idx_top), _p(small), _st())
     out = dict(idx6=idx6, neg_rows=neg_rows, idx_top=idx_top, Rcap=Rcap, rows_dev=small[34 * B:34 * B + 1], mn_dev=small[34 * B + 1:34 * B + 2])
     for k, (o, n) in FUSION_SMALL.items():

@@ -91,7 +91,6 @@ class OverlappedGradSync:
         # The exchange is the only stream beside the backward chain: the asynchronous weight-gradient stream rests meanwhile
         # (three chip-filling streams side by side ran the step in 76-78 ms against 61-62)
         self.exclusive = True
-        self.trace = None            # set to [] to record (lo, hi, issue event, done event) per slice (tests / timeline checks)
         self.wait_events = None      # set to [] to record, per step, an event pair around finish()'s wait on the compute stream: the
         #                              communication time the backward did NOT hide (bench.py `comm_exposed_ms`)
 
@@ -99,17 +98,11 @@ class OverlappedGradSync:
         assert grad.numel() == self.total
         self._grad, self._work, self._done, self._staged = grad, [], [], []
         self._avg = dist.get_backend() == "nccl"
-        if self.trace is not None:
-            self.trace.clear()
 
     def _reduce(self, lo, hi):
         if hi <= lo:
             return
         sl = self._grad[lo:hi]
-        issue = None
-        if self.trace is not None and sl.is_cuda:
-            issue = torch.cuda.Event(enable_timing=True)
-            issue.record()                                       # on the stream that just finished writing this slice
         if self.wire == "fp32":
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             works = [dist.all_reduce(sl, op=op, async_op=True)]
@@ -126,14 +119,6 @@ class OverlappedGradSync:
             self._staged.append((lo, hi, buf, shard))           # both stay alive until finish(): RCCL reads / writes them on its stream
         self._work.extend(works)
         self._done.append((lo, hi))
-        if issue is not None:
-            from . import streams
-            done = torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(streams.get(sl.device, "observer")):   # the observer waits for the collective; the compute stream does not
-                for w in works:
-                    w.wait()
-                done.record()
-            self.trace.append((lo, hi, issue, done))
 
     def layer_done(self, prefix: str):
         if self._grad is None or prefix not in self._ranges:
@@ -190,12 +175,12 @@ def grad_sync_fn(store=None, options: Optional[EngineOptions] = None):
             torch.cuda.synchronize(dev)
             if not late:
                 # ... and the streams of a data-parallel step take their hardware queues NOW, in the order measured fast (RCCL's stream,
-                # side0, side1, observer).  A stream gets its queue at its first use and there are only a handful: orders that make
+                # side0, side1, wgrad).  A stream gets its queue at its first use and there are only a handful: orders that make
                 # RCCL's stream share one with a stream it exchanges dependencies with run the step at 79-87 ms instead of 60.5
                 # (EXPERIMENTS.md 2.7b, profiles/r04_stream_order.txt).
-                streams.bind_in_order(dev, ("side0", "side1", "observer"))
+                streams.bind_in_order(dev, ("side0", "side1", "wgrad"))
             streams.note(f"cuda:{dev}: first collective issued " + ("AFTER the compute side streams existed (an order EXPERIMENTS.md 2.7b measured slow is possible)"
-                                                                     if late else "first, then side0, side1, observer bound to hardware queues in that order"))
+                                                                     if late else "first, then side0, side1, wgrad bound to hardware queues in that order"))
             if late:
                 import warnings
                 warnings.warn("spmm_amd: HIP side streams were created before the first RCCL collective; create the process group and "

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-ORDER = ("side0", "side1", "wgrad", "observer")     # creation order = queue placement; never create them any other way
+ORDER = ("side0", "side1", "wgrad")     # creation order = queue placement; never create them any other way
 
 _pool: Dict[tuple, torch.cuda.Stream] = {}
 _log: List[str] = []

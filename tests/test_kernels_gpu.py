@@ -1429,6 +1429,25 @@ def test_fusion_plan_matches_tensor_bookkeeping(ops, B, Lt, Lp):
         assert torch.equal(fp["start_" + nm], src.start) and torch.equal(fp["list_" + nm], src.list), nm
 
 
+@pytest.mark.parametrize("M,N,K,Md", [(20000, 768, 768, 100), (20000, 2304, 768, 255), (16384, 768, 3072, 1), (20000, 768, 768, 256), (20000, 768, 768, 257)])
+def test_weight_gradient_with_few_device_side_rows(ops, M, N, K, Md):
+    """The 8-phase weight-gradient kernel under a device-side row count BELOW its 256-row minimum slicing (the packed text negatives of a
+    step can total fewer than 256 tokens while the batch is allocated for B x Lt): the rows past the count hold whatever the allocator
+    left there -- NaN here, in BOTH operands -- and must contribute nothing (0 x NaN would poison the product: both operands' rows are
+    zeroed in LDS, csrc/gemm_tn.hip TP_MASK_TAIL)."""
+    assert ops.lib().cdll.spmm_gemm_tn_splits(M, N, K, 0) > 1       # (the shape takes the 8-phase kernel with several row slices)
+    md = torch.tensor([Md], dtype=torch.int32, device="cuda")
+    dY, X = rnd(M, N, seed=5), rnd(M, K, seed=6)
+    dY[Md:] = float("nan"); X[Md:] = float("nan")
+    g_d, g_s = torch.zeros(N, K, device="cuda"), torch.zeros(N, K, device="cuda")
+    ops.gemm_tn(dY, X, g_d, M_dev=md)
+    ops.gemm_tn(dY[:Md], X[:Md], g_s)
+    assert bool(torch.isfinite(g_d).all())
+    close(g_d, g_s, 2e-3 * Md ** 0.5, 1e-4, "weight gradient")
+    want = dY[:Md].float().t() @ X[:Md].float()
+    close(g_d, want, 2e-3 * Md ** 0.5, 1e-4, "weight gradient vs fp32")
+
+
 @pytest.mark.parametrize("M,N,K,Md", [(9000, 768, 768, 8200), (9000, 768, 768, 9000), (700, 128, 128, 300), (20000, 2304, 768, 17123), (5000, 768, 3072, 4097)])
 def test_device_side_row_counts(ops, M, N, K, Md):
     """The launches over a batch whose row count only the device knows (include/spmm_hip.h, "device-side row counts"): the NT GEMM, the

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _in_fresh_child(test_name, attempts=3, **env):
+def _in_fresh_child(test_name, attempts=1, **env):
     """Runs `test_name` of this file in a fresh process (GPU_MAX_HW_QUEUES=8 like bench.py / pretrain.py); a failed attempt is
     repeated (stream -> hardware-queue placement is drawn per process: round 4 saw one full-suite run in eight lose two attempts in a
     row) and its output kept in gpurun_out/timing_failures.txt.  Returns the captured output of the passing attempt."""
@@ -56,7 +56,8 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
     mpm = torch.zeros(4, 53).cuda()
     neg = tuple(_cuda(torch.arange(4).roll(1), torch.arange(4).roll(2)))
     ref = _tiny_train_model(env, dropout=False)
-    want = [float(x) for x in ref.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)]
+    for _ in range(2):                                            # (the measured step below is the model's SECOND: the first one warms everything up)
+        want = [float(x) for x in ref.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)]
     want_flat = ref.store.flat.clone()
 
     # Stream -> hardware-queue placement, as the product checks it at data-parallel start-up (spmm_amd/streams.py): the stand-in
@@ -72,7 +73,9 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
             break
         comm = torch.cuda.Stream()
     assert not clash, f"no communication stream independent of {clash} found"
-    issued_from = []
+    issued_from, records, posts, host_t = [], [], [], []
+    scratch = torch.zeros(64, device="cuda")
+    sleep_cycles = [1000]                                         # the warm-up step's collectives are short
     c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     SLEEP = 40_000_000                                           # ~20 ms: many times a tiny layer's (host-bound) backward (at ~10 ms one attempt in ~20 lost to a host hiccup)
     torch.cuda._sleep(1000)
@@ -87,43 +90,76 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
         def wait(self):
             torch.cuda.current_stream().wait_event(self.ev)
 
+    m = _tiny_train_model(env, dropout=False)
+
     def slow_all_reduce(t, op=None, async_op=False):
+        # The stand-in owns BOTH timestamps of a slice: `issue` on the stream the product issues the collective from (behind the last
+        # writer of the slice), `done` on its own stream.  Nothing else waits for `done` before finish(): round 5's version let the
+        # product park an "observer" stream behind every collective to take that timestamp, and whenever HIP placed the observer on the
+        # hardware queue of the stream running the backward, the next layer's kernels queued behind the observer's wait packet -- the
+        # test then saw "next issue 0.5-0.9 ms AFTER done" (GPUTEST_r05: 3/3 fresh processes) for a product that overlaps fine.
         assert async_op
         issued_from.append(torch.cuda.current_stream().cuda_stream)
-        ready = torch.cuda.Event()
-        ready.record()
+        host_t.append(time.perf_counter())
+        issue = torch.cuda.Event(enable_timing=True)
+        issue.record()
         with torch.cuda.stream(comm):
-            comm.wait_event(ready)
-            torch.cuda._sleep(SLEEP)                            # "link time"
+            comm.wait_event(issue)
+            torch.cuda._sleep(sleep_cycles[0])                  # "link time"
             t.mul_(1.0)                                          # one rank: the mean is the value itself
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=True)
             done.record()
+        lo = (t.data_ptr() - m.store.grad.data_ptr()) // t.element_size()
+        records.append((lo, lo + t.numel(), issue, done))
+        # diagnostic timestamps on the issuing stream: right behind the issue, and behind one more tiny kernel
+        p1 = torch.cuda.Event(enable_timing=True); p1.record()
+        scratch.add_(1.0)
+        p2 = torch.cuda.Event(enable_timing=True); p2.record()
+        posts.append((issue, p1, p2))
         return Work(done)
 
     monkeypatch.setattr(parallel.dist, "all_reduce", slow_all_reduce)
     monkeypatch.setattr(parallel.dist, "get_backend", lambda *a: "nccl")
-    m = _tiny_train_model(env, dropout=False)
     sync = parallel.OverlappedGradSync(m.store.order, m.store.offset, m.store.total, wire="fp32")
-    sync.trace = []
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # Step 1 = warm-up THROUGH the stand-in collective: round 6 found the host stalling 40-90 ms inside the stand-in's first call (lazy
+    # code-object load of its `mul_` kernel; 9 ms on a good day) in 3 of 25 fresh processes -- the 20-ms "link time" was then over before
+    # the host issued the next layer's backward, and the timeline read "no overlap" (GPUTEST_r05's red test; gpurun_out/r06_2).
+    m.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, grad_sync=sync)
+    torch.cuda.synchronize()
+    for l in (issued_from, records, posts, host_t):
+        l.clear()
+    sleep_cycles[0] = SLEEP
     t0.record()
-    got = [float(x) for x in m.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, grad_sync=sync)]
+    got = m.fused_step(prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg, grad_sync=sync)
     t1.record()
     torch.cuda.synchronize()
-    trace = list(sync.trace)
+    got = [float(x) for x in got]
+    trace = list(records)
+    print("[overlap-probe] per slice, ms from its issue to (the issuing stream's next event, one tiny kernel later): "
+          + " ".join(f"({a.elapsed_time(b):.2f} {a.elapsed_time(c):.2f})" for a, b, c in posts), f"issued from {[hex(x) for x in issued_from]}", flush=True)
     nl = m.cfg.text.num_hidden_layers + m.cfg.prop.num_hidden_layers
     layer_slices = trace[:nl]                                    # per-layer slices come first, the sweep of the rest follows
     assert len(trace) > nl and len(issued_from) == len(trace)
     covered = sorted((lo, hi) for lo, hi, _, _ in trace)
     assert covered[0][0] == 0 and covered[-1][1] == m.store.total
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))            # every element exactly once
-    for (lo, hi, issue, done), (_, _, issue_next, _) in zip(layer_slices, layer_slices[1:]):
+    gaps, host_gaps = [], []
+    for i, ((lo, hi, issue, done), (_, _, issue_next, _)) in enumerate(zip(layer_slices, layer_slices[1:])):
         assert issue.elapsed_time(done) >= 0.8 * link_ms                       # the fake collective really takes its time
-        assert issue_next.elapsed_time(done) > 0.0, "the next layer's backward did not finish before this layer's reduce ended: no overlap"
+        gaps.append(issue_next.elapsed_time(done))
+        host_gaps.append((host_t[i + 1] - host_t[i]) * 1e3)
+    print("[overlap-probe] ms between the NEXT layer's issue and this layer's done (positive = overlapped): " + " ".join(f"{g:.2f}" for g in gaps)
+          + " | host ms between the two issues: " + " ".join(f"{g:.2f}" for g in host_gaps) + f" | link {link_ms:.1f} ms", flush=True)
+    # A pair only counts when the HOST itself reached the next issue well inside the link time (a tiny model's backward is host-bound: a
+    # host that takes longer than the collective proves nothing about the streams); the warmed-up step leaves every pair countable.
+    counted = [g for g, h in zip(gaps, host_gaps) if h < 0.5 * link_ms]
+    assert counted, f"the host needed {host_gaps} ms between issues against a {link_ms:.1f}-ms collective: nothing to judge"
+    assert min(counted) > 0.0, f"the next layer's backward did not finish before this layer's reduce ended: no overlap ({gaps}; host {host_gaps})"
     # all slices ran back to back on the communication stream; the compute stream joined once, at the end
     assert t0.elapsed_time(t1) < len(trace) * link_ms * 1.5 + 200.0
-    np.testing.assert_allclose(got, want, rtol=1e-5)             # (fp32 atomic sums: two runs agree to rounding, not bit for bit)
-    assert (m.store.flat - want_flat).abs().max().item() < 2.5e-3            # one AdamW step at lr 1e-3: sign flips of ~0 gradients move a weight by <= 2 lr
+    np.testing.assert_allclose(got, want, rtol=2e-4)             # (fp32 atomic sums: two runs of two steps agree to rounding, not bit for bit)
+    assert (m.store.flat - want_flat).abs().max().item() < 5e-3              # two AdamW steps at lr 1e-3: sign flips of ~0 gradients move a weight by <= 2 lr each
 
 
 def test_hipgraph_replay_host_cost(env):
