@@ -43,7 +43,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
-PEAK_FP8_TFLOPS = 5000.0       # dense E4M3 MFMA (same guide: ~5 PF dense)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -174,13 +173,13 @@ def cpu_baseline(B, Lt, seconds_budget=150.0):
             "sample": f"oracle/spmm_oracle.py OracleTrainer, full 12+6-layer H=768 model fp32, B={B}, Lt={Lt}, {n} timed step(s) after 1 warm-up"}
 
 
-def child_bench(flags, keep, timeout=420):
+def child_bench(flags, keep, timeout=420, env=None):
     """One more measurement of this file in a child process (never an exec from a process that has touched the GPU); -> the named keys
-    of its JSON line, or {"error": ...}."""
+    of its JSON line, or {"error": ...}.  `env`: variables added to the child's environment (the parent's SPMM_* ones are not inherited)."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + flags, capture_output=True, text=True, timeout=timeout,
-                           env={k: v for k, v in os.environ.items() if not k.startswith("SPMM_")})
+                           env=dict({k: v for k, v in os.environ.items() if not k.startswith("SPMM_")}, **(env or {})))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"error": f"rc={r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
@@ -321,7 +320,6 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (NOT the benchmark configuration)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (dense text layout, one rank; implies --no-kernel-timing)")
-    ap.add_argument("--fp8", action="store_true", help="fp8 (E4M3) FFN forward GEMMs (BASELINE configs[4] tier; NOT the headline configuration)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run assert parameters / queues are identical on all ranks")
     ap.add_argument("--extra-streams", type=int, default=0, help="diagnostic: create N more HIP streams and run one tiny kernel on each before the "
                     "run (what the number of ACTIVE hardware queues costs; profiles/r03_hw_queues.txt)")
@@ -340,7 +338,7 @@ def main():
     args = ap.parse_args()
     # the other configs ride only on the default workload of one GPU (what the driver runs), not on every experiment
     default_run = (args.batch == 128 and args.seq_len == 128 and args.layers == "12,6,6" and args.queue == 36864 and not args.eval_mode and not args.graph
-                   and not args.fp8 and args.gpus == 1 and not args.no_kernel_timing)
+                   and args.gpus == 1 and not args.no_kernel_timing)
     if args.decode:
         if args.warmup == 10:
             args.warmup = 1
@@ -400,7 +398,7 @@ def main():
     tc = {'embed_dim': 256, 'temp': 0.07, 'mlm_probability': 0.15, 'queue_size': args.queue, 'momentum': 0.995, 'alpha': 0.4,
           'schedular': sched, 'optimizer': {'opt': 'adamW', 'lr': 5e-5, 'weight_decay': 0.02}}
     torch.manual_seed(42)                                   # SPMM_pretrain.py:48 default seed; same init on every rank
-    opts = EngineOptions.from_env(**({"fp8": True} if args.fp8 else {}))
+    opts = EngineOptions.from_env()
     model = SPMM(config=tc, spmm_config=cfg, loader_len=1000, options=opts)
     broadcast_state_([model.store.flat, model.store.flat_m] + [model.store.buffers[k] for k in ("prop_queue", "text_queue")])
     model.store.refresh_shadows()
@@ -587,14 +585,11 @@ def main():
         i2 = sorted(a.elapsed_time(b) for _, (a, b) in pairs)[100]
         ev_overhead_ms = max(0.0, 2 * i1 - i2)
         ops.gemm_nt = timed("gemm", orig_gemm, gemm_flops)
-        orig_f8 = ops.gemm_nt_f8
-        ev["f8"] = []
-        ops.gemm_nt_f8 = timed("f8", orig_f8, lambda A8, sa, W8, sw, C, **k: 2.0 * A8.shape[0] * W8.shape[0] * A8.shape[1])   # (--fp8 only: the E4M3 launches)
         nsteps = min(3, args.steps)
         for i in range(nsteps):
             one_step(i)
         torch.cuda.synchronize()
-        ops.gemm_nt, ops.gemm_nt_f8 = orig_gemm, orig_f8
+        ops.gemm_nt = orig_gemm
         # sustained shader clock of the single-stream schedule these intervals come from: the same steps again, un-instrumented, under
         # the sampler (the events' host work would otherwise thin the load the clock responds to)
         smp1 = smi_sampler() if rank == 0 else None
@@ -713,13 +708,6 @@ def main():
         else:
             roof["clock_mhz"] = None
             roof["clock_note"] = f"no clock source on this box: {clk1}"
-        if ev["f8"]:                                         # the fp8 tier's own launches, against the dense E4M3 peak
-            f8_ms = sum(a.elapsed_time(b) for a, b, _ in ev["f8"]) - len(ev["f8"]) * ev_overhead_ms
-            f8_fl = sum(fl for _, _, fl in ev["f8"])
-            roof["fp8_launches"] = {"kernel": "gemm_nt_p8_kernel<., true> (E4M3 operands, v_mfma_scale_f32_16x16x128_f8f6f4): the FFN forward products of the "
-                                              "fp8 option", "achieved": round(f8_fl / (f8_ms * 1e-3) / 1e12, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(f8_fl / (f8_ms * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4), "launches_per_step": len(ev["f8"]) // nsteps,
-                                    "ms_per_step": round(f8_ms / nsteps, 3)}
         # per-shape table of the same launches (where the family's time goes inside the step): M bucketed to 1 k rows
         by_shape = {}
         for (a, b, _), (M_, N_, K_, epi_, f32_) in zip(ev["gemm"], shape_log):
@@ -744,7 +732,7 @@ def main():
     value = world * B / (dt / args.steps)
     out = {"metric": "pretrain molecules/sec", "value": round(value, 2), "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "fp8 (E4M3 FFN forward GEMMs) + bf16" if args.fp8 else "bf16", "data": "synthetic", "step_ms": spread,
+           "dtype": "bf16", "data": "synthetic", "step_ms": spread,
            "config": {"workload": f"SPMM pretrain step, text {nt} layers (fusion at {f}) + PV {npv} layers, H=768, 12 heads, queue {args.queue}, "
                                   f"train mode (dropout 0.1), fwd+bwd+clip+AdamW+EMA", "global_batch": world * B, "seq_len": Lt,
                       "parallelism": f"dp{world}", "schedule": "one hipGraph replay per step, dense text layout" if args.graph else
@@ -796,9 +784,11 @@ def main():
                 "configs[4] per-GPU shape in bf16 (B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5", "--warmup", "4",
                     "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs"],
                     ("metric", "value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "mfma_frac_of_peak_step", "hbm", "config")),
-                "configs[4] per-GPU shape with the fp8 option (E4M3 FFN forward; B=512, Lt=256)": child_bench(["--batch", "512", "--seq-len", "256", "--steps", "5",
-                    "--warmup", "4", "--no-cpu-baseline", "--no-other-configs", "--fp8"],
-                    ("value", "unit", "ms_per_step", "step_ms", "model_tflops_per_gpu", "dtype", "roofline"))}
+                "configs[2] code path on ONE GPU: the default workload through the N>1 step (one-rank RCCL group, SPMM_FORCE_DIST=1: per-layer gradient "
+                "exchanges on RCCL's stream during the backward, the fused feature all-gather) -- ms_per_step against this line's own is what the "
+                "data-parallel schedule costs before any link time": child_bench(["--steps", "20", "--warmup", "6", "--no-cpu-baseline", "--no-kernel-timing",
+                    "--no-other-configs"], ("value", "unit", "ms_per_step", "step_ms", "schedule_check", "stream_placement"),
+                    env={"SPMM_FORCE_DIST": "1", "MASTER_PORT": str(29533 + os.getpid() % 400)})}
         print(json.dumps(out), flush=True)
     if args.check_replicas and world > 1:
         check_replicas(args.warmup + args.steps, fatal=True)

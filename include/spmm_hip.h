@@ -288,13 +288,6 @@ int spmm_itm_head(const void* xa, long stride_a, const void* xb, long stride_b, 
 int spmm_mpm_head(const void* h, int Lp, int H, const float* w, const float* bias, const float* target, const float* mask,
                   int B, int* n_keep_ws, const float* gscale, float* losses, int loss_slot, float* pred_out, void* dh,
                   float* dw, float* db, int do_bwd, int x_is_f32, spmm_stream_t stream);
-/* ---- fp8 tier (BASELINE configs[4]; K6/K7 = xbert.py:434-451 with E4M3 operands, fp32 accumulation).
- * spmm_quant_rows_fp8: q[r][k] = e4m3(x[r][k] / scale[r]), scale[r] = max|x[r][:]| / 448; x bf16 or fp32.
- * spmm_gemm_nt_f8: C[M,N] (bf16) = epi((A8 W8^T) * sa[m] * sw[n] + bias) on the 8-phase 256x256 schedule with
- * v_mfma_f32_16x16x128_f8f6f4; epi SPMM_EPI_BF16 (+R) or SPMM_EPI_GELU_DERIV (C = gelu, optional C2 = gelu').  K % 256 == 0, N % 8 == 0. */
-int spmm_quant_rows_fp8(const void* x, int x_is_f32, long ldx, long rows, int K, void* q, long ldq, float* scale, spmm_stream_t stream);
-int spmm_gemm_nt_f8(const void* A8, long lda, const float* sa, const void* W8, long ldw, const float* sw, int M, int N, int K,
-                    const float* bias, const void* R, long ldr, void* C, long ldc, void* C2, long ldc2, int epi, spmm_stream_t stream);
 /* Small dense heads of the inference tier: out[r,n] = act(bias[n] + sum_k x[r,k] W[n,k]) in fp32 (x fp32 or bf16; act 0 = none,
  * 1 = erf-GELU) -- property_embed / property_proj / text_proj / itm_head / property_mtr_head called as modules on a few rows
  * (SPMM_models.py:36-43; d_smiles2pv.py:15-25, d_pv2smiles_batched.py:25-27). */

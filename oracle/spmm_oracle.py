@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import json
 import math
+import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -302,23 +303,25 @@ _BF16_STORAGE = False
 _BF16_STORAGE_BWD = False
 _BF16_FUSED_SUM = False
 _BF16_ONLY = None
+_BF16_WEIGHTS = None          # regex on the Linear's parameter prefix: which weight shadows are rounded (None = all)
 
 
 class bf16_storage:
-    def __init__(self, backward: bool = False, fused_sum: bool = False, only=None):
+    def __init__(self, backward: bool = False, fused_sum: bool = False, only=None, weights=None):
         self.backward, self.fused_sum = backward, fused_sum
+        self.weights = None if weights is None else re.compile(weights)
         self.only = None if only is None else frozenset(only)
         if self.only is not None and not self.only <= set(STORAGE_CLASSES):
             raise ValueError(f"unknown storage classes {sorted(self.only - set(STORAGE_CLASSES))}")
 
     def __enter__(self):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY
-        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY), True
-        _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY = self.backward, self.fused_sum, self.only
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS
+        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS), True
+        _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS = self.backward, self.fused_sum, self.only, self.weights
 
     def __exit__(self, *exc):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY
-        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY = self._old
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS
+        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS = self._old
 
 
 class _RoundBothWays(torch.autograd.Function):
@@ -358,6 +361,8 @@ def _lin(sd: SD, p: str, x: Tensor, act=None, f32_out: bool = False, f32_w: bool
     """nn.Linear (+ fused activation).  bf16 storage model: bf16 weight shadow unless `f32_w` (the small loss heads read the fp32
     master), fp32 accumulation + bias + activation, bf16 output unless `f32_out` (logits, feature projections, head outputs)."""
     w = sd[p + ".weight"]
+    if _BF16_WEIGHTS is not None and not _BF16_WEIGHTS.search(p):
+        f32_w = True
     y = F.linear(x, w if f32_w else _st(w, "weights"), sd[p + ".bias"])
     if act is not None:
         y = act(y)
@@ -470,7 +475,10 @@ def mlm_head(sd: SD, p: str, c: BertCfg, x: Tensor) -> Tensor:
     """BertOnlyMLMHead xbert.py:662-706: decoder(LN(gelu(dense(x)))) + bias, decoder tied."""
     h = _lin(sd, p + "cls.predictions.transform.dense", x, act=F.gelu)
     h = _ln(sd, p + "cls.predictions.transform.LayerNorm", h, c.layer_norm_eps)
-    return F.linear(h, _st(sd[p + "cls.predictions.decoder.weight"], "weights"), sd[p + "cls.predictions.bias"])
+    dw = sd[p + "cls.predictions.decoder.weight"]
+    if _BF16_WEIGHTS is None or _BF16_WEIGHTS.search(p + "cls.predictions.decoder"):
+        dw = _st(dw, "weights")
+    return F.linear(h, dw, sd[p + "cls.predictions.bias"])
 
 
 # ------------------------------------------------------------------ SPMM_models.py

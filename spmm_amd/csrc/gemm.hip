@@ -43,7 +43,6 @@ struct GemmP {
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output; EPI_GELU_DERIV: gelu'(pre-activation)
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range (tile_of): 0 row-major, 3 row-major inside 2 column groups
-  const float* sa; const float* sw;   // fp8 operands (spmm_gemm_nt_f8): per-row scale of A [M], per-row scale of W [N]; C = (A W^T) sa sw^T
   // EPI_DROPRES (spmm_gemm_nt_drop): the hidden dropout of BertSelfOutput / BertOutput (xbert.py:371,449) inside the epilogue -- the mask
   // spmm_ln_fwd / spmm_ln_bwd draw for (seed, salt, row, column): element (m, n) uses half (n & 1) of drop_pair(drop_rowkey(seed', m), n >> 1)
   const uint64_t* seed_ptr; uint64_t salt; uint32_t drop_thresh16; float drop_scale;
@@ -821,13 +820,7 @@ __device__ __forceinline__ void p8_dsr128u(u32x4& d, uint32_t addr) {
 // HAS_EX: an R (EPI_BF16) / G (EPI_GELU_GRAD) operand is read.  Its loads and their uses are unconditional (edge tiles clamp the
 // address): a load whose use sits behind a different branch would stay "pending" in the compiler's waitcnt model at the top of the
 // K loop and cost a vmcnt(0) -- a drain of the DMA pipeline -- on every iteration.
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x8 p8_cat8(bf16x8 lo, bf16x8 hi) {   // two 16-byte fragment pieces -> the 8-VGPR fp8 operand
-  const i32x4v a = __builtin_bit_cast(i32x4v, lo), b = __builtin_bit_cast(i32x4v, hi);
-  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-template <int EPI, bool INTERIOR, bool HAS_EX, bool F8, typename Hook>
+template <int EPI, bool INTERIOR, bool HAS_EX, typename Hook>
 __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[2][4][4], uint32_t xb /* LDS byte address of the wave's 4 KiB */,
                                                    int m_base, int n_base, int lane, Hook hook) {
   float scale = 1.f;                                            // (EPI_DROPRES takes neither alpha nor div nor colsum: its scalar registers go to the dropout state)
@@ -843,14 +836,6 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       if (INTERIOR || n_base + ni * 16 + 4 * g < p.N) b[ni] = *(const f32x4*)(p.bias + n_base + ni * 16 + 4 * g);
-  }
-  f32x4 cs8[4];                                                 // fp8: the columns' (W rows') quantisation scales
-  if constexpr (F8) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      cs8[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (INTERIOR || n_base + ni * 16 + 4 * g < p.N) cs8[ni] = *(const f32x4*)(p.sw + n_base + ni * 16 + 4 * g);
-    }
   }
   uint32_t wad[4];                                              // write address of the (ni) piece: row m, columns ni*16 + 4g
 #pragma unroll
@@ -892,15 +877,10 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
       const uint32_t bo = (blk & 1) * 2048;                     // two images per wave: block b+1 is written while b's reads return
       const bool ok1 = INTERIOR || (n_ok && row0 + blk * 16 < p.M), ok2 = INTERIOR || (n_ok && row0 + blk * 16 + 8 < p.M);
       float v[4][4];
-      float rs = 1.f;                                             // fp8: the row's quantisation scale
-      if constexpr (F8) { long r_ = m_base + blk * 16 + m; if (!INTERIOR) r_ = r_ < p.M ? r_ : p.M - 1; rs = p.sa[r_]; }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if constexpr (F8) v[ni][j] = acc[h][mi][ni][j] * (scale * rs) * cs8[ni][j] + b[ni][j];
-          else v[ni][j] = acc[h][mi][ni][j] * scale + b[ni][j];
-        }
+        for (int j = 0; j < 4; ++j) v[ni][j] = acc[h][mi][ni][j] * scale + b[ni][j];
       // the accumulators of this block are zeroed for the next tile HERE, in the shadow of the block's LDS round trip and store
       // issue (a P8_ZERO after the epilogue is 128 VALU slots per wave with the MFMA pipe idle)
 #pragma unroll
@@ -918,7 +898,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
             v[ni][j] = gg.x; v[ni][j + 1] = gg.y;
             w[ni][j] = dd.x; w[ni][j + 1] = dd.y;
           }
-        if (c2p && !F8) {
+        if (c2p) {
           // both outputs of the block go through the wave's two LDS images at once (second output in this block's image, the
           // activation in the other one): one LDS round trip per block instead of two
           u32x4 q1, q2;
@@ -934,19 +914,10 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
           __builtin_amdgcn_sched_barrier(0);
           if (ok1) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2) = q1;
           if (ok2) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2 + 8 * p.ldc2) = q2;
-        } else if (c2p) {                                       // (fp8 variant: no registers for four pieces in flight)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(w[ni][0], w[ni][1]), p8_pack2(w[ni][2], w[ni][3]));
-          p8_dsr128u<0>(o1, rad + bo);
-          p8_dsr128u<1024>(o2, rad + bo);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          if (ok1) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2) = o1;
-          if (ok2) *(u32x4*)(c2p + (long)blk * 16 * p.ldc2 + 8 * p.ldc2) = o2;
         }
       }
       // (the same wave's LDS operations execute in order: the image writes below cannot pass the reads above)
-      if (!(GELU2 && c2p && !F8)) {
+      if (!(GELU2 && c2p)) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) p8_dsw64<0>(wad[ni] + bo, p8_pack2(v[ni][0], v[ni][1]), p8_pack2(v[ni][2], v[ni][3]));
         p8_dsr128u<0>(o1, rad + bo);
@@ -1015,7 +986,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
       hook(blk);
       // the second half's R / G pieces are requested as soon as the first half's pieces of the same block row have been used
       // (three blocks of lead instead of one: the loads come from HBM)
-      if constexpr (HAS_EX && (EPI == EPI_GELU_GRAD || F8)) {   // (these variants have no registers left for the staggered form: it spilled)
+      if constexpr (HAS_EX && EPI == EPI_GELU_GRAD) {   // (this variant has no registers left for the staggered form: it spilled)
         if (blk == 3) { P8_LOAD_EX(1); }
       } else if constexpr (HAS_EX) {
         if (h == 0) {
@@ -1052,7 +1023,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
 // launch, the kernel-argument fetch and the address set-up once, and the tile boundary is {epilogue from registers -> DMA
 // prologue of the next tile} instead of {drain, exit, dispatch, prologue}.  (PMC at 84000x3072x768, one workgroup per tile:
 // the MFMA pipe was busy 49 % of the CU-busy cycles against 82 % at 4096^3 -- ~10 us of boundary per 13.6-us main loop.)
-template <int EPI, bool F8 = false>   // F8: A and W hold fp8 (E4M3) bytes, K-tile = 128 elements (the same 128 bytes per row), MFMA 16x16x128
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1061,7 +1032,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
   GEMM_DYN_M(p);                                     // device-side row count: fewer row panels than the grid was sized for
   const int ntm = (p.M + BM3 - 1) / BM3, ntn = (p.N + BN3 - 1) / BN3, nt = ntm * ntn;
   if ((int)blockIdx.x >= nt) return;                 // (whole workgroups: no barrier has been executed yet)
-  const int nk = p.K / (F8 ? 2 * BK : BK);           // even, >= 2 (launcher)
+  const int nk = p.K / BK;                           // even, >= 2 (launcher)
 
   f32x4 acc[2][4][4];                                // [m half][mi][ni], 128 accumulators
 #define P8_ZERO()                                                              \
@@ -1087,10 +1058,10 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                        \
       int row_ = m0 + j_ * 128 + h_ * 64 + (tid >> 3);                                                        \
       row_ = row_ < p.M ? row_ : p.M - 1;              /* clamped rows are computed and never stored */       \
-      offA[h_][j_] = (uint32_t)row_ * (uint32_t)(p.lda * (F8 ? 1 : 2)) + ls16;                                           \
+      offA[h_][j_] = (uint32_t)row_ * (uint32_t)(p.lda * 2) + ls16;                                                      \
       int col_ = n0 + (j_ * 2 + (tid >> 8)) * 64 + h_ * 32 + ((tid >> 3) & 31);                               \
       col_ = col_ < p.N ? col_ : p.N - 1;                                                                     \
-      offW[h_][j_] = (uint32_t)col_ * (uint32_t)(p.ldw * (F8 ? 1 : 2)) + ls16;                                           \
+      offW[h_][j_] = (uint32_t)col_ * (uint32_t)(p.ldw * 2) + ls16;                                                      \
     }                                                                                                         \
   } while (0)
   const char* gA = (const char*)p.A;
@@ -1147,23 +1118,13 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
     p8_dsr<(H) * P8_HT + 1 * 2048>(FW[1][1], wad[BUF][1]);                                    \
   } while (0)
   // one quadrant x K=64: 16 MFMA, 8 independent accumulators between dependent pairs
-  // (fp8: the two 16-byte pieces of a fragment are lane group q's chunks q and 4 + q of the 128-byte row -- the SAME two chunks
-  //  for both operands, so the 32 k-bytes a lane group feeds to v_mfma_f32_16x16x128_f8f6f4 pair up element by element; 8 MFMA
-  //  of 8 passes instead of 16 of 4: the phase keeps its 256 MFMA cycles)
 #define P8_MM(H, NH, FW)                                                                                        \
   do {                                                                                                          \
-    if constexpr (F8) {                                                                                         \
-      _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                       \
-      _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                                       \
-        acc[H][mi_][(NH) * 2 + ni_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                         \
-            p8_cat8(FW[ni_][0], FW[ni_][1]), p8_cat8(fa[mi_][0], fa[mi_][1]), acc[H][mi_][(NH) * 2 + ni_], 0, 0, 0, 0, 0, 0); \
-    } else {                                                                                                    \
-      _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                       \
-      _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                       \
-      _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                                       \
-        acc[H][mi_][(NH) * 2 + ni_] =                                                                           \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[ni_][kk_], fa[mi_][kk_], acc[H][mi_][(NH) * 2 + ni_], 0, 0, 0); \
-    }                                                                                                           \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                         \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                         \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                                         \
+      acc[H][mi_][(NH) * 2 + ni_] =                                                                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[ni_][kk_], fa[mi_][kk_], acc[H][mi_][(NH) * 2 + ni_], 0, 0, 0); \
   } while (0)
 #define P8_BAR() __builtin_amdgcn_s_barrier()
 #define P8_SB() __builtin_amdgcn_sched_barrier(0)
@@ -1272,7 +1233,6 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       GemmP q = p;
       asm volatile("" : "+s"(q.C), "+s"(q.ldc), "+s"(q.C2), "+s"(q.ldc2));
       asm volatile("" : "+s"(q.R), "+s"(q.ldr), "+s"(q.G), "+s"(q.ldg));
-      if constexpr (F8) asm volatile("" : "+s"(q.sa), "+s"(q.sw));
       if constexpr (EPI == EPI_DROPRES) asm volatile("" : "+s"(q.seed_ptr), "+s"(q.salt), "+s"(q.drop_thresh16), "+s"(q.drop_scale));
       if constexpr (EPI == EPI_DROPRES) asm volatile("" : "+s"(q.bias), "+s"(q.M), "+s"(q.N));
       else asm volatile("" : "+s"(q.bias), "+s"(q.colsum), "+s"(q.div_ptr), "+s"(q.alpha), "+s"(q.M), "+s"(q.N));
@@ -1281,14 +1241,14 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       const int mb = cm0 + wr * 128, nb = cn0 + wc * 64;
       const bool interior = cm0 + BM3 <= q.M && cn0 + BN3 <= q.N;
       if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
-        if (interior) p8_epilogue_blocks<EPI, true, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
-        else p8_epilogue_blocks<EPI, false, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
+        if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
       } else if (EPI == EPI_DROPRES || (EPI == EPI_BF16 && q.R != nullptr)) {
-        if (interior) p8_epilogue_blocks<EPI, true, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
-        else p8_epilogue_blocks<EPI, false, true, F8>(q, acc, xb, mb, nb, lane_e, hook);
+        if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
       } else {
-        if (interior) p8_epilogue_blocks<EPI, true, false, F8>(q, acc, xb, mb, nb, lane_e, hook);
-        else p8_epilogue_blocks<EPI, false, false, F8>(q, acc, xb, mb, nb, lane_e, hook);
+        if (interior) p8_epilogue_blocks<EPI, true, false>(q, acc, xb, mb, nb, lane_e, hook);
+        else p8_epilogue_blocks<EPI, false, false>(q, acc, xb, mb, nb, lane_e, hook);
       }
     }
     P8_STAMP(4);
@@ -1328,15 +1288,15 @@ int raise_lds(K kernel, int bytes, const char* what) {
   return SPMM_OK;
 }
 
-template <int EPI, bool F8 = false>
+template <int EPI>
 int launch_p8_one(const GemmP& p, hipStream_t st, bool persist) {
-  static const int rc = raise_lds(gemm_nt_p8_kernel<EPI, F8>, P8_LDS + P8_XLDS, "the 8-phase kernel");
+  static const int rc = raise_lds(gemm_nt_p8_kernel<EPI>, P8_LDS + P8_XLDS, "the 8-phase kernel");
   if (rc != SPMM_OK) return rc;
   const int nt = ((p.M + BM3 - 1) / BM3) * ((p.N + BN3 - 1) / BN3);
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n & ~7 : 256; }();
   // persistent: one workgroup per CU (a multiple of 8 so that a workgroup's tiles stay on its XCD's contiguous range)
   dim3 grid(persist && nt > ncu ? ncu : nt);
-  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, F8>), grid, dim3(512), P8_LDS + P8_XLDS, st, p);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI>), grid, dim3(512), P8_LDS + P8_XLDS, st, p);
   return SPMM_OK;
 }
 int launch_p8(int epi, const GemmP& p, hipStream_t st, bool persist) {
@@ -1486,7 +1446,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum; p.sa = nullptr; p.sw = nullptr;
+  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum;
   p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f; p.M_ptr = nullptr;
   // tile order (tile_of): K <= 1024 -> 2 (blocks of 8 row panels x up to 4 column tiles per XCD), longer K -> 0 (row-major).  Measured in
   // the cache state the step presents (a 256-MiB memset between launches, tools/gemm_bench sustain GEMM_BENCH_BETWEEN=1): 84256x2304x768
@@ -1544,7 +1504,7 @@ extern "C" int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ld
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
   p.M = M; p.N = N; p.K = K; p.ksplit = K; p.bias = bias; p.div_ptr = nullptr; p.alpha = 1.f;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = nullptr; p.ldg = 0; p.C = C; p.ldc = ldc;
-  p.C2 = nullptr; p.ldc2 = 0; p.colsum = nullptr; p.sa = nullptr; p.sw = nullptr;
+  p.C2 = nullptr; p.ldc2 = 0; p.colsum = nullptr;
   p.order = K > 1024 ? 0 : 2;
   p.seed_ptr = seed_ptr; p.salt = salt; p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f); p.drop_scale = 1.f / (1.f - dropout_p);
   p.M_ptr = M_dev;
@@ -1553,33 +1513,5 @@ extern "C" int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ld
                                   : launch_p8(EPI_DROPRES, p, stream, !(kernel == SPMM_GEMM_AUTO_TILES || kernel == 9));
   if (rc > 0) return rc;
   SPMM_LAUNCH_CHECK("spmm_gemm_nt_drop");
-  return SPMM_OK;
-}
-
-// ---- fp8 (E4M3) operands on the same 8-phase schedule: C[M,N] (bf16) = epi((A8 W8^T) * sa[m] * sw[n] + bias).
-// A8 [M,K], W8 [N,K] hold one byte per element (row strides in bytes = elements), sa / sw are the per-row quantisation scales
-// (value = byte * scale; spmm_quant_rows_fp8).  K % 256 == 0, N % 8 == 0.  Epilogues: SPMM_EPI_BF16 (+R), SPMM_EPI_GELU_DERIV
-// (C2 = gelu' optional: without it this is the plain GELU forward).
-extern "C" int spmm_gemm_nt_f8(const void* A8, long lda, const float* sa, const void* W8, long ldw, const float* sw, int M, int N, int K,
-                               const float* bias, const void* R, long ldr, void* C, long ldc, void* C2, long ldc2, int epi,
-                               hipStream_t stream) {
-  SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && K % 256 == 0 && N % 8 == 0, "spmm_gemm_nt_f8: M=%d N=%d K=%d (K %% 256 == 0, N %% 8 == 0)", M, N, K);
-  SPMM_CHECK_SHAPE(lda % 16 == 0 && ldw % 16 == 0 && ((uintptr_t)A8 % 16 == 0) && ((uintptr_t)W8 % 16 == 0), "spmm_gemm_nt_f8: fp8 rows must be 16-B aligned");
-  SPMM_CHECK_SHAPE(ldc % 8 == 0 && (!R || ldr % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (uintptr_t)C % 16 == 0, "spmm_gemm_nt_f8: bf16 outputs need 16-B aligned rows");
-  SPMM_CHECK_SHAPE(sa && sw, "spmm_gemm_nt_f8: the quantisation scales are required");
-  SPMM_CHECK_SHAPE(epi == EPI_BF16 || epi == EPI_GELU_DERIV, "spmm_gemm_nt_f8: epilogue %d (plain or GELU + derivative; C2 may be null)", epi);
-  SPMM_CHECK_SHAPE((unsigned long)M * (unsigned long)lda < (1ul << 32) && (unsigned long)N * (unsigned long)ldw < (1ul << 32), "spmm_gemm_nt_f8: operands must be < 4 GiB");
-  GemmP p;
-  p.A = (const bf16*)A8; p.lda = lda; p.W = (const bf16*)W8; p.ldw = ldw;
-  p.M = M; p.N = N; p.K = K; p.ksplit = K; p.bias = bias; p.div_ptr = nullptr; p.alpha = 1.f;
-  p.R = (const bf16*)R; p.ldr = ldr; p.G = nullptr; p.ldg = 0; p.C = C; p.ldc = ldc;
-  p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = nullptr; p.sa = sa; p.sw = sw;
-  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f; p.M_ptr = nullptr;
-  p.order = K > 2048 ? 0 : 2;
-  int rc;
-  if (epi == EPI_BF16) rc = launch_p8_one<EPI_BF16, true>(p, stream, true);
-  else rc = launch_p8_one<EPI_GELU_DERIV, true>(p, stream, true);
-  if (rc > 0) return rc;
-  SPMM_LAUNCH_CHECK("spmm_gemm_nt_f8");
   return SPMM_OK;
 }

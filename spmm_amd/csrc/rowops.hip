@@ -661,53 +661,6 @@ int grid_for(long work, int block) {
 }
 
 
-// ---------------------------------------------------------------- fp8 (E4M3, OCP) row quantisation for spmm_gemm_nt_f8
-// q[r][k] = fp8(x[r][k] / scale[r]), scale[r] = max_k |x[r][k]| / 448 (1 for an all-zero row).  One wave per row: the row is
-// read twice (the second time from L1 / L2), 8 elements per lane per step.  v_cvt_pk_fp8_f32 does not saturate (|v| > 464
-// becomes NaN), so the scaled value is clamped to +-448 first.
-template <bool XF32>
-__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xv, long ldx, long rows, int K,
-                                                             uint8_t* __restrict__ q, long ldq, float* __restrict__ scale) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  auto load8 = [&](int k, float (&v)[8]) {
-    if (XF32) {
-      const f32x4 a = *(const f32x4*)((const float*)xv + r * ldx + k), b = *(const f32x4*)((const float*)xv + r * ldx + k + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
-    } else {
-      const bf16x8 a = *(const bf16x8*)((const bf16*)xv + r * ldx + k);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
-    }
-  };
-  float amax = 0.f;
-  for (int k = lane * 8; k < K; k += 512) {
-    float v[8];
-    load8(k, v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-  }
-  amax = wave_max(amax);
-  const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
-  const float inv = 1.f / sc;
-  if (lane == 0) scale[r] = sc;
-  for (int k = lane * 8; k < K; k += 512) {
-    float v[8];
-    load8(k, v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j] * inv, -448.f), 448.f);
-    uint32_t w0 = 0, w1 = 0;
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
-    uint2 o; o.x = w0; o.y = w1;
-    *(uint2*)(q + r * ldq + k) = o;
-  }
-}
-
 }  // namespace
 
 extern "C" int spmm_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* zout,
@@ -741,15 +694,6 @@ extern "C" int spmm_ln_fwd_r32(const void* x, const float* res32, const float* g
   hipLaunchKernelGGL(ln_fwd_r32_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)x, res32, gamma, beta, (bf16*)y, y32,
                      (bf16*)zout, mean, rstd, rows, H, eps, (uint32_t)(dropout_p * 65536.f + 0.5f), 1.f / (1.f - dropout_p), seed_ptr, salt);
   SPMM_LAUNCH_CHECK("spmm_ln_fwd_r32");
-  return SPMM_OK;
-}
-
-extern "C" int spmm_quant_rows_fp8(const void* x, int x_is_f32, long ldx, long rows, int K, void* q, long ldq, float* scale, hipStream_t stream) {
-  SPMM_CHECK_SHAPE(rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "spmm_quant_rows_fp8: rows=%ld K=%d ldx=%ld ldq=%ld (multiples of 8)", rows, K, ldx, ldq);
-  SPMM_CHECK_SHAPE(((uintptr_t)x % 16 == 0) && ((uintptr_t)q % 8 == 0), "spmm_quant_rows_fp8: x must be 16-B aligned, q 8-B aligned");
-  if (x_is_f32) hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, K, (uint8_t*)q, ldq, scale);
-  else hipLaunchKernelGGL(quant_rows_fp8_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, K, (uint8_t*)q, ldq, scale);
-  SPMM_LAUNCH_CHECK("spmm_quant_rows_fp8");
   return SPMM_OK;
 }
 

@@ -80,22 +80,6 @@ class nt_tiles_per_workgroup:
         return False
 
 
-# Timing experiment (tools/fp8_bound.sh, EXPERIMENTS.md 3.5; NOT a product path, results are garbage): every NT GEMM whose epilogue the E4M3
-# kernel has (plain / +R / GELU + derivative) runs on it with the BYTES of its bf16 operands reinterpreted as fp8 -- no quantisation pass,
-# no extra memory -- which prices "all forward and data-gradient GEMMs in fp8 with free quantisation": an upper bound for the fp8 tier.
-_FP8_TIMING = os.environ.get("SPMM_FP8_TIMING_EXPERIMENT") == "1"
-_f8_ones = {}
-
-
-def _gemm_nt_f8_timing(A, W, C, bias, epi, R, C2, K):
-    M, N = A.shape[0], W.shape[0]
-    one = _f8_ones.get(A.device)
-    if one is None or one.numel() < max(M, N):
-        one = _f8_ones[A.device] = torch.full((max(M, N, 1 << 18),), 1e-3, dtype=torch.float32, device=A.device)
-    gemm_nt_f8(A.view(torch.uint8)[:, :K], one[:M], W.view(torch.uint8)[:, :K], one[:N], C, bias=bias, epi=epi, R=R, C2=C2)
-    return C
-
-
 def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=1.0, div=None, splits=1, K=None, colsum=None, kernel=0,
             M_dev=None):
     """C[M,N] (+)= A[M,K] @ W[N,K]^T.  A, W bf16 (row stride free, unit column stride).  kernel: 0 = chosen from the shape,
@@ -110,9 +94,6 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
         assert C.dtype == BF16
     else:
         assert C.dtype == torch.float32
-    if (_FP8_TIMING and M_dev is None and epi in (EPI_BF16, EPI_GELU_DERIV) and K % 256 == 0 and N % 8 == 0 and M >= 4096 and div is None and colsum is None
-            and alpha == 1.0 and splits == 1 and C.stride(1) == 1):
-        return _gemm_nt_f8_timing(A, W, C, bias, epi, R, C2, K)
     _call("spmm_gemm_nt", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, splits, _p(bias), _p(div),
                float(alpha), _p(R), 0 if R is None else _row_stride(R), _p(G), 0 if G is None else _row_stride(G),
                _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), epi, _p(colsum), int(kernel), _p(M_dev), _st())
@@ -404,26 +385,6 @@ def mpm_head(h, Lp, H, w, bias, target, mask, *, B, ws, losses, slot, pred=None,
     do_bwd = dh is not None
     _call("spmm_mpm_head", _p(h), Lp, H, _p(w), _p(bias), _p(target), _p(mask), B, _p(ws), _p(gscale), _p(losses), slot,
                _p(pred), _p(dh), _p(dw), _p(db), int(do_bwd), int(h.dtype == torch.float32), _st())
-
-
-def quant_rows_fp8(x, q=None, scale=None):
-    """Per-row E4M3 quantisation: returns (q uint8 [rows, K], scale fp32 [rows]) with x ~ q * scale[:, None]."""
-    rows, K = x.shape
-    assert x.dtype in (BF16, torch.float32) and x.stride(1) == 1
-    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
-    scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
-    _call("spmm_quant_rows_fp8", _p(x), int(x.dtype == torch.float32), _row_stride(x), rows, K, _p(q), _row_stride(q), _p(scale), _st())
-    return q, scale
-
-
-def gemm_nt_f8(A8, sa, W8, sw, C, *, bias=None, epi=EPI_BF16, R=None, C2=None):
-    """C[M,N] (bf16) = epi((A8 @ W8^T) * sa[:, None] * sw[None, :] + bias): fp8 (E4M3) operands as uint8, fp32 accumulation."""
-    M, K = A8.shape
-    N = W8.shape[0]
-    assert A8.dtype == torch.uint8 and W8.dtype == torch.uint8 and W8.shape[1] == K and C.dtype == BF16
-    _call("spmm_gemm_nt_f8", _p(A8), _row_stride(A8), _p(sa), _p(W8), _row_stride(W8), _p(sw), M, N, K, _p(bias), _p(R),
-          0 if R is None else _row_stride(R), _p(C), _row_stride(C), _p(C2), 0 if C2 is None else _row_stride(C2), int(epi), _st())
-    return C
 
 
 def rows_linear(x, W, bias, out, *, act=0):

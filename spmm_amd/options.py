@@ -18,7 +18,6 @@ _ENV = {
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
     "pv_wgrad_inline": ("SPMM_PV_WGRAD_INLINE", int),
-    "fp8": ("SPMM_FP8", lambda s: s == "1"),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
     "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
     "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
@@ -47,8 +46,7 @@ class EngineOptions:
     #                               own stream: it ends ~2 ms before the text encoder's on the side stream, and the one weight-gradient stream,
     #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10)
     fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)
-    # --- precision tiers (NOT the headline configuration) ---
-    fp8: bool = False             # E4M3 FFN forward GEMMs (BASELINE configs[4])
+    # --- precision (NOT the headline configuration) ---
     resid_fp32: bool = False      # fp32 residual stream through the LayerNorms and fp32 inputs to the loss heads
     # --- data parallelism (spmm_amd/parallel.py) ---
     grad_overlap: bool = True     # per-layer gradient exchange issued during the backward; False = one bucketed all-reduce after it

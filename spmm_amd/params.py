@@ -68,7 +68,6 @@ class ParamStore:
             elif k == "ptr":
                 self.buffers[n] = torch.zeros(1, dtype=torch.long, device=device)
         self._wT: Dict[str, torch.Tensor] = {}     # transposed bf16 shadows for dgrad, keyed by (fused) name
-        self._w8: Dict[str, tuple] = {}            # fp8 tier: name -> (fp32 master view, E4M3 bytes, per-row scales)
         self._wF: Dict[str, tuple] = {}            # fused cross-attention: name -> (bf16 shadow view, fragment-ordered image, is momentum)
 
     # ---- views -----------------------------------------------------------------------------------------------
@@ -144,28 +143,16 @@ class ParamStore:
             if mom == momentum:
                 ops.xattn_pack_wo(src, out)
 
-    def w8(self, name: str):
-        """(fp8 E4M3 bytes [out,in], per-output-row scale [out]) of a weight for the fp8 tier (spmm_gemm_nt_f8); quantised from the
-        fp32 master (student or momentum twin) on first use and again by refresh_shadows()."""
-        if name not in self._w8:
-            src = self.w(name)
-            self._w8[name] = (src, torch.empty(src.shape, dtype=torch.uint8, device=self.device),
-                              torch.empty(src.shape[0], dtype=torch.float32, device=self.device))
-            ops.quant_rows_fp8(src, self._w8[name][1], self._w8[name][2])
-        return self._w8[name][1], self._w8[name][2]
-
     # ---- maintenance -----------------------------------------------------------------------------------------
     def refresh_shadows(self, transposed_only: bool = False, part: str = "all"):
         """bf16 shadows <- fp32 masters (after load_state_dict / optimiser step).  AdamW and the EMA kernels already
         refresh the flat shadows; the transposed dgrad shadows are rebuilt here, one launch for all of them.
-        part: "forward" = only what the next FORWARD reads (fp8 weight images, fragment-ordered images of the fused cross-attention),
+        part: "forward" = only what the next FORWARD reads (fragment-ordered images of the fused cross-attention),
         "transposed" = only the data-gradient GEMMs' transposed shadows (read by the next BACKWARD: Engine.off_path), "all" = both."""
         if not transposed_only:
             ops.cast_f32_bf16(self.flat, self.shadow)
             ops.cast_f32_bf16(self.flat_m, self.shadow_m)
         if part in ("all", "forward"):
-            for src, q, sc in self._w8.values():
-                ops.quant_rows_fp8(src, q, sc)
             self.refresh_frag(False)
             if not transposed_only:
                 self.refresh_frag(True)

@@ -702,59 +702,6 @@ def test_dropout_masks_equal_the_host_model_of_the_hash(ops):
         assert abs((1 - m.mean()) - pt) < 4 * (pt * (1 - pt) / n) ** 0.5, (1 - m.mean(), pt)
 
 
-# ------------------------------------------------------------------------------------------- fp8 tier (BASELINE configs[4])
-def _e4m3_decode(q):
-    """uint8 -> float: OCP E4M3 (bias 7, no infinities, 0x7f / 0xff NaN)."""
-    q = q.to(torch.int32)
-    s, e, m = q >> 7, (q >> 3) & 15, q & 7
-    v = torch.where(e == 0, m.float() * 2.0 ** -9, (1 + m.float() / 8) * torch.exp2(e.float() - 7))
-    return torch.where(s == 1, -v, v)
-
-
-@pytest.mark.parametrize("dtype", [BF, torch.float32])
-def test_fp8_row_quantisation(ops, dtype):
-    rows, K = 1001, 768
-    x = (torch.randn(rows, K, device="cuda") * torch.logspace(-3, 2, rows, device="cuda")[:, None]).to(dtype)
-    x[5] = 0
-    q, sc = ops.quant_rows_fp8(x)
-    xf = x.float()
-    amax = xf.abs().amax(1)
-    assert torch.allclose(sc, torch.where(amax > 0, amax / 448, torch.ones_like(amax)), rtol=1e-6)
-    deq = _e4m3_decode(q) * sc[:, None]
-    assert torch.isfinite(deq).all() and (deq[5] == 0).all()
-    # E4M3 has 3 mantissa bits: |rel err| <= 2^-4 for normal values, absolute floor = half the smallest subnormal step of the row
-    bound = xf.abs() * 2.0 ** -4 + sc[:, None] * 2.0 ** -10
-    assert ((deq - xf).abs() <= bound).all()
-    assert (_e4m3_decode(q).abs().amax(1)[amax > 0] == 448).all()                   # the row maximum lands on the largest code
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (1000, 768, 768, 0), (2100, 3072, 768, 6), (4099, 768, 3072, 0), (517, 264, 512, 6)])
-def test_fp8_gemm_matches_dequantised_reference(ops, M, N, K, epi):
-    """spmm_gemm_nt_f8 against fp32 matmul of the DEQUANTISED operands (so only accumulation order and the bf16 output rounding
-    differ), plus the distance to the unquantised product (what fp8 costs: ~2^-4 / sqrt-K-averaged)."""
-    A, W = rnd(M, K, seed=70), rnd(N, K, scale=0.05, seed=71)
-    bias = (0.1 * torch.randn(N)).cuda()
-    A8, sa = ops.quant_rows_fp8(A)
-    W8, sw = ops.quant_rows_fp8(W)
-    C = torch.empty(M, N, dtype=BF, device="cuda")
-    C2 = torch.empty(M, N, dtype=BF, device="cuda") if epi == 6 else None
-    R = rnd(M, N, seed=72) if epi == 0 else None
-    ops.gemm_nt_f8(A8, sa, W8, sw, C, bias=bias, epi=epi, R=R, C2=C2)
-    pre = (_e4m3_decode(A8) * sa[:, None]) @ (_e4m3_decode(W8) * sw[:, None]).t() + bias
-    full = A.float() @ W.float().t() + bias
-    if epi == 0:
-        close(C, pre + R.float(), 2e-2, 1e-2, "fp8 gemm (+R)")
-        rel = ((C.float() - R.float() - full).norm() / full.norm()).item()
-    else:
-        close(C, torch.nn.functional.gelu(pre), 2e-2, 1e-2, "fp8 gemm + gelu")
-        x = pre
-        dref = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-        close(C2, dref, 2e-2, 1e-2, "fp8 gemm gelu'")
-        rel = ((C.float() - torch.nn.functional.gelu(full)).norm() / torch.nn.functional.gelu(full).norm()).item()
-    print(f"  fp8 vs unquantised: relative L2 error {rel:.4f}")
-    assert rel < 0.06
-
-
 # ------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,H", [(7, 128), (1000, 768), (1003, 768), (333, 256), (64, 1024), (61, 512), (5, 1000)])
 def test_layernorm_fwd_bwd(ops, rows, H):

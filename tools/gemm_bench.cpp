@@ -252,39 +252,6 @@ static int cmd_tntime(int M, int N, int K, int rounds) {
   return 0;
 }
 
-// fp8 (E4M3) GEMM on the 8-phase schedule next to the bf16 one: `f8time M N K [epi 0|6] [rounds]` (quantisation timed separately)
-static int cmd_f8time(int M, int N, int K, int epi, int rounds) {
-  auto hA = rand_bf16((size_t)M * K, 1.0f), hW = rand_bf16((size_t)N * K, 0.05f);
-  Buf A, W, A8, W8, sa, sw, C, C2;
-  A.alloc(hA.size() * 2); W.alloc(hW.size() * 2); A8.alloc(hA.size()); W8.alloc(hW.size()); sa.alloc((size_t)M * 4); sw.alloc((size_t)N * 4);
-  C.alloc((size_t)M * N * 2); C2.alloc((size_t)M * N * 2);
-  CK(hipMemcpy(A.d, hA.data(), A.bytes, hipMemcpyHostToDevice)); CK(hipMemcpy(W.d, hW.data(), W.bytes, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  if (spmm_quant_rows_fp8(W.d, 0, K, N, K, W8.d, K, (float*)sw.d, 0)) { printf("%s\n", spmm_last_error()); return 1; }
-  std::vector<float> tq, t8, t16;
-  for (int r = 0; r < rounds; ++r) {
-    float ms;
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i) if (spmm_quant_rows_fp8(A.d, 0, K, M, K, A8.d, K, (float*)sa.d, 0)) { printf("%s\n", spmm_last_error()); return 1; }
-    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); tq.push_back(ms / 5);
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i)
-      if (spmm_gemm_nt_f8(A8.d, K, (const float*)sa.d, W8.d, K, (const float*)sw.d, M, N, K, nullptr, nullptr, 0, C.d, N, epi == SPMM_EPI_GELU_DERIV ? C2.d : nullptr, N, epi, 0)) {
-        printf("%s\n", spmm_last_error()); return 1; }
-    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t8.push_back(ms / 5);
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i)
-      if (spmm_gemm_nt(A.d, K, W.d, K, M, N, K, 1, nullptr, nullptr, 1.0f, nullptr, N, nullptr, N, C.d, N, epi == SPMM_EPI_GELU_DERIV ? C2.d : nullptr, N, epi, nullptr, 8, nullptr, 0)) {
-        printf("%s\n", spmm_last_error()); return 1; }
-    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t16.push_back(ms / 5);
-  }
-  auto med = [](std::vector<float>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-  const float q = med(tq), f8 = med(t8), b16 = med(t16);
-  printf("%6d x %5d x %5d epi %d :  fp8 %8.1f us %7.1f TF   bf16 %8.1f us %7.1f TF   quantise A %7.1f us (%.0f GB/s)\n", M, N, K, epi, f8 * 1e3,
-         2.0 * M * N * K / (f8 * 1e-3) / 1e12, b16 * 1e3, 2.0 * M * N * K / (b16 * 1e-3) / 1e12, q * 1e3, 3.0 * M * K / (q * 1e-3) / 1e9);
-  return 0;
-}
-
 // `sustain M N K [epi] [launches]`: back-to-back launches of one GEMM, TF/s per block of 100 -- does the rate of the first
 // milliseconds (what `time` reports) hold once the chip has been at full MFMA load for a second?  With GEMM_BENCH_ROTATE=n the
 // launches rotate over n different A / C buffer pairs (as the training step's GEMMs do) instead of re-using one.
@@ -379,7 +346,6 @@ int main(int argc, char** argv) {
   if (argc >= 9 && !strcmp(argv[1], "contend"))
     return cmd_contend(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), argc > 9 ? atoi(argv[9]) : 100);
   if (argc >= 5 && !strcmp(argv[1], "sustain")) return cmd_sustain(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 2000);
-  if (argc >= 5 && !strcmp(argv[1], "f8time")) return cmd_f8time(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 5);
   if (argc >= 2 && !strcmp(argv[1], "check")) return cmd_check();
   if (argc >= 2 && !strcmp(argv[1], "tncheck")) return cmd_tncheck();
   if (argc >= 5 && !strcmp(argv[1], "tntime")) return cmd_tntime(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 5);
