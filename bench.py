@@ -619,17 +619,20 @@ def main():
             fl = sum(cross_attn_unit_flops(g.nseq, g.L, g.Lkv) for g in groups)
             Hh = X.shape[1]
             core_b = 2.0 * (2 * X.shape[0] * Hh + sum(g.nseq * g.Lkv * 2 * Hh for g in groups))      # Q in, context out, K / V per query sequence
-            ev["xattn"].append((e0, e1, (fl, cross_attn_executed_flops(groups, X.shape[0]), core_b, 2.0 * 4 * X.shape[0] * Hh)))
+            ev["xattn"].append((e0, e1, (fl, cross_attn_executed_flops(groups, X.shape[0]), core_b, 2.0 * 4 * X.shape[0] * Hh, bool(save))))
             return r
 
         eng._attn_block_fwd = blk
         for i in range(nsteps):
             one_step(i)
         torch.cuda.synchronize()
-        # ... and the same block as ONE launch per query group (csrc/xattn.hip, EngineOptions.fused_xattn): timed beside the composite
-        # whichever of the two the step uses by default
+        # ... and the other form beside the default one.  Default since round 6 (EngineOptions.fused_xattn = "nograd"): the passes that keep
+        # no tape (the momentum fusion pass) run the block as ONE launch per query group (csrc/xattn.hip: core + output projection + dropout +
+        # residual + LayerNorm), the taped student passes as the composite of launches; the other form here = the composite everywhere
+        # ("off"; or "all" = the row-panel kernel everywhere when the run's default is "off")
         n_comp = len(ev["xattn"])
-        eng.opt = opts.replace(fused_xattn=not opts.fused_xattn)
+        other_mode = "off" if opts.fused_xattn != "off" else "all"
+        eng.opt = opts.replace(fused_xattn=other_mode)
         one_step(0)                                          # untimed: the fused form's one-time self-check (a host sync) happens here
         torch.cuda.synchronize()
         n_comp, n_skip = len(ev["xattn"]), len(ev["xattn"]) - n_comp
@@ -655,9 +658,16 @@ def main():
                  "executed_tflops": round(x_exe / (x_ms * 1e-3) / 1e12, 1),
                  "executed_frac_of_bf16_peak": round(x_exe / (x_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                  "calls_per_step": len(ev["xattn"]) // nsteps, "ms_per_step": round(x_ms / nsteps, 3),
-                 "form": "fused row-panel kernel (csrc/xattn.hip) + Q and K/V projection GEMMs" if opts.fused_xattn else
-                         "composite: Q GEMM + K/V GEMM + attn_fwd per group + output GEMM + ln_fwd",
+                 "form": {"off": "composite: Q GEMM + K/V GEMM + attn_fwd per group + output GEMM + ln_fwd",
+                          "all": "fused row-panel kernel (csrc/xattn.hip) + Q and K/V projection GEMMs",
+                          "nograd": "no-grad passes (momentum fusion pass, 6 of the 12 calls): fused row-panel kernel (csrc/xattn.hip) + Q and K/V projection "
+                                    "GEMMs; taped student passes: composite of Q GEMM + K/V GEMM + attn_fwd per group + output GEMM + ln_fwd"}[opts.fused_xattn],
+                 "ms_per_step_taped_calls": round(sum(a.elapsed_time(b) for a, b, fl in ev["xattn"] if fl[4]) / nsteps, 3),
+                 "ms_per_step_nograd_calls": round(sum(a.elapsed_time(b) for a, b, fl in ev["xattn"] if not fl[4]) / nsteps, 3),
+                 "other_form": other_mode,
                  "other_form_ms_per_step": round(sum(a.elapsed_time(b) for a, b, _ in ev_other) / nsteps, 3),
+                 "other_form_ms_per_step_taped_calls": round(sum(a.elapsed_time(b) for a, b, fl in ev_other if fl[4]) / nsteps, 3),
+                 "other_form_ms_per_step_nograd_calls": round(sum(a.elapsed_time(b) for a, b, fl in ev_other if not fl[4]) / nsteps, 3),
                  "other_form_executed_frac_of_bf16_peak": round(sum(fl[1] for _, _, fl in ev_other) / (sum(a.elapsed_time(b) for a, b, _ in ev_other) * 1e-3)
                                                                 / 1e12 / PEAK_BF16_TFLOPS, 4),
                  "note": "algorithmic = the reference's work, nseq*(4H^2 Lq + 4H^2 Lkv + 4 Lq Lkv H) per query sequence; executed = what runs here "

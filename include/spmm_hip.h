@@ -71,17 +71,7 @@ const char* spmm_last_error(void);
 int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int splits, const float* bias,
                  const float* div_ptr, float alpha, const void* R, long ldr, const void* G, long ldg, void* C, long ldc,
                  void* C2, long ldc2, int epi, float* colsum, int kernel, const int* M_dev, spmm_stream_t stream);
-/* The output projection in front of a residual LayerNorm with the hidden dropout and the residual in its epilogue:
- *   C(bf16) = dropout(bf16(A W^T + bias)) + R        BertSelfOutput / BertOutput xbert.py:370-372, 448-450 (up to the LayerNorm)
- * on the 8-phase kernel, so that spmm_ln_fwd(C, res = NULL, dropout_p = 0) reads one tensor instead of two.  The mask is the one
- * spmm_ln_fwd / spmm_ln_bwd draw for the same (seed, salt, row, column): spmm_ln_bwd(..., dropout_p, seed, salt) serves it unchanged.
- * K % 128 == 0, N % 8 == 0; kernel 0 / SPMM_GEMM_AUTO_TILES / 8 / 9.  spmm_gemm_nt_drop_ok: 1 where the automatic choice of spmm_gemm_nt
- * would take the 8-phase kernel for this shape anyway (callers keep the two-launch form elsewhere). */
-int spmm_gemm_nt_drop_ok(int M, int N, int K);
-int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, const void* R,
-                      long ldr, void* C, long ldc, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int kernel,
-                      const int* M_dev, spmm_stream_t stream);
-/* Device-side row counts (`M_dev` / `R_dev` / `rows_dev`, optional, null = none): spmm_gemm_nt (8-phase kernel), spmm_gemm_nt_drop,
+/* Device-side row counts (`M_dev` / `R_dev` / `rows_dev`, optional, null = none): spmm_gemm_nt (8-phase kernel),
  * spmm_gemm_tn (8-phase kernel, split launch), spmm_colsum_bf16, spmm_ln_fwd and spmm_ln_bwd take a pointer to an int in device memory
  * holding the number of rows to process, <= the host-side row count the launch and the buffers are sized for.  Rows past it are neither
  * read nor written.  For batches whose tail length only the device knows -- here the text hard negatives drawn on the device

@@ -289,10 +289,7 @@ def _finish_aliases(sd: SD, cfg: SPMMCfg) -> None:
 # Round 5: `bf16_storage(backward=True)` extends the model to the BACKWARD: the gradient that autograd sends back through one of those
 # storage points is rounded to bf16 too -- the product materialises d(loss)/d(that tensor) as a bf16 tensor between two of its kernels
 # (data-gradient GEMM / LayerNorm-backward / attention-backward outputs), while weight and bias gradients, the hub gradients of the
-# shared key / value sources and all accumulation stay fp32 (engine.py, step.py).  `bf16_storage(fused_sum=True)` models the
-# EngineOptions.fuse_drop_res form: the projection in front of a residual LayerNorm writes the pre-norm sum itself (spmm_gemm_nt_drop), so
-# that sum is a storage point the LayerNorm reads back (`_ln(..., stored_sum=True)`); in the default form the LayerNorm kernel forms the
-# sum in fp32 registers and only its backward copy is rounded.
+# shared key / value sources and all accumulation stay fp32 (engine.py, step.py).
 # Round 6: `bf16_storage(only={...})` rounds ONE (or a few) storage classes and leaves the others in fp32 -- the ablation that says which
 # stores carry a loss's deviation (tools/storage_ablation.py -> profiles/r06_storage_ablation.txt).  Classes: "weights" (bf16 GEMM shadows),
 # "qkv" (query / key / value projections), "softmax_e" (the un-normalised numerators fed to the second attention MFMA), "attn_ctx" (attention
@@ -301,27 +298,26 @@ def _finish_aliases(sd: SD, cfg: SPMMCfg) -> None:
 STORAGE_CLASSES = ("weights", "qkv", "softmax_e", "attn_ctx", "attn_proj", "ffn_up", "ffn_down", "ln", "heads")
 _BF16_STORAGE = False
 _BF16_STORAGE_BWD = False
-_BF16_FUSED_SUM = False
 _BF16_ONLY = None
 _BF16_WEIGHTS = None          # regex on the Linear's parameter prefix: which weight shadows are rounded (None = all)
 
 
 class bf16_storage:
-    def __init__(self, backward: bool = False, fused_sum: bool = False, only=None, weights=None):
-        self.backward, self.fused_sum = backward, fused_sum
+    def __init__(self, backward: bool = False, only=None, weights=None):
+        self.backward = backward
         self.weights = None if weights is None else re.compile(weights)
         self.only = None if only is None else frozenset(only)
         if self.only is not None and not self.only <= set(STORAGE_CLASSES):
             raise ValueError(f"unknown storage classes {sorted(self.only - set(STORAGE_CLASSES))}")
 
     def __enter__(self):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS
-        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS), True
-        _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS = self.backward, self.fused_sum, self.only, self.weights
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_ONLY, _BF16_WEIGHTS
+        self._old, _BF16_STORAGE = (_BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_ONLY, _BF16_WEIGHTS), True
+        _BF16_STORAGE_BWD, _BF16_ONLY, _BF16_WEIGHTS = self.backward, self.only, self.weights
 
     def __exit__(self, *exc):
-        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS
-        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_FUSED_SUM, _BF16_ONLY, _BF16_WEIGHTS = self._old
+        global _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_ONLY, _BF16_WEIGHTS
+        _BF16_STORAGE, _BF16_STORAGE_BWD, _BF16_ONLY, _BF16_WEIGHTS = self._old
 
 
 class _RoundBothWays(torch.autograd.Function):
@@ -369,10 +365,8 @@ def _lin(sd: SD, p: str, x: Tensor, act=None, f32_out: bool = False, f32_w: bool
     return y if f32_out else _st(y, _lin_class(p))
 
 
-def _ln(sd: SD, p: str, x: Tensor, eps: float, stored_sum: bool = False) -> Tensor:
-    """stored_sum: x is the pre-norm sum dropout(dense(.)) + residual, which the product writes to HBM (bf16) before the LayerNorm reads it."""
-    if stored_sum and _BF16_FUSED_SUM:
-        x = _st(x, "ln")
+def _ln(sd: SD, p: str, x: Tensor, eps: float) -> Tensor:
+    """(the product's LayerNorm kernel forms the pre-norm sum in fp32 registers: only the OUTPUT is a storage point)"""
     return _st(F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps), "ln")
 
 
@@ -431,7 +425,7 @@ def attention(sd: SD, p: str, c: BertCfg, hidden: Tensor, add_mask: Tensor,
         pr = _drop(torch.softmax(s, dim=-1), c.attention_probs_dropout_prob, train)
         ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
     out = _drop(_lin(sd, p + ".output.dense", ctx), c.hidden_dropout_prob, train)
-    return _ln(sd, p + ".output.LayerNorm", out + hidden, c.layer_norm_eps, stored_sum=True)
+    return _ln(sd, p + ".output.LayerNorm", out + hidden, c.layer_norm_eps)
 
 
 def bert_layer(sd: SD, p: str, c: BertCfg, i: int, has_cross: bool, hidden, self_mask,
@@ -444,7 +438,7 @@ def bert_layer(sd: SD, p: str, c: BertCfg, i: int, has_cross: bool, hidden, self
         a = attention(sd, lp + "crossattention", c, a, enc_mask, enc, train)
     h = _lin(sd, lp + "intermediate.dense", a, act=F.gelu)                   # :434-437 erf GELU
     o = _drop(_lin(sd, lp + "output.dense", h), c.hidden_dropout_prob, train)  # :447-451
-    return _ln(sd, lp + "output.LayerNorm", o + a, c.layer_norm_eps, stored_sum=True)
+    return _ln(sd, lp + "output.LayerNorm", o + a, c.layer_norm_eps)
 
 
 def bert_model(sd: SD, p: str, c: BertCfg, has_cross: bool, *, input_ids=None, inputs_embeds=None,

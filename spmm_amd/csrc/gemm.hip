@@ -23,11 +23,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
 
-enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5, EPI_GELU_DERIV = 6, EPI_MUL = 7,
-           EPI_DROPRES = 10 };                    // C = dropout(bf16(acc + bias)) + R: spmm_gemm_nt_drop (8-phase kernel only)
+enum Epi { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_F32_ATOMIC = 3, EPI_GELU_GRAD = 4, EPI_F32_ACC = 5, EPI_GELU_DERIV = 6, EPI_MUL = 7 };
 // bf16-output epilogues (LDS-transposed, row-coalesced stores): BF16, GELU (C2 = pre-activation), GELU_DERIV (C2 = gelu'(pre)),
 // GELU_GRAD (C = acc * gelu'(G), G = pre-activation), MUL (C = acc * G, G = a stored derivative)
-constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU || e == EPI_GELU_GRAD || e == EPI_GELU_DERIV || e == EPI_MUL || e == EPI_DROPRES; }
+constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU || e == EPI_GELU_GRAD || e == EPI_GELU_DERIV || e == EPI_MUL; }
 
 struct GemmP {
   const bf16* A; long lda;
@@ -43,9 +42,6 @@ struct GemmP {
   bf16* C2; long ldc2;       // EPI_GELU: pre-activation output; EPI_GELU_DERIV: gelu'(pre-activation)
   float* colsum;             // optional: colsum[n] += sum_m C[m][n] of the (bf16-rounded) output -- bias gradient of the producing layer
   int order;                 // tile order inside an XCD's range (tile_of): 0 row-major, 3 row-major inside 2 column groups
-  // EPI_DROPRES (spmm_gemm_nt_drop): the hidden dropout of BertSelfOutput / BertOutput (xbert.py:371,449) inside the epilogue -- the mask
-  // spmm_ln_fwd / spmm_ln_bwd draw for (seed, salt, row, column): element (m, n) uses half (n & 1) of drop_pair(drop_rowkey(seed', m), n >> 1)
-  const uint64_t* seed_ptr; uint64_t salt; uint32_t drop_thresh16; float drop_scale;
   // optional device-side row count (8-phase kernel only): the launch is SIZED for M rows, the kernel computes *M_ptr <= M of them -- the
   // rows of a batch whose tail length only the device knows (step.py: the hard negatives drawn as text queries)
   const int* M_ptr;
@@ -823,11 +819,8 @@ __device__ __forceinline__ void p8_dsr128u(u32x4& d, uint32_t addr) {
 template <int EPI, bool INTERIOR, bool HAS_EX, typename Hook>
 __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[2][4][4], uint32_t xb /* LDS byte address of the wave's 4 KiB */,
                                                    int m_base, int n_base, int lane, Hook hook) {
-  float scale = 1.f;                                            // (EPI_DROPRES takes neither alpha nor div nor colsum: its scalar registers go to the dropout state)
-  if constexpr (EPI != EPI_DROPRES) {
-    scale = p.alpha;
-    if (p.div_ptr) scale /= *p.div_ptr;
-  }
+  float scale = p.alpha;
+  if (p.div_ptr) scale /= *p.div_ptr;
   const int m = lane & 15, g = lane >> 4, r8 = lane >> 3, c16 = lane & 7;
   f32x4 b[4];
 #pragma unroll
@@ -866,8 +859,6 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
     }                                                                          \
   }
   P8_LOAD_EX(0);
-  uint64_t dseed = 0;
-  if constexpr (EPI == EPI_DROPRES) dseed = seed_mix(p.seed_ptr, p.salt);
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -932,21 +923,6 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
           o2[d] = p8_pack2(p8_lo(o2[d]) + p8_lo(ex[2 * mi + 1][d]), p8_hi(o2[d]) + p8_hi(ex[2 * mi + 1][d]));
         }
       }
-      if constexpr (EPI == EPI_DROPRES) {
-        // z = dropout(x) + R on the bf16-rounded x, exactly what spmm_ln_fwd computes from a stored x: o1 / o2 hold columns n .. n + 7 of
-        // rows row0 + blk * 16 (+ 8); one 32-bit hash per pair of columns, keyed by the row (common.h)
-        const float ds = p.drop_scale;
-        const uint32_t th = p.drop_thresh16;
-        const uint32_t k1 = drop_rowkey(dseed, (uint64_t)(row0 + blk * 16)), k2 = drop_rowkey(dseed, (uint64_t)(row0 + blk * 16 + 8));
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const uint32_t h1 = drop_pair(k1, ((uint32_t)n >> 1) + d), h2 = drop_pair(k2, ((uint32_t)n >> 1) + d);
-          const float a0 = (h1 & 0xffffu) >= th ? p8_lo(o1[d]) * ds : 0.f, a1 = (h1 >> 16) >= th ? p8_hi(o1[d]) * ds : 0.f;
-          const float b0 = (h2 & 0xffffu) >= th ? p8_lo(o2[d]) * ds : 0.f, b1 = (h2 >> 16) >= th ? p8_hi(o2[d]) * ds : 0.f;
-          o1[d] = p8_pack2(a0 + p8_lo(ex[2 * mi][d]), a1 + p8_hi(ex[2 * mi][d]));
-          o2[d] = p8_pack2(b0 + p8_lo(ex[2 * mi + 1][d]), b1 + p8_hi(ex[2 * mi + 1][d]));
-        }
-      }
       if constexpr (EPI == EPI_GELU_GRAD) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -961,7 +937,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
           o2[d] = p8_pack2(p8_lo(o2[d]) * p8_lo(ex[2 * mi + 1][d]), p8_hi(o2[d]) * p8_hi(ex[2 * mi + 1][d]));
         }
       }
-      if constexpr (!GELU2 && EPI != EPI_DROPRES) {
+      if constexpr (!GELU2) {
         if (p.colsum) {
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
@@ -1001,7 +977,7 @@ __device__ __forceinline__ void p8_epilogue_blocks(const GemmP& p, f32x4 (&acc)[
     }
 #undef P8_LOAD_EX
 #undef P8_EX_LOAD1
-  if constexpr (!GELU2 && EPI != EPI_DROPRES) {
+  if constexpr (!GELU2) {
     if (p.colsum) {   // lanes l, l^8, l^16, l^32 hold the same 8 columns for different rows
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1233,9 +1209,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       GemmP q = p;
       asm volatile("" : "+s"(q.C), "+s"(q.ldc), "+s"(q.C2), "+s"(q.ldc2));
       asm volatile("" : "+s"(q.R), "+s"(q.ldr), "+s"(q.G), "+s"(q.ldg));
-      if constexpr (EPI == EPI_DROPRES) asm volatile("" : "+s"(q.seed_ptr), "+s"(q.salt), "+s"(q.drop_thresh16), "+s"(q.drop_scale));
-      if constexpr (EPI == EPI_DROPRES) asm volatile("" : "+s"(q.bias), "+s"(q.M), "+s"(q.N));
-      else asm volatile("" : "+s"(q.bias), "+s"(q.colsum), "+s"(q.div_ptr), "+s"(q.alpha), "+s"(q.M), "+s"(q.N));
+      asm volatile("" : "+s"(q.bias), "+s"(q.colsum), "+s"(q.div_ptr), "+s"(q.alpha), "+s"(q.M), "+s"(q.N));
       auto hook = [](int) {};
       const uint32_t xb = lds0 + P8_LDS + wave * 4096;
       const int mb = cm0 + wr * 128, nb = cn0 + wc * 64;
@@ -1243,7 +1217,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmP p) {
       if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_MUL) {
         if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
         else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
-      } else if (EPI == EPI_DROPRES || (EPI == EPI_BF16 && q.R != nullptr)) {
+      } else if (EPI == EPI_BF16 && q.R != nullptr) {
         if (interior) p8_epilogue_blocks<EPI, true, true>(q, acc, xb, mb, nb, lane_e, hook);
         else p8_epilogue_blocks<EPI, false, true>(q, acc, xb, mb, nb, lane_e, hook);
       } else {
@@ -1306,7 +1280,6 @@ int launch_p8(int epi, const GemmP& p, hipStream_t st, bool persist) {
     case EPI_GELU_GRAD: return launch_p8_one<EPI_GELU_GRAD>(p, st, persist);
     case EPI_GELU_DERIV: return launch_p8_one<EPI_GELU_DERIV>(p, st, persist);
     case EPI_MUL: return launch_p8_one<EPI_MUL>(p, st, persist);
-    case EPI_DROPRES: return launch_p8_one<EPI_DROPRES>(p, st, persist);
     default: return -1;
   }
 }
@@ -1447,7 +1420,7 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   p.M = M; p.N = N; p.K = K; p.ksplit = ksplit; p.bias = bias; p.div_ptr = div_ptr; p.alpha = alpha;
   p.R = (const bf16*)R; p.ldr = ldr; p.G = (const bf16*)G; p.ldg = ldg; p.C = C; p.ldc = ldc;
   p.C2 = (bf16*)C2; p.ldc2 = ldc2; p.colsum = colsum;
-  p.seed_ptr = nullptr; p.salt = 0; p.drop_thresh16 = 0; p.drop_scale = 1.f; p.M_ptr = nullptr;
+  p.M_ptr = nullptr;
   // tile order (tile_of): K <= 1024 -> 2 (blocks of 8 row panels x up to 4 column tiles per XCD), longer K -> 0 (row-major).  Measured in
   // the cache state the step presents (a 256-MiB memset between launches, tools/gemm_bench sustain GEMM_BENCH_BETWEEN=1): 84256x2304x768
   // 1 072 TF/s with order 2 against 960 with the column-group order 3 used before (which had the lowest counter traffic with warm
@@ -1483,35 +1456,5 @@ extern "C" int spmm_gemm_nt(const void* A, long lda, const void* W, long ldw, in
   if (rc > 0) return rc;
   if (rc < 0) { spmm_set_error("spmm_gemm_nt: epilogue %d is not built for kernel %d", epi, k); return SPMM_ERR_UNSUPPORTED; }
   SPMM_LAUNCH_CHECK("spmm_gemm_nt");
-  return SPMM_OK;
-}
-
-// ---- the output projections in front of a residual LayerNorm: C = dropout(bf16(A W^T + bias)) + R in the 8-phase kernel's epilogue
-// (BertSelfOutput / BertOutput, xbert.py:370-372, 448-450, up to the LayerNorm itself), so that spmm_ln_fwd reads ONE tensor.
-// The mask is the one spmm_ln_fwd / spmm_ln_bwd draw for the same (seed, salt): the existing backward serves it unchanged.
-extern "C" int spmm_gemm_nt_drop_ok(int M, int N, int K) {
-  return (M >= 6000 && pick_tile(M, N, EPI_BF16) == 3 && K % 128 == 0 && N % 8 == 0) ? 1 : 0;
-}
-extern "C" int spmm_gemm_nt_drop(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, const void* R,
-                                 long ldr, void* C, long ldc, float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int kernel,
-                                 const int* M_dev, hipStream_t stream) {
-  SPMM_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0, "spmm_gemm_nt_drop: M=%d N=%d K=%d (K %% 128 == 0, N %% 8 == 0)", M, N, K);
-  SPMM_CHECK_SHAPE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0 && R != nullptr, "spmm_gemm_nt_drop: rows must be multiples of 8 elements and R is required");
-  SPMM_CHECK_SHAPE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)R % 16 == 0), "spmm_gemm_nt_drop: operands must be 16-B aligned");
-  SPMM_CHECK_SHAPE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || seed_ptr != nullptr), "spmm_gemm_nt_drop: dropout %g needs a device seed", dropout_p);
-  SPMM_CHECK_SHAPE(kernel == SPMM_GEMM_AUTO || kernel == SPMM_GEMM_AUTO_TILES || kernel == 8 || kernel == 9, "spmm_gemm_nt_drop: runs on the 8-phase kernel only");
-  GemmP p;
-  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw;
-  p.M = M; p.N = N; p.K = K; p.ksplit = K; p.bias = bias; p.div_ptr = nullptr; p.alpha = 1.f;
-  p.R = (const bf16*)R; p.ldr = ldr; p.G = nullptr; p.ldg = 0; p.C = C; p.ldc = ldc;
-  p.C2 = nullptr; p.ldc2 = 0; p.colsum = nullptr;
-  p.order = K > 1024 ? 0 : 2;
-  p.seed_ptr = seed_ptr; p.salt = salt; p.drop_thresh16 = (uint32_t)(dropout_p * 65536.f + 0.5f); p.drop_scale = 1.f / (1.f - dropout_p);
-  p.M_ptr = M_dev;
-  SPMM_CHECK_SHAPE(p8_ok(p, EPI_DROPRES), "spmm_gemm_nt_drop: operands must be < 4 GiB");
-  int rc = (p.drop_thresh16 == 0) ? launch_p8(EPI_BF16, p, stream, !(kernel == SPMM_GEMM_AUTO_TILES || kernel == 9))
-                                  : launch_p8(EPI_DROPRES, p, stream, !(kernel == SPMM_GEMM_AUTO_TILES || kernel == 9));
-  if (rc > 0) return rc;
-  SPMM_LAUNCH_CHECK("spmm_gemm_nt_drop");
   return SPMM_OK;
 }

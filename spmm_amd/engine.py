@@ -323,19 +323,14 @@ class Engine:
         return y32
 
     def _proj_ln(self, A, Wb, bias, resid, X32, gamma, beta, *, save, eps, ph):
-        """y = LayerNorm(dropout(A W^T + b) + resid): BertSelfOutput / BertOutput (xbert.py:369-373, 447-451).
-        Where the projection runs on the 8-phase kernel, dropout and residual sit in ITS epilogue (spmm_gemm_nt_drop) and the LayerNorm
-        reads one tensor -- the pre-norm sum z it would otherwise have written itself; elsewhere (small M, fp32 residual stream) the
-        two-launch form.  Same dropout mask either way: spmm_ln_bwd regenerates it from (seed, salt).  -> (y, z, mean, rstd, salt, y32)"""
+        """y = LayerNorm(dropout(A W^T + b) + resid): BertSelfOutput / BertOutput (xbert.py:369-373, 447-451): the projection GEMM, then
+        dropout + residual + LayerNorm in one row kernel (the pre-norm sum z is formed in fp32 registers; its bf16 copy is kept for the
+        backward, which regenerates the dropout mask from (seed, salt)).  -> (y, z, mean, rstd, salt, y32)"""
         M, H = A.shape[0], Wb.shape[0]
         x, y = self._new(M, H), self._new(M, H)
         mean = self._new(M, dtype=torch.float32) if save else None
         rstd = self._new(M, dtype=torch.float32) if save else None
         salt = self._next_salt()
-        if X32 is None and self.opt.fuse_drop_res and ops.gemm_nt_drop_ok(M, H, A.shape[1]):
-            ops.gemm_nt_drop(A, Wb, x, bias=bias, R=resid, dropout_p=ph, seed=self.seed, salt=salt, M_dev=self._md(A))
-            ops.ln_fwd(x, None, gamma, beta, y, mean=mean, rstd=rstd, eps=eps, rows_dev=self._md(A))
-            return y, x, mean, rstd, salt, None
         ops.gemm_nt(A, Wb, x, bias=bias, M_dev=self._md(A))
         y32 = self._ln_res(x, resid, X32, gamma, beta, y, zout=x if save else None, mean=mean, rstd=rstd, eps=eps, dropout_p=ph, seed=self.seed, salt=salt)
         return y, x, mean, rstd, salt, y32
@@ -381,7 +376,8 @@ class Engine:
             bkv = P.fused(pfx + ".self.", ("key", "value"), "bias", what="w")
             sv["Qc"], sv["KV"] = Qc, []
             shared = {}                                          # K/V of a shared source: projected once per layer
-            fused = self.opt.fused_xattn and X32 is None and self._md(X) is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
+            fx = self.opt.fused_xattn
+            fused = (fx is True or fx == "all" or (fx == "nograd" and not save)) and X32 is None and self._md(X) is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
             if fused:
                 # ONE launch per group for core + output projection + dropout + residual + LayerNorm (csrc/xattn.hip); the salts are
                 # drawn in the composite's order (every group's attention salt, then the hidden one): both forms draw the same masks

@@ -100,22 +100,6 @@ def gemm_nt(A, W, C, *, bias=None, epi=EPI_BF16, R=None, G=None, C2=None, alpha=
     return C
 
 
-def gemm_nt_drop_ok(M, N, K):
-    """True where `gemm_nt_drop` serves the shape (the shapes the automatic choice gives to the 8-phase kernel anyway)."""
-    return bool(M >= 6000 and K % 128 == 0 and N % 8 == 0) if _DRY_RUN else bool(lib().cdll.spmm_gemm_nt_drop_ok(int(M), int(N), int(K)))
-
-
-def gemm_nt_drop(A, W, C, *, bias, R, dropout_p=0.0, seed=None, salt=0, M_dev=None):
-    """C = dropout(bf16(A @ W^T + bias)) + R in the GEMM's epilogue (the projection in front of a residual LayerNorm: ln_fwd then reads C
-    alone); the mask is the one ln_fwd / ln_bwd draw for the same (seed, salt)."""
-    M, K = A.shape
-    N = W.shape[0]
-    assert A.dtype == BF16 and W.dtype == BF16 and C.dtype == BF16 and R.dtype == BF16 and W.shape[1] >= K and tuple(C.shape) == (M, N) and tuple(R.shape) == (M, N)
-    _call("spmm_gemm_nt_drop", _p(A), _row_stride(A), _p(W), _row_stride(W), M, N, K, _p(bias), _p(R), _row_stride(R), _p(C), _row_stride(C),
-          float(dropout_p), _p(seed), salt, int(_nt_auto), _p(M_dev), _st())
-    return C
-
-
 def gemm_tn(A, B, C, *, alpha=1.0, splits=None, kernel=0, M_dev=None):
     """C[N,K] (fp32) += alpha * A[M,N]^T @ B[M,K]  -- weight gradients straight from token-major activations.
     kernel: 0 = chosen from the shape, 1 = 128x128 tiles, 8 = 256x256 8-phase (N, K multiples of 8)."""

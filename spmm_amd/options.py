@@ -14,12 +14,11 @@ from dataclasses import dataclass
 _ENV = {
     "pack_text": ("SPMM_PACK_TEXT", lambda s: s != "0"),
     "cls_only_top": ("SPMM_CLS_ONLY_TOP", lambda s: s != "0"),
-    "fuse_drop_res": ("SPMM_FUSE_DROP_RES", lambda s: s == "1"),
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
     "pv_wgrad_inline": ("SPMM_PV_WGRAD_INLINE", int),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
-    "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: s != "0"),
+    "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: {"0": "off", "1": "all"}.get(s, s)),
     "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
     "grad_wire": ("SPMM_GRAD_WIRE", str),
     "nt_under_comm": ("SPMM_NT_UNDER_COMM", str),
@@ -35,17 +34,15 @@ class EngineOptions:
     pack_text: bool = True        # drop padding-token rows from the text passes whose losses read only position 0
     cls_only_top: bool = True     # last fusion layer of the ITM passes on position 0 only (what the ITM head reads, SPMM_models.py:199-201); their other
     #                               rows stay keys / values of its self-attention.  Packed path only; exact
-    fuse_drop_res: bool = False   # hidden dropout + residual of BertSelfOutput / BertOutput inside the projection GEMM's epilogue (spmm_gemm_nt_drop):
-    #                               the LayerNorm behind it reads one tensor instead of two (LayerNorm forward 2.4 -> 1.4 ms per step, the
-    #                               step 54.6 -> 54.3 ms).  OFF: the LayerNorm then starts from the bf16-ROUNDED pre-norm sum, one more rounding
-    #                               per sublayer on the residual stream -- loss_itm deviates 2.6e-3 from the fp32 oracle at the benchmark shape
-    #                               instead of 1.3e-3, loss_ita 4.8e-3 instead of 3.6e-3 (EXPERIMENTS.md 3.4)
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
     pv_wgrad_inline: int = 3      # ... except those of the PV encoder's first `n` layers (the LAST its backward reaches), which stay on that chain's
     #                               own stream: it ends ~2 ms before the text encoder's on the side stream, and the one weight-gradient stream,
     #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10)
-    fused_xattn: bool = False     # cross-attention forward as ONE row-panel kernel (core + output projection + residual LayerNorm)
+    fused_xattn: str = "nograd"   # cross-attention block forward as ONE row-panel launch (csrc/xattn.hip: core + output projection + dropout + residual +
+    #                               LayerNorm): "nograd" = the passes that keep no tape (momentum fusion pass, inference facades) -- 52.88 vs 53.01 ms
+    #                               per step in three alternating pairs, profiles/r06_xattn_modes.txt; "all" = the taped passes too (53.00: no gain
+    #                               there, the tape's extra outputs cost what the fusion saves); "off" = the composite of launches everywhere
     # --- precision (NOT the headline configuration) ---
     resid_fp32: bool = False      # fp32 residual stream through the LayerNorms and fp32 inputs to the loss heads
     # --- data parallelism (spmm_amd/parallel.py) ---
@@ -69,6 +66,10 @@ class EngineOptions:
                 kw[field] = parse(os.environ[var])
         kw.update(overrides)
         o = cls(**kw)
+        if isinstance(o.fused_xattn, bool):
+            o.fused_xattn = "all" if o.fused_xattn else "off"
+        if o.fused_xattn not in ("off", "nograd", "all"):
+            raise ValueError(f"fused_xattn must be off, nograd or all, not {o.fused_xattn!r}")
         if o.grad_wire not in ("fp32", "bf16"):
             raise ValueError(f"grad_wire must be fp32 or bf16, not {o.grad_wire!r}")
         if o.nt_under_comm not in ("tiles", "persistent"):

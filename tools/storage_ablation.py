@@ -35,7 +35,7 @@ def main():
             if kw.get("fp32"):
                 out = O.spmm_forward({k: v.clone() for k, v in sd.items()}, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)
             else:
-                with O.bf16_storage(only=kw.get("only")):
+                with O.bf16_storage(only=kw.get("only"), weights=kw.get("weights")):
                     out = O.spmm_forward({k: v.clone() for k, v in sd.items()}, ocfg, prop, ids, mask, 0.4, mpm_mask=mpm, neg_idx=neg)
         return np.array([float(x) for x in out]), time.time() - t0
 
@@ -51,6 +51,16 @@ def main():
     for label, only in rows:
         got, _ = run(only=only)
         print(f"{label:48s} " + "  ".join(f"{abs(g - r):11.2e}" for g, r in zip(got, ref)), flush=True)
+    # the weight shadows alone, by weight group (regex on the Linear's parameter prefix)
+    groups = {"property_encoder(_m)": r"^property_encoder", "text layers 0-5 (+_m)": r"^text_encoder(_m)?\.bert\.encoder\.layer\.[0-5]\.",
+              "text fusion layers 6-11 (+_m)": r"^text_encoder(_m)?\.bert\.encoder\.layer\.(6|7|8|9|10|11)\.",
+              "fusion: self-attention": r"layer\.(6|7|8|9|10|11)\.attention\.", "fusion: cross-attention": r"crossattention",
+              "fusion: FFN": r"layer\.(6|7|8|9|10|11)\.(intermediate|output)\.dense", "heads (cls / mtr / proj / itm)": r"^(?!.*encoder\.layer)",
+              "student only (no _m)": r"^(property_encoder|text_encoder)\.", "momentum only": r"_m\."}
+    print("\nbf16 rounding of the WEIGHT shadows only, by weight group:")
+    for label, rx in groups.items():
+        got, _ = run(only={"weights"}, weights=rx)
+        print(f"ONLY weights of {label:32s} " + "  ".join(f"{abs(g - r):11.2e}" for g, r in zip(got, ref)), flush=True)
 
 
 if __name__ == "__main__":
