@@ -51,6 +51,18 @@ def wrap_any(name):             # PHASES_DETAIL=1: single layers outside the sta
 if os.environ.get("PHASES_DETAIL") == "1":
     for n_ in ("_layer_fwd", "_layer_bwd", "lm_head_fwd", "lm_head_bwd", "_s6_forward_cls", "_s6_backward_cls", "_banks"):
         wrap_any(n_)
+if os.environ.get("PHASES_BOUNDARY") == "1":      # the step's head and tail: plan kernels, embeddings, whole forward / backward, joins, optimiser
+    for n_ in ("_pack_plan", "embed_text", "embed_pv", "forward", "backward", "wgrad_join", "_embed_ln_bwd"):
+        wrap_any(n_)
+    _o = model.optimizers()
+    _orig_step = _o.step
+    def _step(*a, **k):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); r = _orig_step(*a, **k); e1.record(st)
+        log.append(("optimiser step (sqnorm, AdamW, forward-side shadows; off-path launches excluded)", st.stream_id, e0, e1))
+        return r
+    _o.step = _step
 opt = model.optimizer if hasattr(model, "optimizer") else None
 marks = []
 for i in range(steps):

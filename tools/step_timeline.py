@@ -33,7 +33,14 @@ for q in qs:
             busy[b] += max(0.0, min(e, be) - max(s, bs)) / 1e6 / binms
     line = "".join("." if x < 0.05 else str(min(9, int(x * 10))) for x in busy)
     print(f"queue {q:>3}: busy {tot:6.2f} ms  {line}")
-print("last 1.5 ms of the step:")
+tail_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 1.5
+head_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+print(f"last {tail_ms:g} ms of the step (times relative to the end of this step's AdamW kernel):")
 for s, e, n, q in rows:
-    if e > hi - 1.5e6:
+    if e > hi - tail_ms * 1e6:
         print(f"   queue {q:>3}  {(s - hi) / 1e3:9.1f} .. {(e - hi) / 1e3:8.1f} us   {short(n)}")
+if head_ms > 0:
+    print(f"first {head_ms:g} ms of the step (times relative to the end of the previous step's AdamW kernel):")
+    for s, e, n, q in rows:
+        if s < lo + head_ms * 1e6:
+            print(f"   queue {q:>3}  {(s - lo) / 1e3:9.1f} .. {(e - lo) / 1e3:8.1f} us   {short(n)}")
