@@ -714,7 +714,7 @@ def main():
             roof["peak_at_clock"] = round(PEAK_BF16_TFLOPS * clk1["clock_mhz"] / 2400.0, 1)
             roof["frac_at_clock"] = round(ach / (PEAK_BF16_TFLOPS * clk1["clock_mhz"] / 2400.0), 4)
             roof["clock_note"] = (f"mean of {clk1['samples']} samples ({clk1['source']}) over 10 un-instrumented single-stream steps; "
-                                  "per kernel family: profiles/r05_power.txt")
+                                  "per kernel family: profiles/r06_power.txt")
         else:
             roof["clock_mhz"] = None
             roof["clock_note"] = f"no clock source on this box: {clk1}"
@@ -730,7 +730,7 @@ def main():
         # HBM-side traffic of the same launches comes from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary is quoted only when it was taken on this exact workload.
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pmc_path = next((os.path.join(pdir, f) for f in ("r05_pmc_nt_gemm.json", "r04_pmc_nt_gemm.json", "r03_pmc_nt_gemm.json", "r02_pmc_nt_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
+        pmc_path = next((os.path.join(pdir, f) for f in ("r06_pmc_nt_gemm.json", "r05_pmc_nt_gemm.json", "r04_pmc_nt_gemm.json", "r03_pmc_nt_gemm.json", "r02_pmc_nt_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
         if pmc_path:
             pmc = json.load(open(pmc_path))
             if pmc["workload"] == {"batch": B, "seq_len": Lt, "layers": nt, "queue": args.queue}:

@@ -212,3 +212,30 @@ def test_wordpiece_tokenizer_matches_reference_golden(golden_dir):
     assert ids[0, 0].item() == tok.cls_token_id
     assert tok.decode(ids[0].tolist()) == str(g["smiles"][0])
     assert tok.decode(ids[4].tolist()) == "CCO"
+
+
+def test_engine_options_from_env_and_overrides(monkeypatch):
+    """EngineOptions.from_env: environment variables are read once, explicit overrides win, and every enumerated field rejects what it does not
+    know -- incl. the legacy 0 / 1 and boolean spellings of `fused_xattn` (rounds 3-5) and the fields removed in round 6."""
+    from spmm_amd.options import EngineOptions, _ENV
+    for var, _ in _ENV.values():
+        monkeypatch.delenv(var, raising=False)
+    o = EngineOptions.from_env()
+    assert o.fused_xattn == "nograd" and o.grad_wire == "fp32" and o.nt_under_comm == "tiles" and o.pack_text and not o.resid_fp32
+    assert not hasattr(o, "fp8") and not hasattr(o, "fuse_drop_res")
+    for spelled, want in (("0", "off"), ("1", "all"), ("off", "off"), ("nograd", "nograd"), ("all", "all")):
+        monkeypatch.setenv("SPMM_FUSED_XATTN", spelled)
+        assert EngineOptions.from_env().fused_xattn == want
+    assert EngineOptions.from_env(fused_xattn=True).fused_xattn == "all" and EngineOptions.from_env(fused_xattn=False).fused_xattn == "off"
+    monkeypatch.setenv("SPMM_FUSED_XATTN", "sometimes")
+    with pytest.raises(ValueError):
+        EngineOptions.from_env()
+    monkeypatch.delenv("SPMM_FUSED_XATTN")
+    monkeypatch.setenv("SPMM_GRAD_WIRE", "fp16")
+    with pytest.raises(ValueError):
+        EngineOptions.from_env()
+    monkeypatch.setenv("SPMM_GRAD_WIRE", "bf16")
+    monkeypatch.setenv("SPMM_STREAMS", "1")
+    o = EngineOptions.from_env(grad_overlap=False)
+    assert o.grad_wire == "bf16" and not o.multi_stream and not o.grad_overlap
+    assert o.replace(grad_wire="fp32").grad_wire == "fp32" and o.grad_wire == "bf16"
