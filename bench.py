@@ -46,11 +46,13 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBS = 8000.0
 
 
-def smi_sampler(period_s=0.05):
-    """Shader clock / socket power sampler (tools/smi_sampler.py: amdsmi, then rocm-smi; read-only).  Measurement plumbing only."""
+def smi_sampler(period_s=0.05, in_process_only=False):
+    """Shader clock / socket power sampler (tools/smi_sampler.py: amdsmi, then rocm-smi; read-only).  Measurement plumbing only.
+    Inside the headline timed region only the in-process amdsmi reader is allowed (a rocm-smi subprocess every 50 ms would perturb the
+    host-enqueue-bound step it annotates); the device index goes through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from smi_sampler import Sampler
-    return Sampler(period_s=period_s, index=int(os.environ.get("LOCAL_RANK", "0")))
+    return Sampler(period_s=period_s, index=int(os.environ.get("LOCAL_RANK", "0")), in_process_only=in_process_only)
 
 
 def synthetic_batch(B, Lt, seed, device):
@@ -476,7 +478,7 @@ def main():
         opt_.step = step_probe
     if hasattr(sync, "wait_events"):
         sync.wait_events = []             # event pair around the compute stream's wait in OverlappedGradSync.finish(), one per timed step
-    smp = smi_sampler() if rank == 0 else None       # clock / power of GPU 0 over the timed region (a 20-Hz reader thread on the host)
+    smp = smi_sampler(in_process_only=True) if rank == 0 else None       # clock / power of this rank's GPU over the timed region (a 20-Hz in-process reader thread)
     if smp is not None:
         smp.__enter__()
     t0 = time.perf_counter()

@@ -72,10 +72,25 @@ class _RocmSmi:
         return {"source": "rocm-smi --showclocks --showpower --json"}
 
 
-def open_source(index=0):
-    """-> (reader, name) or (None, reason)."""
+def physical_index(local_index=0):
+    """Index of the GPU the process calls device `local_index`, after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (integer lists only)."""
+    import os
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                ids = [int(x) for x in v.split(",") if x.strip() != ""]
+                return ids[local_index] if local_index < len(ids) else local_index
+            except ValueError:
+                return local_index
+    return local_index
+
+
+def open_source(index=0, in_process_only=False):
+    """-> (reader, name) or (None, reason).  in_process_only: no subprocess-based reader (forking `rocm-smi` every period from a process
+    that enqueues a host-bound step perturbs what it annotates)."""
     errs = []
-    for cls in (_AmdSmi, _RocmSmi):
+    for cls in ((_AmdSmi,) if in_process_only else (_AmdSmi, _RocmSmi)):
         try:
             return cls(index), cls.__name__.strip("_").lower()
         except Exception as e:   # noqa: BLE001
@@ -87,9 +102,9 @@ class Sampler:
     """with Sampler() as s: <timed region>;  s.summary() -> {'clock_mhz': mean, 'power_w': mean, 'samples': n, 'source': ...} or
     {'source': None, 'error': ...} when the box exposes nothing."""
 
-    def __init__(self, period_s=0.02, index=0):
+    def __init__(self, period_s=0.02, index=0, in_process_only=False):
         self.period, self.src, self.name = period_s, None, None
-        self.src, self.name = open_source(index)
+        self.src, self.name = open_source(physical_index(index), in_process_only=in_process_only)
         self.rows, self._stop, self._t = [], threading.Event(), None
 
     def __enter__(self):
