@@ -284,6 +284,15 @@ def decode_bench(args):
                        "avg_launch_us": round(tms * 1e3 / len(ev), 2), "algorithmic_bytes_per_launch": round(nbytes / len(ev)),
                        "bytes_per_launch_if_every_beam_row_read_its_own_prefix": round(nbytes_rows / len(ev)),
                        "measured": "HIP events around every decode_attn launch of one eager chunk (event-pair overhead ~2 us included)"}
+    # HBM-side traffic of the same kernel from separate rocprofv3 --pmc passes (tools/pmc_decode.sh), quoted when taken on this workload
+    pdir = os.path.join(ROOT, "profiles")
+    ppath = next((os.path.join(pdir, f) for f in ("r06_pmc_decode_attn.json",) if os.path.exists(os.path.join(pdir, f))), "")
+    if ppath:
+        pmc = json.load(open(ppath))
+        if pmc["workload"] == {"molecules": args.molecules, "beams": k, "positions": T, "chunk": args.chunk}:
+            out["roofline"]["traffic"] = round(pmc["traffic_bytes_per_launch"])
+            out["roofline"]["traffic_note"] = (f"bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{os.path.basename(ppath)} (L2<->fabric requests, "
+                                               "Infinity-Cache hits included; average over self- and cross-attention launches of all chunks)")
     npos = T + 1
     out["position_breakdown_ms"] = {"note": "one eager single-stream chunk, HIP events around every launch of the three kernel families (event-pair overhead included); "
                                             "rest = the beam bookkeeping launch (spmm_beam_step), embedding, LM head tail, launch gaps and the event pairs themselves (the cache update is part of decode_attn since round 5)",
