@@ -1,6 +1,6 @@
 """Wall-clock / timeline properties of the step on a real MI355X.  They sort LAST (test_zz_*) so that a timing assertion can never
-hide a parity test under `pytest -x`; every threshold is derived from a calibration made inside the test, and a failed attempt is
-repeated (up to three attempts) in a FRESH child process (stream -> hardware-queue placement and clocks differ from process to process)."""
+hide a parity test under `pytest -x`; every threshold is derived from a calibration made inside the test, and each test runs ONCE, in a
+FRESH child process (stream -> hardware-queue placement and clocks differ from process to process; round 6: single attempt)."""
 import json
 import os
 import socket
@@ -19,9 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _in_fresh_child(test_name, attempts=1, **env):
-    """Runs `test_name` of this file in a fresh process (GPU_MAX_HW_QUEUES=8 like bench.py / pretrain.py); a failed attempt is
-    repeated (stream -> hardware-queue placement is drawn per process: round 4 saw one full-suite run in eight lose two attempts in a
-    row) and its output kept in gpurun_out/timing_failures.txt.  Returns the captured output of the passing attempt."""
+    """Runs `test_name` of this file in a fresh process (GPU_MAX_HW_QUEUES=8 like bench.py / pretrain.py), once (`attempts` exists for
+    local diagnosis only); a failure's output is kept in gpurun_out/timing_failures.txt.  Returns the captured output of the passing run."""
     last = None
     for a in range(attempts):
         out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", os.path.abspath(__file__) + "::" + test_name],
@@ -94,10 +93,8 @@ def test_gradient_exchange_overlaps_backward(env, monkeypatch):
 
     def slow_all_reduce(t, op=None, async_op=False):
         # The stand-in owns BOTH timestamps of a slice: `issue` on the stream the product issues the collective from (behind the last
-        # writer of the slice), `done` on its own stream.  Nothing else waits for `done` before finish(): round 5's version let the
-        # product park an "observer" stream behind every collective to take that timestamp, and whenever HIP placed the observer on the
-        # hardware queue of the stream running the backward, the next layer's kernels queued behind the observer's wait packet -- the
-        # test then saw "next issue 0.5-0.9 ms AFTER done" (GPUTEST_r05: 3/3 fresh processes) for a product that overlaps fine.
+        # writer of the slice), `done` on its own stream.  Nothing else waits for `done` before finish() (rounds 3-5 let the product park an
+        # "observer" stream behind every collective to take that timestamp; it is gone -- and it was not what made GPUTEST_r05 red, see below).
         assert async_op
         issued_from.append(torch.cuda.current_stream().cuda_stream)
         host_t.append(time.perf_counter())
