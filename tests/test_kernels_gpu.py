@@ -318,6 +318,38 @@ def test_attention_backward(ops, nseq, nH, Lq, Lkv, causal_from, is_cross):
         close(got, ref2, 3e-2 * max(1.0, ref2.abs().max().item() / 8), 2e-2, nm)
 
 
+def test_attention_backward_dk_dv_across_two_query_chunks(ops):
+    """128 < Lq <= 256: the backward runs one launch per 128-query chunk and the second chunk ADDS its dK / dV to the first one's bf16
+    result (csrc/attention.hip, spmm_attn_bwd) -- one more bf16 rounding than the single-chunk form.  Held tight here: the whole-tensor
+    relative L2 error of dK and dV against fp32 autograd at Lq = Lkv = 256 must stay within a rounding or two of bf16 (2^-9 / sqrt 3 =
+    1.1e-3 per rounding) and within 1.6 x the single-chunk error at Lq = 128 on the same keys.  Measured: dK 2.85e-3 -> 3.37e-3, dV 2.33e-3 ->
+    2.94e-3 (dQ 2.90e-3 both): the extra rounding costs 18-26 %, bound 4e-3."""
+    nseq, nH, Lkv = 6, 4, 256
+    H = nH * 64
+    err = {}
+    for Lq in (128, 256):
+        qkv, kv, mask = _attn_inputs(nseq, nH, Lq, Lkv, seed=77)
+        Q, K, V = qkv[:, :H], kv[:, :H], kv[:, H:]
+        dO = rnd(nseq * Lq, H, seed=78)
+        O = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+        lse = torch.zeros(nseq, nH, Lq, device="cuda")
+        ops.attn_fwd(Q, K, V, O, lse, nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, is_cross=True)
+        dQ = torch.zeros(nseq * Lq, H, dtype=BF, device="cuda")
+        dKV = torch.zeros(nseq * Lkv, 2 * H, dtype=BF, device="cuda")
+        ops.attn_bwd(Q, K, V, O, lse, dO, dQ, dKV[:, :H], dKV[:, H:], nseq=nseq, nH=nH, Lq=Lq, Lkv=Lkv, kmask=mask, is_cross=True)
+        q = Q.float().reshape(nseq, Lq, H).requires_grad_(True)
+        k = K.float().reshape(nseq, Lkv, H).requires_grad_(True)
+        v = V.float().reshape(nseq, Lkv, H).requires_grad_(True)
+        ro, _ = ref_attention(q, k, v, mask, nH, nseq, True)
+        ro.backward(dO.float().view(nseq, Lq, H))
+        rel = lambda got, ref: ((got.float() - ref.reshape(got.shape)).norm() / ref.norm()).item()
+        err[Lq] = (rel(dKV[:, :H], k.grad), rel(dKV[:, H:], v.grad), rel(dQ, q.grad))
+        print(f"Lq={Lq}: relative L2 error dK {err[Lq][0]:.2e} dV {err[Lq][1]:.2e} dQ {err[Lq][2]:.2e}")
+    for i, nm in enumerate(("dK", "dV")):
+        assert err[256][i] < 4e-3, (nm, err)
+        assert err[256][i] < 1.6 * err[128][i] + 2e-4, (nm, err)
+
+
 @pytest.mark.parametrize("nseq,U,nH,Lq,Lkv", [(8, 3, 2, 54, 128), (8, 2, 12, 128, 54), (5, 5, 2, 40, 40)])
 def test_cross_attention_with_shared_kv_sources(ops, nseq, U, nH, Lq, Lkv):
     """kv_seq: query sequence s reads K/V of source kv_seq[s].  Outputs and dQ equal the kernel run on physically gathered
