@@ -377,7 +377,7 @@ class Engine:
             sv["Qc"], sv["KV"] = Qc, []
             shared = {}                                          # K/V of a shared source: projected once per layer
             fx = self.opt.fused_xattn
-            fused = (fx is True or fx == "all" or (fx == "nograd" and not save)) and X32 is None and self._md(X) is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
+            fused = (fx is True or fx == "all" or (fx == "nograd" and not save)) and not getattr(self, "_xattn_off", False) and X32 is None and self._md(X) is None and all(ops.xattn_supported(H, nH, g.L, g.Lkv) for g in groups)
             if fused:
                 # ONE launch per group for core + output projection + dropout + residual + LayerNorm (csrc/xattn.hip); the salts are
                 # drawn in the composite's order (every group's attention salt, then the hidden one): both forms draw the same masks
@@ -423,9 +423,16 @@ class Engine:
                         ops.ln_fwd(x2, X[r], P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), y2,
                                    eps=c.layer_norm_eps, dropout_p=ph, seed=self.seed, salt=salt_h)
                         d = (y[r].float() - y2.float()).abs()
-                        if not (float(d.max()) < 0.25 and float(d.mean()) < 5e-3):      # (bf16 roundings of x differ: ~1e-3 on average)
-                            raise RuntimeError(f"fused cross-attention kernel disagrees with the composite launches: max |dy| {float(d.max()):.3g}, "
-                                               f"mean {float(d.mean()):.3g} -- set SPMM_FUSED_XATTN=0")
+                        scale = max(1.0, float(y2.float().abs().max()) / 8.0)              # (outlier channels of a trained model scale the roundings)
+                        if not (float(d.max()) < 0.25 * scale and float(d.mean()) < 5e-3 * scale):      # (bf16 roundings of x differ: ~1e-3 on average)
+                            # Not fatal: the composite of launches is always available.  This process stops using the one-launch form and
+                            # says so (a default path must not be able to end a run; the kernel's own parity tests compare it directly).
+                            import warnings
+                            warnings.warn(f"spmm_amd: the fused cross-attention kernel disagrees with the composite launches (max |dy| {float(d.max()):.3g}, "
+                                          f"mean {float(d.mean()):.3g}); falling back to the composite for this process (SPMM_FUSED_XATTN=off)")
+                            streams.note("fused cross-attention kernel failed its one-time self-check: composite launches used instead")
+                            self._xattn_off = True
+                            return self._attn_block_fwd(pfx, c, X, groups, save, cross, X32=X32)
                 else:
                     salt = self._next_salt()
                     self._attn_fwd(Qc[r], KV[:, :H], KV[:, H:], ctx[r], lse, nseq=g.nseq, nH=nH, Lq=g.L, Lkv=g.Lkv, is_cross=True,

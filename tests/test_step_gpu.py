@@ -178,6 +178,47 @@ def test_forward_matches_oracle_h768(env):
         assert err < tol, key
 
 
+def test_fused_cross_attention_self_check_falls_back_to_the_composite(env, monkeypatch):
+    """The one-launch cross-attention block is in the DEFAULT path (the passes that keep no tape) and is checked once per process against
+    the composite of launches on the first block it serves.  A kernel that disagrees must not end the run: the engine warns, stops using it
+    for the process and the forward's results are the composite's.  Here the kernel is made to disagree (its output zeroed)."""
+    O, SPMM, *_ = env
+    from spmm_amd import ops
+    from spmm_amd.options import EngineOptions
+    cfg, ocfg = _mid_cfg(env)
+    sd = O.init_state_dict(ocfg, seed=3)
+    B, Lt = 8, 48
+    prop, ids, mask = O.synthetic_batch(B, Lt, seed=21)
+    mpm = torch.bernoulli(torch.full((B, 53), 0.5), generator=torch.Generator().manual_seed(1))
+    neg = (torch.arange(B).roll(1), torch.arange(B).roll(2))
+    out, calls = {}, []
+    orig = ops.xattn_fwd
+
+    def broken(Q, K, V, WoF, bo, R, gamma, beta, Y, **kw):
+        calls.append(1)
+        r = orig(Q, K, V, WoF, bo, R, gamma, beta, Y, **kw)
+        Y.zero_()
+        return r
+
+    for mode in ("off", "broken"):
+        m = SPMM(config=None, spmm_config=cfg, options=EngineOptions.from_env(fused_xattn="off" if mode == "off" else "nograd"))
+        m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+        m.eval()
+        if mode == "broken":
+            monkeypatch.setattr(ops, "xattn_fwd", broken)
+        with torch.no_grad():
+            if mode == "broken":
+                with pytest.warns(UserWarning, match="falling back to the composite"):
+                    out[mode] = np.array([float(x) for x in m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))])
+                n_first = len(calls)
+                m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))          # a second forward: the kernel stays unused
+                assert len(calls) == n_first == 1 and m.engine._xattn_off
+            else:
+                out[mode] = np.array([float(x) for x in m(prop, ids, mask, alpha=0.4, mpm_mask=mpm.cuda(), neg_idx=tuple(_cuda(*neg)))])
+    print("composite", out["off"], "after the fallback", out["broken"])
+    np.testing.assert_allclose(out["broken"], out["off"], rtol=1e-5, atol=1e-6)       # (eval mode: no dropout, the composite is deterministic but for atomic sums)
+
+
 def test_fused_cross_attention_inside_the_step(env):
     """EngineOptions.fused_xattn: the cross-attention blocks of every fusion layer as ONE launch each (csrc/xattn.hip) inside the real
     step -- H=768, 2+2 layers, packed text rows, shared K/V sources, train mode with dropout.  Both forms draw the same dropout
