@@ -150,10 +150,13 @@ int spmm_ln_fwd_r32(const void* x, const float* res32, const float* gamma, const
                     uint64_t salt, spmm_stream_t stream);
 /* dz = dLN(dy + dy2); dx = dropout-mask(dz) when drop_on_dy == 0; drop_on_dy == 1 masks dy instead (embeddings);
  * dgamma/dbeta accumulate with atomics (may be null for frozen parameters); dxsum (optional) += column sums of dx,
- * i.e. the bias gradient of the dense layer whose output was normalised. */
+ * i.e. the bias gradient of the dense layer whose output was normalised.
+ * beta_from_y (optional, [H]): `z` then holds the LayerNorm's OUTPUT y (what spmm_ln_fwd wrote, no dropout behind it) and the normalised
+ * values are recovered as (y - beta) / gamma (0 where gamma == 0); `mean` may be null and spmm_ln_fwd need not keep its pre-norm sum. */
 int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd, const float* gamma,
                 void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H, float dropout_p,
-                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, const int* rows_dev, spmm_stream_t stream);
+                const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, const int* rows_dev,
+                const float* beta_from_y, spmm_stream_t stream);
 
 /* One decode step of BertEmbeddings.forward (xbert.py:193-220) at inference: y[r] = LN(word[ids[r]] + pos[pos_index] +
  * type[0]) for `rows` single-token rows (every beam is at the same position).  pos_ptr (optional) overrides pos_index

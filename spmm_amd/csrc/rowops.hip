@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16* __restrict__ 
 // NC = 8-byte chunks per lane (3 covers H <= 768, 4 covers H <= 1024).  The raw bf16 rows of the NEXT iteration are
 // requested before the current row is reduced, so the wave always has loads in flight (the kernel is pure HBM streaming:
 // 2-3 rows in, 1-2 rows out per row).
+#ifndef LN_BWD_FROMY_WGS
+#define LN_BWD_FROMY_WGS 3      // workgroups per CU the from-output variant is compiled for (4 spills 13 registers: 52 B of scratch per lane)
+#endif
 template <int NC>
 struct RawRow { bf16x4 v[NC]; };
 
@@ -277,10 +280,15 @@ __device__ __forceinline__ void load_raw(const bf16* __restrict__ p, int H, int 
 
 // EXACT: H == 256 * NC, no column guards.  HOT: the combination every encoder layer of a training step uses (one incoming
 // gradient, dropout on x, dx + dgamma + dbeta + dxsum all wanted) with the run-time switches folded away.
-template <int NC, bool EXACT, bool HOT>
-__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2,
+// FROMY (round 6): `z` holds the LayerNorm's OUTPUT y instead of its input, and the normalised value is recovered as (y - beta) / gamma
+// (a channel with gamma == 0 carries no information about it: xhat = 0 there).  The forward then need not store its pre-norm sum at all --
+// one 131-MB write per residual LayerNorm at the benchmark shape -- and y is alive anyway as the next GEMM's operand.  Numerically the same
+// as the z form for gamma of order 1 (both read one bf16-rounded tensor; EXPERIMENTS.md 4.8).
+template <int NC, bool EXACT, bool HOT, bool FROMY>
+__global__ __launch_bounds__(256, FROMY ? LN_BWD_FROMY_WGS : 4) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2,
                                                      const bf16* __restrict__ z, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
                                                      bf16* __restrict__ dz_o, bf16* __restrict__ dx_o,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H,
                                                      uint32_t thresh16, float dscale, const uint64_t* seed_ptr, uint64_t salt,
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
     load_raw<NC, EXACT>(dy + row * H, H, lane, ng);
     if (has2) load_raw<NC, EXACT>(dy2 + row * H, H, lane, ng2);
     load_raw<NC, EXACT>(z + row * H, H, lane, nz);
-    nmean = mean_i[row]; nrstd = rstd_i[row];
+    nmean = FROMY ? 0.f : mean_i[row]; nrstd = rstd_i[row];
   }
   for (; row < rows; row += stride) {
     RawRow<NC> cg = ng, cg2 = ng2, cz = nz;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
       load_raw<NC, EXACT>(dy + nrow * H, H, lane, ng);
       if (has2) load_raw<NC, EXACT>(dy2 + nrow * H, H, lane, ng2);
       load_raw<NC, EXACT>(z + nrow * H, H, lane, nz);
-      nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
+      nmean = FROMY ? 0.f : mean_i[nrow]; nrstd = rstd_i[nrow];
     }
     float g[NC][4], xh[NC][4];
     const uint32_t rowkey = drop ? drop_rowkey(seed, (uint64_t)row) : 0u;
@@ -340,20 +348,27 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
       const int c = (lane + 64 * i) * 4;
       if (EXACT || c < H) {
         const f32x4 gm = *(const f32x4*)(gamma + c);      // L1-resident; keeping it in registers costs occupancy
+        f32x4 bt = {0.f, 0.f, 0.f, 0.f}, ig = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FROMY) {
+          bt = *(const f32x4*)(beta + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ig[j] = gm[j] != 0.f ? __builtin_amdgcn_rcpf(gm[j]) : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float x = ((float)cz.v[i][j] - mean) * rstd;
+          const float x = FROMY ? ((float)cz.v[i][j] - bt[j]) * ig[j] : ((float)cz.v[i][j] - mean) * rstd;
           const float dg = g[i][j] * gm[j];
           gsum[i][j] += g[i][j] * x;
           bsum[i][j] += g[i][j];
-          xh[i][j] = x;
+          if constexpr (!FROMY) xh[i][j] = x;             // (FROMY recomputes it from the raw row below: 12 registers less across the reduction,
+                                                          //  which is what keeps this variant inside the 128-register bound without scratch)
           g[i][j] = dg;
           s1 += dg;
           s2 += dg * x;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { if constexpr (!FROMY) xh[i][j] = 0.f; g[i][j] = 0.f; }
       }
     }
     s1 = wave_sum_dpp(s1) / H;
@@ -364,8 +379,17 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
       const int c = (lane + 64 * i) * 4;
       if (EXACT || c < H) {
         float o[4];
+        if constexpr (FROMY) {
+          const f32x4 gm = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+          for (int j = 0; j < 4; ++j) {
+            const float x = ((float)cz.v[i][j] - bt[j]) * (gm[j] != 0.f ? __builtin_amdgcn_rcpf(gm[j]) : 0.f);
+            o[j] = rstd * (g[i][j] - s1 - x * s2);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        }
         const bf16x4 ob = to_bf16x4(o[0], o[1], o[2], o[3]);
         *(bf16x4*)(dz_o + row * H + c) = ob;
         if (has_dx) {
@@ -700,8 +724,10 @@ extern "C" int spmm_ln_fwd_r32(const void* x, const float* res32, const float* g
 extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, long rows, int H,
                            float dropout_p, const uint64_t* seed_ptr, uint64_t salt, int drop_on_dy, float* dxsum, const int* rows_dev,
-                           hipStream_t stream) {
+                           const float* beta_from_y, hipStream_t stream) {
   SPMM_CHECK_SHAPE(rows > 0 && H > 0 && H % 4 == 0 && H <= 1024, "spmm_ln_bwd: rows=%ld H=%d", rows, H);
+  SPMM_CHECK_SHAPE(beta_from_y != nullptr || mean != nullptr, "spmm_ln_bwd: the row means are required unless `z` holds the LayerNorm output (beta_from_y)");
+  SPMM_CHECK_SHAPE(beta_from_y == nullptr || !drop_on_dy, "spmm_ln_bwd: the output of a LayerNorm followed by dropout does not determine the normalised values");
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
   static const long gmax = getenv("SPMM_LN_BWD_GRID") ? atol(getenv("SPMM_LN_BWD_GRID")) : 1024;   // 4 workgroups per CU: measured best of 256..4096 (fewer same-address atomics at the end than 2048)
@@ -709,12 +735,18 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
   const float ds = 1.f / (1.f - dropout_p);
   const bool hot = !dy2 && dx && dgamma && dbeta && dxsum && th && !drop_on_dy;
-#define LN_BWD_LAUNCH(NC, EX, HOT)                                                                                                \
-  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX, HOT>), dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, \
-                     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum, rows_dev)
-  if (H == 768 && hot) LN_BWD_LAUNCH(3, true, true);
-  else if (H <= 768) LN_BWD_LAUNCH(3, false, false);
-  else LN_BWD_LAUNCH(4, false, false);
+#define LN_BWD_LAUNCH(NC, EX, HOT, FY)                                                                                                \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX, HOT, FY>), dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)z, \
+                     mean, rstd, gamma, beta_from_y, (bf16*)dz, (bf16*)dx, dgamma, dbeta, rows, H, th, ds, seed_ptr, salt, drop_on_dy, dxsum, rows_dev)
+  if (beta_from_y != nullptr) {
+    if (H == 768 && hot) LN_BWD_LAUNCH(3, true, true, true);
+    else if (H <= 768) LN_BWD_LAUNCH(3, false, false, true);
+    else LN_BWD_LAUNCH(4, false, false, true);
+  } else {
+    if (H == 768 && hot) LN_BWD_LAUNCH(3, true, true, false);
+    else if (H <= 768) LN_BWD_LAUNCH(3, false, false, false);
+    else LN_BWD_LAUNCH(4, false, false, false);
+  }
 #undef LN_BWD_LAUNCH
   SPMM_LAUNCH_CHECK("spmm_ln_bwd");
   return SPMM_OK;

@@ -332,8 +332,13 @@ class Engine:
         rstd = self._new(M, dtype=torch.float32) if save else None
         salt = self._next_salt()
         ops.gemm_nt(A, Wb, x, bias=bias, M_dev=self._md(A))
-        y32 = self._ln_res(x, resid, X32, gamma, beta, y, zout=x if save else None, mean=mean, rstd=rstd, eps=eps, dropout_p=ph, seed=self.seed, salt=salt)
-        return y, x, mean, rstd, salt, y32
+        # The backward recovers the normalised values from the OUTPUT y (spmm_ln_bwd, beta_from_y): the pre-norm sum is not stored -- one
+        # write pass per residual LayerNorm less, and the projection's output buffer is free again at once (EngineOptions.ln_from_y;
+        # the fp32 residual stream keeps the stored sum)
+        from_y = self.opt.ln_from_y and X32 is None
+        y32 = self._ln_res(x, resid, X32, gamma, beta, y, zout=x if (save and not from_y) else None, mean=mean, rstd=rstd, eps=eps, dropout_p=ph,
+                           seed=self.seed, salt=salt)
+        return y, (None if from_y else x), mean, rstd, salt, y32
 
     def _attn_block_fwd(self, pfx, c, X, groups, save, cross, X32=None):
         """BertAttention.forward xbert.py:401-422 on a token batch.  cross=True uses g.kv as key/value source.
@@ -441,12 +446,12 @@ class Engine:
                 sv["lse"].append(lse)
                 sv["salt_a"].append(salt)
             if fused:
-                sv.update(ctx=ctx, z=z, mean=mean, rstd=rstd, salt_h=salt_h)
+                sv.update(ctx=ctx, z=z, y=y, mean=mean, rstd=rstd, salt_h=salt_h)
                 return y, (sv if save else None), None
         y, x, mean, rstd, salt, y32 = self._proj_ln(ctx, P.wb(pfx + ".output.dense.weight"), P.w(pfx + ".output.dense.bias"), X, X32,
                                                     P.w(pfx + ".output.LayerNorm.weight"), P.w(pfx + ".output.LayerNorm.bias"), save=save,
                                                     eps=c.layer_norm_eps, ph=ph)
-        sv.update(ctx=ctx, z=x, mean=mean, rstd=rstd, salt_h=salt)
+        sv.update(ctx=ctx, z=x, y=y, mean=mean, rstd=rstd, salt_h=salt)
         return y, (sv if save else None), y32
 
     def _attn_block_bwd(self, pfx, c, sv, dY, groups, dkv_acc):
@@ -457,9 +462,11 @@ class Engine:
         pa, ph = self._p_attn(c), self._p_hidden(c)
         dz = self._new(M, H)
         dx = self._new(M, H) if ph > 0 else dz
-        ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(pfx + ".output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
+        from_y = sv["z"] is None                          # (the forward kept no pre-norm sum: normalised values from the output, _proj_ln)
+        ops.ln_bwd(dY, sv["y"] if from_y else sv["z"], sv["mean"], sv["rstd"], P.w(pfx + ".output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(pfx + ".output.LayerNorm.weight"), dbeta=P.g(pfx + ".output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt_h"], dxsum=P.g(pfx + ".output.dense.bias"), rows_dev=self._md(dY))
+                   seed=self.seed, salt=sv["salt_h"], dxsum=P.g(pfx + ".output.dense.bias"), rows_dev=self._md(dY),
+                   beta_from_y=P.w(pfx + ".output.LayerNorm.bias") if from_y else None)
         self._wgrad(dx, sv["ctx"], P.g(pfx + ".output.dense.weight"))
         dctx = self._new(M, H)
         ops.gemm_nt(dx, self._wT(pfx + ".output.dense", P.w(pfx + ".output.dense.weight")), dctx, M_dev=self._md(dx))
@@ -543,7 +550,7 @@ class Engine:
         y, x, mean, rstd, salt, y32 = self._proj_ln(h, P.wb(lp + "output.dense.weight"), P.w(lp + "output.dense.bias"), a, a32,
                                                     P.w(lp + "output.LayerNorm.weight"), P.w(lp + "output.LayerNorm.bias"), save=save,
                                                     eps=c.layer_norm_eps, ph=self._p_hidden(c))
-        sv = dict(att=sv1, cross=sv2, a=a, h=h, dact=dact, z=x, mean=mean, rstd=rstd, salt=salt) if save else None
+        sv = dict(att=sv1, cross=sv2, a=a, h=h, dact=dact, z=x, y=y, mean=mean, rstd=rstd, salt=salt) if save else None
         return y, sv, y32
 
     def _layer_bwd(self, lp, c, sv, dY, groups, dkv_acc):
@@ -551,9 +558,11 @@ class Engine:
         ph = self._p_hidden(c)
         dz = self._new(M, H)
         dx = self._new(M, H) if ph > 0 else dz
-        ops.ln_bwd(dY, sv["z"], sv["mean"], sv["rstd"], P.w(lp + "output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
+        from_y = sv["z"] is None
+        ops.ln_bwd(dY, sv["y"] if from_y else sv["z"], sv["mean"], sv["rstd"], P.w(lp + "output.LayerNorm.weight"), dz, dx=dx if ph > 0 else None,
                    dgamma=P.g(lp + "output.LayerNorm.weight"), dbeta=P.g(lp + "output.LayerNorm.bias"), dropout_p=ph,
-                   seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"), rows_dev=self._md(dY))
+                   seed=self.seed, salt=sv["salt"], dxsum=P.g(lp + "output.dense.bias"), rows_dev=self._md(dY),
+                   beta_from_y=P.w(lp + "output.LayerNorm.bias") if from_y else None)
         self._wgrad(dx, sv["h"], P.g(lp + "output.dense.weight"))
         dpre = self._new(M, I)
         ops.gemm_nt(dx, self._wT(lp + "output.dense", P.w(lp + "output.dense.weight")), dpre,

@@ -184,10 +184,11 @@ def ln_fwd_r32(x, res32, gamma, beta, y, *, y32=None, zout=None, mean=None, rstd
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, *, dy2=None, dx=None, dgamma=None, dbeta=None, dropout_p=0.0, seed=None, salt=0,
-           drop_on_dy=False, dxsum=None, rows_dev=None):
+           drop_on_dy=False, dxsum=None, rows_dev=None, beta_from_y=None):
+    """beta_from_y: `z` is the LayerNorm's OUTPUT y; the normalised values are recovered as (y - beta) / gamma (mean may be None)."""
     rows, H = dy.shape
     _call("spmm_ln_bwd", _p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
-               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _p(dxsum), _p(rows_dev), _st())
+               rows, H, float(dropout_p), _p(seed), salt, int(drop_on_dy), _p(dxsum), _p(rows_dev), _p(beta_from_y), _st())
     return dz
 
 

@@ -17,6 +17,7 @@ _ENV = {
     "multi_stream": ("SPMM_STREAMS", lambda s: s != "1"),
     "wgrad_stream": ("SPMM_WGRAD_STREAM", lambda s: s != "0"),
     "pv_wgrad_inline": ("SPMM_PV_WGRAD_INLINE", int),
+    "ln_from_y": ("SPMM_LN_FROM_Y", lambda s: s != "0"),
     "resid_fp32": ("SPMM_RESID_FP32", lambda s: s == "1"),
     "fused_xattn": ("SPMM_FUSED_XATTN", lambda s: {"0": "off", "1": "all"}.get(s, s)),
     "grad_overlap": ("SPMM_GRAD_OVERLAP", lambda s: s != "0"),
@@ -39,6 +40,9 @@ class EngineOptions:
     pv_wgrad_inline: int = 3      # ... except those of the PV encoder's first `n` layers (the LAST its backward reaches), which stay on that chain's
     #                               own stream: it ends ~2 ms before the text encoder's on the side stream, and the one weight-gradient stream,
     #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10)
+    ln_from_y: bool = True        # the residual LayerNorms keep no pre-norm sum for the backward: spmm_ln_bwd recovers the normalised values from the
+    #                               OUTPUT, (y - beta) / gamma -- one 131-MB write per LayerNorm less at the benchmark shape (-0.5 ms per step), same
+    #                               rounding budget (one bf16 tensor read either way; EXPERIMENTS.md 4.8).  False = the stored sum (rounds 1-5)
     fused_xattn: str = "nograd"   # cross-attention block forward as ONE row-panel launch (csrc/xattn.hip: core + output projection + dropout + residual +
     #                               LayerNorm): "nograd" = the passes that keep no tape (momentum fusion pass, inference facades) -- 52.88 vs 53.01 ms
     #                               per step in three alternating pairs, profiles/r06_xattn_modes.txt; "all" = the taped passes too (53.00: no gain

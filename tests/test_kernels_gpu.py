@@ -766,6 +766,56 @@ def test_layernorm_fwd_bwd(ops, rows, H):
     close(db, b.grad, 2e-2 * math.sqrt(rows), 1e-2, "ln dbeta")
 
 
+@pytest.mark.parametrize("rows,H,p", [(1000, 768, 0.1), (1003, 768, 0.0), (333, 256, 0.1), (61, 512, 0.0), (5, 1000, 0.1), (20000, 768, 0.1)])
+def test_layernorm_backward_from_the_output(ops, rows, H, p):
+    """spmm_ln_bwd with `beta_from_y`: the forward keeps NO pre-norm sum; the backward reads the LayerNorm's output y and recovers the
+    normalised values as (y - beta) / gamma.  Against fp32 autograd through the exact sum, next to the stored-sum form on the same inputs:
+    dz, dx (same dropout mask), dgamma, dbeta and the bias-gradient column sums must be as close as the stored-sum form's (one bf16-rounded
+    tensor is read either way), incl. a channel with gamma == 0 (no information about the normalised value there: it contributes nothing)."""
+    x, res = rnd(rows, H, seed=60), rnd(rows, H, seed=61)
+    gamma = (1 + 0.2 * torch.randn(H)).cuda()
+    gamma[7] = 0.0
+    gamma[11] = -0.03
+    beta = (0.2 * torch.randn(H)).cuda()
+    seed = torch.full((1,), 4242, dtype=torch.int64, device="cuda")
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.ln_fwd(x, res, gamma, beta, y, zout=z, mean=mean, rstd=rstd, eps=1e-12, dropout_p=p, seed=seed, salt=9)
+    y_only = torch.empty_like(x)
+    rstd2 = torch.empty(rows, device="cuda")
+    ops.ln_fwd(x, res, gamma, beta, y_only, zout=None, mean=torch.empty(rows, device="cuda"), rstd=rstd2, eps=1e-12, dropout_p=p, seed=seed, salt=9)
+    assert torch.equal(y_only, y) and torch.equal(rstd2, rstd)                      # the forward without the stored sum writes the same output
+    dy = rnd(rows, H, seed=62)
+    out = {}
+    for mode in ("z", "y"):
+        dz, dx = torch.empty_like(x), torch.empty_like(x)
+        dg, db, dxs = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        ops.ln_bwd(dy, z if mode == "z" else y, mean if mode == "z" else None, rstd, gamma, dz, dx=dx if p > 0 else None, dgamma=dg, dbeta=db, dxsum=dxs,
+                   dropout_p=p, seed=seed, salt=9, beta_from_y=beta if mode == "y" else None)
+        out[mode] = (dz, dx if p > 0 else dz, dg, db, dxs)
+    # fp32 reference from the UNROUNDED sum the kernel formed (z is its bf16 copy: use the stored copy's fp32 value + the forward's statistics)
+    zr = z.float().requires_grad_(True)
+    g = gamma.clone().requires_grad_(True)
+    b = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(zr, (H,), g, b, 1e-12).backward(dy.float())
+    keep = out["z"][1].float() != 0 if p > 0 else None
+    usual = torch.ones(H, dtype=torch.bool, device="cuda")
+    usual[7] = usual[11] = False                            # gamma == 0 and |gamma| = 0.03: looked at separately below
+    for i, nm in enumerate(("dz", "dx", "dgamma", "dbeta", "dxsum")):
+        a_z, a_y = out["z"][i].float(), out["y"][i].float()
+        ref = {"dz": zr.grad, "dgamma": g.grad, "dbeta": b.grad}.get(nm, a_z)          # dx / dxsum: same mask, the two forms against each other
+        sel = (lambda t: t[usual]) if nm in ("dgamma", "dbeta", "dxsum") else (lambda t: t[:, usual])
+        scale = sel(ref).abs().max().item() + 1e-6
+        e_z, e_y = (sel(a_z) - sel(ref)).abs().max().item() / scale, (sel(a_y) - sel(ref)).abs().max().item() / scale
+        print(f"  {nm}: relative max error stored-sum form {e_z:.2e}, from-output form {e_y:.2e}")
+        assert e_y < 2.0 * e_z + 1.2e-2, (nm, e_z, e_y)
+    assert float(out["y"][2][7]) == 0.0                     # gamma == 0: the output says nothing about xhat, the channel's d(gamma) is reported as 0
+    sc = g.grad.abs().max().item()
+    assert abs(float(out["y"][2][11]) - float(g.grad[11])) < 0.15 * sc       # |gamma| = 0.03: the rounding of y is amplified 1 / |gamma| times
+    if p > 0:
+        assert torch.equal(out["y"][1].float() != 0, keep) or ((out["y"][1].float() != 0) ^ keep).float().mean().item() < 1e-3   # same dropout mask (zeros of dz aside)
+
+
 def test_layernorm_dropout_masks_match(ops):
     rows, H, p = 256, 768, 0.1
     x = torch.ones(rows, H, dtype=BF, device="cuda")
