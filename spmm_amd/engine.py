@@ -169,6 +169,8 @@ class Engine:
         # binding there: what decides is whether a data-parallel exchange will run, not whether torch.distributed is initialised.)
         dist_ = torch.distributed
         will_exchange = dist_.is_available() and dist_.is_initialized() and (dist_.get_world_size() > 1 or self.opt.force_dist)
+        # data-parallel runs with EngineOptions.dp_four_streams: the momentum chains share side stream 0 with the text student chain
+        self._one_side = bool(will_exchange and self.opt.dp_four_streams)
         if self.multi_stream and torch.device(device).type == "cuda" and not ops._DRY_RUN and not will_exchange:
             streams.bind_in_order(device, ("side0", "side1", "wgrad"))
         self.force_one_stream = False     # set by the data-parallel schedule check (model.py::_schedule_check)
@@ -186,7 +188,7 @@ class Engine:
         """-> side stream `which` that waits for everything enqueued so far on the current stream (None: single-stream mode)."""
         if not self.multi_stream or self._one_stream or self.dev.type != "cuda" or ops._DRY_RUN:
             return None
-        side = streams.get(self.dev, f"side{which}")        # process-wide: every model of a process shares the same streams
+        side = streams.get(self.dev, "side0" if self._one_side else f"side{which}")        # process-wide: every model of a process shares the same streams
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         side.wait_event(ev)
@@ -595,8 +597,18 @@ class Engine:
     def _layer_done(self, prefix):
         """Hand a finished layer's slice to the gradient exchange.  While slices are exchanged the weight gradients run on the
         backward's own stream (SPMM.fused_step), so the stream calling this is ordered behind every writer of the slice."""
-        self.wgrad_join()
-        return self.layer_done_cb(prefix)
+        ws = self._wg_stream if (self._wg_pending and self.wgrad_async) else None
+        if ws is None:
+            self.wgrad_join()
+            return self.layer_done_cb(prefix)
+        # asynchronous weight gradients beside the exchange (EngineOptions.dp_four_streams): the slice is final once the weight-gradient stream
+        # AND the stream this layer's backward ran on are done with it -- the collective is issued from the weight-gradient stream behind an
+        # event on the current one (ProcessGroupNCCL orders RCCL's stream behind the issuing stream); the backward itself does not wait
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            return self.layer_done_cb(prefix)
 
     # --------------------------------------------------------------------------------------------- embeddings
     def embed_text(self, pfx, c, ids32, nseq, L, save):

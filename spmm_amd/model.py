@@ -343,7 +343,7 @@ class SPMM(_Base):
         eng.gscale.fill_(1.0)
         # (single rank only: beside RCCL's stream the weight-gradient stream shares a hardware slot with the caller's stream -- queue index
         #  4 = 0 mod 4 -- and two streams that wait for each other there run the step at 74-76 ms instead of 57, profiles/r06_dp_one_rank.txt)
-        eng._off_path_ok = grad_sync is None
+        eng._off_path_ok = grad_sync is None or (self.options.dp_four_streams and getattr(grad_sync, "exclusive", True) is False)
         eng.off_path(lambda: ops.zero_(self.store.grad))        # nothing reads or writes a gradient before the backward
         dev = self.device_
         losses = eng.forward(prop.to(dev), ids.to(dev), mask.to(dev), mpm_mask=mpm_mask, neg_idx=neg_idx, gather=self._gather_fn(),

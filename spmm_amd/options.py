@@ -24,6 +24,7 @@ _ENV = {
     "grad_wire": ("SPMM_GRAD_WIRE", str),
     "nt_under_comm": ("SPMM_NT_UNDER_COMM", str),
     "force_dist": ("SPMM_FORCE_DIST", lambda s: s == "1"),
+    "dp_four_streams": ("SPMM_DP_FOUR_STREAMS", lambda s: s != "0"),
     "probe_streams": ("SPMM_PROBE_STREAMS", lambda s: s != "0"),
     "schedule_check": ("SPMM_SCHEDULE_CHECK", lambda s: s != "0"),
 }
@@ -54,6 +55,12 @@ class EngineOptions:
     grad_wire: str = "fp32"       # "fp32": all-reduce on the arena; "bf16": cast + reduce-scatter + all-gather (half the link bytes)
     nt_under_comm: str = "tiles"  # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile) or "persistent"
     force_dist: bool = False      # run the N>1 code path with a one-rank process group (tests on a one-GPU box)
+    dp_four_streams: bool = True  # data-parallel schedule on FOUR streams -- caller, RCCL's, ONE side stream (text student and momentum chains share it),
+    #                               weight-gradient -- so that no two of them share a hardware slot (streams take slots by first use, index mod 4): the
+    #                               asynchronous weight-gradient stream and the off-path maintenance then run beside the exchange as on a single rank,
+    #                               and a layer's slice is handed to RCCL from the weight-gradient stream (behind an event on the backward's stream)
+    #                               instead of stalling the backward until its weight gradients are done.  False = round 5's schedule (five streams,
+    #                               the weight-gradient stream idle during the exchange)
     schedule_check: bool = True   # data-parallel runs try both schedules during their first 16 steps with an exchange (3 + 3 warm-up steps, then
     #                               5 + 5 timed steps alternating) and keep the single stream only if its median is >= 13 % faster: the stream-order
     #                               dependent 80-ms mode of EXPERIMENTS.md 1.4 cannot be ruled out on a node this package has never run on

@@ -90,7 +90,7 @@ class OverlappedGradSync:
         self.tiles_under_comm = opt.nt_under_comm != "persistent"
         # The exchange is the only stream beside the backward chain: the asynchronous weight-gradient stream rests meanwhile
         # (three chip-filling streams side by side ran the step in 76-78 ms against 61-62)
-        self.exclusive = True
+        self.exclusive = not opt.dp_four_streams      # (four streams: no two share a hardware slot, the weight-gradient stream keeps running)
         self.wait_events = None      # set to [] to record, per step, an event pair around finish()'s wait on the compute stream: the
         #                              communication time the backward did NOT hide (bench.py `comm_exposed_ms`)
 
@@ -178,9 +178,10 @@ def grad_sync_fn(store=None, options: Optional[EngineOptions] = None):
                 # side0, side1, wgrad).  A stream gets its queue at its first use and there are only a handful: orders that make
                 # RCCL's stream share one with a stream it exchanges dependencies with run the step at 79-87 ms instead of 60.5
                 # (EXPERIMENTS.md 2.7b, profiles/r04_stream_order.txt).
-                streams.bind_in_order(dev, ("side0", "side1", "wgrad"))
+                order = ("side0", "wgrad") if opt.dp_four_streams else ("side0", "side1", "wgrad")
+                streams.bind_in_order(dev, order)
             streams.note(f"cuda:{dev}: first collective issued " + ("AFTER the compute side streams existed (an order EXPERIMENTS.md 2.7b measured slow is possible)"
-                                                                     if late else "first, then side0, side1, wgrad bound to hardware queues in that order"))
+                                                                     if late else f"first, then {', '.join(order)} bound to hardware queues in that order"))
             if late:
                 import warnings
                 warnings.warn("spmm_amd: HIP side streams were created before the first RCCL collective; create the process group and "
