@@ -375,15 +375,19 @@ class SPMM(_Base):
             check.record(torch.cuda.current_stream())
         return losses
 
-    # Data-parallel runs only (EngineOptions.schedule_check): the first SCHEDULE_CHECK_STEPS steps THAT CARRY A GRADIENT EXCHANGE try both
-    # schedules -- 3 steps on the side streams and 3 on one stream to warm up (allocator pools grow while batches of new packed sizes
-    # arrive), then 10 timed steps ALTERNATING between the two (five samples each, neither schedule always measured on the warmer clocks /
-    # pools) -- and the faster one runs from then on, the single stream only if its median wins by 13 % or more.  On every node measured so
-    # far the three-stream schedule is 5-9 % faster; with some orders of stream creation next to RCCL's stream it runs at 80 ms instead of
-    # 60 (EXPERIMENTS.md 1.4), and this package has never run next to a multi-rank communicator.  Both schedules give the same results
-    # bit for bit; the events are read once, at the decision, which is logged with both medians (streams.log()).
-    SCHEDULE_CHECK_STEPS = 16
-    _SCHED_WARM = (3, 3)              # untimed warm-up steps: three streams, then one stream
+    # Data-parallel runs only (EngineOptions.schedule_check): the first SCHEDULE_CHECK_STEPS steps THAT CARRY A GRADIENT EXCHANGE try the
+    # schedules this package cannot choose between without the node it runs on -- 4 steps on the side streams and 4 on one stream to warm up
+    # (allocator pools grow while batches of new packed sizes arrive), then timed steps ROTATING between the candidates (four samples each,
+    # none always measured on the warmer clocks / pools): "three streams" (side streams, NT GEMMs one workgroup per tile under the exchange),
+    # "one stream", and -- with EngineOptions.nt_under_comm = "auto" -- "three streams, persistent NT" (faster by 1.3 ms per step when the
+    # collectives' kernels are short, slower when ring kernels hold CUs for milliseconds: DESIGN.md 6).  The fastest of the two multi-stream
+    # forms runs from then on (the persistent one only if its median wins by >= 1.5 %), the single stream only if ITS median wins by 13 % or
+    # more (with some orders of stream creation next to RCCL's stream the multi-stream step ran at 80 ms instead of 60, EXPERIMENTS.md 1.4;
+    # this package has never run next to a multi-rank communicator).  All candidates give the same results bit for bit; the events are read
+    # once, at the decision, which is logged with the medians (streams.log()).
+    _SCHED_WARM = (4, 4)              # untimed warm-up steps: three streams, then one stream
+    _SCHED_SAMPLES = 4                # timed samples per candidate
+    SCHEDULE_CHECK_STEPS = 8 + 3 * 4  # (two candidates when nt_under_comm is not "auto": the last third of the steps then re-times "three streams")
 
     def _schedule_check_begin(self, grad_sync):
         eng = self.engine
@@ -392,41 +396,52 @@ class SPMM(_Base):
         st = getattr(self, "_sched", None)
         if st is None:
             on = (eng.opt.schedule_check and eng.multi_stream and self.device_.type == "cuda" and not getattr(ops, "_DRY_RUN", False))
-            st = self._sched = {"n": 0, "on": on, "ev": []}
+            cands = ["three streams", "one stream"] + (["three streams, persistent NT"] if getattr(grad_sync, "nt_auto", False) else ["three streams"])
+            st = self._sched = {"n": 0, "on": on, "ev": [], "cands": cands, "tiles0": getattr(grad_sync, "tiles_under_comm", True)}
         if not st["on"]:
             return None
         n = st["n"]
         w3, w1 = self._SCHED_WARM
         if n >= self.SCHEDULE_CHECK_STEPS:
-            ms = {"three streams": [], "one stream": []}
+            ms = {}
             for e0, e1, which in st["ev"]:
                 e1.synchronize()
-                ms[which].append(e0.elapsed_time(e1))
-            multi, single = (sorted(v)[len(v) // 2] for v in (ms["three streams"], ms["one stream"]))
+                ms.setdefault(which, []).append(e0.elapsed_time(e1))
+            med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+            names = sorted(med)
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 # the step ends when the slowest rank does: every rank decides on the slowest rank's medians (and so decides the same)
-                both = torch.tensor([multi, single], dtype=torch.float32, device=self.device_)
-                dist.all_reduce(both, op=dist.ReduceOp.MAX)
-                multi, single = float(both[0]), float(both[1])
-            keep_single = single <= 0.87 * multi
+                t = torch.tensor([med[k] for k in names], dtype=torch.float32, device=self.device_)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                med = {k: float(t[i]) for i, k in enumerate(names)}
+            multi, single = med["three streams"], med["one stream"]
+            pers = med.get("three streams, persistent NT")
+            keep_persistent = pers is not None and pers <= 0.985 * multi
+            best_multi = pers if keep_persistent else multi
+            keep_single = single <= 0.87 * best_multi
             eng.force_one_stream = keep_single
+            if hasattr(grad_sync, "tiles_under_comm"):
+                grad_sync.tiles_under_comm = st["tiles0"] and not keep_persistent
             st["on"], st["ev"] = False, []
-            st["decision"] = {"three_streams_ms": round(multi, 2), "one_stream_ms": round(single, 2), "samples_each": len(ms["one stream"]),
-                              "kept": "one stream" if keep_single else "three streams"}
+            kept = "one stream" if keep_single else ("three streams, persistent NT" if keep_persistent else "three streams")
+            st["decision"] = {"three_streams_ms": round(multi, 2), "one_stream_ms": round(single, 2),
+                              "three_streams_persistent_nt_ms": None if pers is None else round(pers, 2),
+                              "samples_each": min(len(v) for v in ms.values()), "kept": kept}
             from . import streams
-            streams.note(f"schedule check: median {multi:.1f} ms on three streams, {single:.1f} ms on one ({len(ms['one stream'])} alternating samples each) -> "
-                         + ("ONE stream kept" if keep_single else "three streams kept"))
+            streams.note("schedule check: medians " + ", ".join(f"{k} {v:.1f} ms" for k, v in sorted(med.items())) + f" -> {kept} kept")
             return None
         st["n"] = n + 1
         if n < w3 + w1:
             eng.force_one_stream = n >= w3
             return None
-        single = (n - w3 - w1) % 2 == 1
-        eng.force_one_stream = single
+        which = st["cands"][(n - w3 - w1) % 3]
+        eng.force_one_stream = which == "one stream"
+        if hasattr(grad_sync, "tiles_under_comm"):
+            grad_sync.tiles_under_comm = st["tiles0"] and which != "three streams, persistent NT"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
-        st["ev"].append((e0, e1, "one stream" if single else "three streams"))
+        st["ev"].append((e0, e1, which))
         return e1
 
     def schedule_decision(self):

@@ -53,7 +53,10 @@ class EngineOptions:
     # --- data parallelism (spmm_amd/parallel.py) ---
     grad_overlap: bool = True     # per-layer gradient exchange issued during the backward; False = one bucketed all-reduce after it
     grad_wire: str = "fp32"       # "fp32": all-reduce on the arena; "bf16": cast + reduce-scatter + all-gather (half the link bytes)
-    nt_under_comm: str = "tiles"  # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile) or "persistent"
+    nt_under_comm: str = "auto"   # NT GEMM launch form while collectives hold CUs: "tiles" (one workgroup per tile: +3-8 % beside a kernel that holds CUs),
+    #                               "persistent" (+30-55 % there, but 1.3 ms per step faster when the collectives are short: 1.026 x instead of 1.051 x of
+    #                               the plain step with a one-rank group) or "auto": start on "tiles" and let the data-parallel schedule check time both
+    #                               on the node it runs on (bit-identical results either way)
     force_dist: bool = False      # run the N>1 code path with a one-rank process group (tests on a one-GPU box)
     dp_four_streams: bool = True  # data-parallel schedule on FOUR streams -- caller, RCCL's, ONE side stream (text student and momentum chains share it),
     #                               weight-gradient -- so that no two of them share a hardware slot (streams take slots by first use, index mod 4): the
@@ -61,8 +64,9 @@ class EngineOptions:
     #                               and a layer's slice is handed to RCCL from the weight-gradient stream (behind an event on the backward's stream)
     #                               instead of stalling the backward until its weight gradients are done.  False = round 5's schedule (five streams,
     #                               the weight-gradient stream idle during the exchange)
-    schedule_check: bool = True   # data-parallel runs try both schedules during their first 16 steps with an exchange (3 + 3 warm-up steps, then
-    #                               5 + 5 timed steps alternating) and keep the single stream only if its median is >= 13 % faster: the stream-order
+    schedule_check: bool = True   # data-parallel runs time their candidate schedules during their first 20 steps with an exchange (4 + 4 warm-up steps, then
+    #                               twelve timed steps rotating between the candidates: SPMM._schedule_check_begin) and keep the single stream only if its
+    #                               median is >= 13 % faster, the persistent NT launch (nt_under_comm = auto) only if >= 1.5 % faster: the stream-order
     #                               dependent 80-ms mode of EXPERIMENTS.md 1.4 cannot be ruled out on a node this package has never run on
     #                               (results are identical either way; bench.py runs these steps before its warm-up)
     probe_streams: bool = False   # diagnostic: at start-up of a data-parallel run, check that RCCL's stream and the compute streams sit on
@@ -83,8 +87,8 @@ class EngineOptions:
             raise ValueError(f"fused_xattn must be off, nograd or all, not {o.fused_xattn!r}")
         if o.grad_wire not in ("fp32", "bf16"):
             raise ValueError(f"grad_wire must be fp32 or bf16, not {o.grad_wire!r}")
-        if o.nt_under_comm not in ("tiles", "persistent"):
-            raise ValueError(f"nt_under_comm must be tiles or persistent, not {o.nt_under_comm!r}")
+        if o.nt_under_comm not in ("tiles", "persistent", "auto"):
+            raise ValueError(f"nt_under_comm must be tiles, persistent or auto, not {o.nt_under_comm!r}")
         return o
 
     def replace(self, **kw) -> "EngineOptions":

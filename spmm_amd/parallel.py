@@ -88,6 +88,7 @@ class OverlappedGradSync:
             raise ValueError(f"grad_wire must be fp32 or bf16, not {self.wire!r}")
         # NT GEMMs of the backward as one workgroup per tile while slices are in flight (see SPMM.fused_step)
         self.tiles_under_comm = opt.nt_under_comm != "persistent"
+        self.nt_auto = opt.nt_under_comm == "auto"     # SPMM._schedule_check_begin times the persistent launch too and keeps the faster form
         # The exchange is the only stream beside the backward chain: the asynchronous weight-gradient stream rests meanwhile
         # (three chip-filling streams side by side ran the step in 76-78 ms against 61-62)
         self.exclusive = not opt.dp_four_streams      # (four streams: no two share a hardware slot, the weight-gradient stream keeps running)

@@ -221,7 +221,7 @@ def test_engine_options_from_env_and_overrides(monkeypatch):
     for var, _ in _ENV.values():
         monkeypatch.delenv(var, raising=False)
     o = EngineOptions.from_env()
-    assert o.fused_xattn == "nograd" and o.grad_wire == "fp32" and o.nt_under_comm == "tiles" and o.pack_text and not o.resid_fp32
+    assert o.fused_xattn == "nograd" and o.grad_wire == "fp32" and o.nt_under_comm == "auto" and o.pack_text and not o.resid_fp32
     assert not hasattr(o, "fp8") and not hasattr(o, "fuse_drop_res")
     for spelled, want in (("0", "off"), ("1", "all"), ("off", "off"), ("nograd", "nograd"), ("all", "all")):
         monkeypatch.setenv("SPMM_FUSED_XATTN", spelled)

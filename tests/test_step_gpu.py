@@ -1337,29 +1337,36 @@ def test_rccl_code_path_single_rank(env):
 
 
 def test_data_parallel_schedule_check_times_both_schedules_and_decides(env):
-    """EngineOptions.schedule_check (data-parallel runs): the first 16 steps try the three-stream and the one-stream schedule (6 warm-up, then
-    10 alternating timed steps; bench.py runs them before its warm-up), the decision and its medians are reported in `stream_placement` and
-    `schedule_check`; the losses of the run equal those of a run without the check at
-    the same step count (both schedules give the same results).  One-rank RCCL group."""
+    """EngineOptions.schedule_check (data-parallel runs): the first 20 steps try the three-stream schedule (NT GEMMs one workgroup per tile
+    under the exchange), the one-stream schedule and -- nt_under_comm = "auto", the default -- the three-stream schedule with the persistent
+    NT launch (8 warm-up steps, then 12 timed steps rotating between the three; bench.py runs them before its warm-up); the decision and its
+    medians are reported in `stream_placement` and `schedule_check`; the losses of the run equal those of a run without the check at the same
+    step count (all candidates give the same results).  One-rank RCCL group."""
     import subprocess, sys, json, socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--batch", "8", "--seq-len", "32", "--layers", "2,1,1",
             "--queue", "64", "--no-cpu-baseline", "--no-kernel-timing", "--eval-mode"]
     res = {}
-    for chk in ("1", "0"):
-        cmd = base + ["--warmup", "2" if chk == "1" else "18"]          # 16 check steps + 2 = 18 untimed steps either way
+    for chk in ("1", "0", "tiles"):
+        cmd = base + ["--warmup", "2" if chk != "0" else "22"]          # 20 check steps + 2 = 22 untimed steps either way (bench.py cycles four batches)
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        extra = dict(SPMM_SCHEDULE_CHECK="0" if chk == "0" else "1", **({"SPMM_NT_UNDER_COMM": "tiles"} if chk == "tiles" else {}))
+        envv = {k: v for k, v in os.environ.items() if k != "SPMM_NT_UNDER_COMM"}
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root,
-                             env=dict(os.environ, SPMM_FORCE_DIST="1", SPMM_SCHEDULE_CHECK=chk, MASTER_PORT=str(port)))
+                             env=dict(envv, SPMM_FORCE_DIST="1", MASTER_PORT=str(port), **extra))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         res[chk] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     notes = " | ".join(res["1"].get("stream_placement", []))
     print(notes)
-    assert "schedule check:" in notes and ("three streams kept" in notes or "ONE stream kept" in notes) and res["1"]["schedule_check_steps"] == 16
+    assert "schedule check:" in notes and "kept" in notes and res["1"]["schedule_check_steps"] == 20
     dec = res["1"]["schedule_check"]
-    assert dec["samples_each"] == 5 and dec["kept"] in ("three streams", "one stream") and dec["three_streams_ms"] > 0 and dec["one_stream_ms"] > 0
+    assert dec["samples_each"] == 4 and dec["kept"] in ("three streams", "one stream", "three streams, persistent NT")
+    assert dec["three_streams_ms"] > 0 and dec["one_stream_ms"] > 0 and dec["three_streams_persistent_nt_ms"] > 0
+    dec_t = res["tiles"]["schedule_check"]                               # an explicit launch form is not second-guessed: two candidates only
+    assert dec_t["three_streams_persistent_nt_ms"] is None and dec_t["kept"] in ("three streams", "one stream")
     assert "schedule check:" not in " | ".join(res["0"].get("stream_placement", []))
     np.testing.assert_allclose(res["1"]["losses"], res["0"]["losses"], rtol=3e-3, atol=0)
+    np.testing.assert_allclose(res["tiles"]["losses"], res["0"]["losses"], rtol=3e-3, atol=0)
 
 
 @pytest.mark.parametrize("case", ["min_len", "full_len_128", "odd_33", "mask_holes", "one_long_rest_short"])
