@@ -38,9 +38,10 @@ class EngineOptions:
     #                               rows stay keys / values of its self-attention.  Packed path only; exact
     multi_stream: bool = True     # independent encoder chains on three HIP streams; False = everything on the caller's stream
     wgrad_stream: bool = True     # weight-gradient GEMMs on a stream of their own (single rank; rests while gradients are exchanged)
-    pv_wgrad_inline: int = 3      # ... except those of the PV encoder's first `n` layers (the LAST its backward reaches), which stay on that chain's
+    pv_wgrad_inline: int = 4      # ... except those of the PV encoder's first `n` layers (the LAST its backward reaches), which stay on that chain's
     #                               own stream: it ends ~2 ms before the text encoder's on the side stream, and the one weight-gradient stream,
-    #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10)
+    #                               fed by both chains, is what the optimiser then waits for (tools/phase_times.py; EXPERIMENTS.md 3.10; round 6 re-swept 2 / 3 / 4 / 5 / 6
+    #                               on the final tree: 4 is best by 0.15-0.2 ms in five of five pairs)
     ln_from_y: bool = True        # the residual LayerNorms keep no pre-norm sum for the backward: spmm_ln_bwd recovers the normalised values from the
     #                               OUTPUT, (y - beta) / gamma -- one 131-MB write per LayerNorm less at the benchmark shape (-0.5 ms per step), same
     #                               rounding budget (one bf16 tensor read either way; EXPERIMENTS.md 4.8).  False = the stored sum (rounds 1-5)
