@@ -730,7 +730,12 @@ extern "C" int spmm_ln_bwd(const void* dy, const void* dy2, const void* z, const
   SPMM_CHECK_SHAPE(beta_from_y == nullptr || !drop_on_dy, "spmm_ln_bwd: the output of a LayerNorm followed by dropout does not determine the normalised values");
   SPMM_CHECK_SHAPE(dropout_p == 0.f || seed_ptr, "spmm_ln_bwd: dropout needs a device seed");
   long g = (rows + 3) / 4;
-  static const long gmax = getenv("SPMM_LN_BWD_GRID") ? atol(getenv("SPMM_LN_BWD_GRID")) : 1024;   // 4 workgroups per CU: measured best of 256..4096 (fewer same-address atomics at the end than 2048)
+  // Grid: every workgroup ends with 3 H same-address atomics (d gamma, d beta, bias-gradient column sums), so fewer, longer workgroups win until the
+  // rows per wave get too few to keep loads in flight: rows / 64 workgroups, between 256 and 512 (round 6, tools/bench_ln.py: 85 k rows 110 -> 100 us,
+  // 28.7 k 44 -> 33-35, 13.8 k 38 -> 21.5 against the fixed 1024 of rounds 2-5).  SPMM_LN_BWD_GRID overrides (tools only).
+  static const long genv = getenv("SPMM_LN_BWD_GRID") ? atol(getenv("SPMM_LN_BWD_GRID")) : 0;
+  long gmax = genv > 0 ? genv : rows / 64;
+  if (genv <= 0) gmax = gmax < 256 ? 256 : (gmax > 512 ? 512 : gmax);
   if (g > gmax) g = gmax;
   const uint32_t th = (uint32_t)(dropout_p * 65536.f + 0.5f);
   const float ds = 1.f / (1.f - dropout_p);
